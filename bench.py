@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py — queries/sec of the dense-retrieval hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2p|c3|c1]
+
+One "step" = one pass of the hot path (ls_search_device: prep -> scan -> select [-> all-gather
+-> merge]) over one batch of synthetic queries, with corpus, queries and outputs resident in HBM.
+
+Workloads (BASELINE.json configs):
+  c2  (default) N=200k d=384 fp32, nq=1,    k=50    HBM-bound     <- the headline metric
+  c3            N=200k d=384 fp16, nq=1024, k=100   MFMA-bound
+  c2p           N=200k d=1024 fp32, nq=1,   k=1000  the reference's real call shape
+  c1            N=10k  d=384 fp32, nq=1,    k=50    the reference's CPU-runnable case
+
+N > 1: the corpus is row-sharded over the ranks (strong scaling: the same corpus, the same
+queries; every rank ends with the identical merged top-k after one RCCL all-gather).
+
+Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+WORKLOADS = {
+    #        n        d     dtype  nq    k
+    "c1": (10_000, 384, "f32", 1, 50),
+    "c2": (200_000, 384, "f32", 1, 50),
+    "c2p": (200_000, 1024, "f32", 1, 1000),
+    "c3": (200_000, 384, "f16", 1024, 100),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA peak
+
+
+def gauss(seed, n, d):
+    x = np.random.default_rng(seed).standard_normal((n, d), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+def algorithmic_bytes(n, d, elem, nq, k):
+    """corpus read once per batch + queries in + (f32 score, i64 row) out."""
+    return n * d * elem + nq * d * 4 + nq * k * 12
+
+
+def cpu_baseline(corpus, queries, k, f16, budget_s=12.0):
+    """The oracle's vectorised build (same source as the checker, -O3 -mavx2 -mfma, OpenMP) timed
+    on this box's host cores on a bounded sample of the same workload. Baseline only."""
+    from oracle import oracle
+
+    cores = len(os.sched_getaffinity(0))
+    oracle.set_num_threads(cores)
+    if f16:
+        corpus = oracle.c_round_f16(corpus)
+    nq = queries.shape[0]
+    sample = queries[: min(nq, 64)]
+    oracle.c_search(corpus, sample[:1], k, f16=False, fast=True)  # warm
+    done, t0 = 0, time.perf_counter()
+    if nq == 1:
+        while time.perf_counter() - t0 < budget_s and done < 2000:
+            oracle.c_search(corpus, sample, k, f16=False, fast=True)
+            done += 1
+        desc = f"{done} single-query searches over the full corpus"
+    else:
+        oracle.c_search(corpus, sample, k, f16=False, fast=True)
+        done = sample.shape[0]
+        desc = f"one batch of {done} of the {nq} queries over the full corpus"
+    dt = time.perf_counter() - t0
+    return {"value": round(done / dt, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": desc + f" ({dt:.1f} s, oracle/flat_ip_ref.c -O3 -mavx2 -mfma OpenMP; "
+                             "faiss is not installed)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from lean_explore_amd import native
+    from lean_explore_amd.index import FlatIPIndex
+    from lean_explore_amd.sharded import ShardedFlatIPIndex, shard_bounds
+
+    n, d, dtype, nq, k = WORKLOADS[args.workload]
+    elem = 2 if dtype == "f16" else 4
+    corpus = gauss(1234, n, d)
+    queries = gauss(5678, nq, d)
+    lo, hi = shard_bounds(n, world, rank)
+    local = FlatIPIndex.from_array(np.ascontiguousarray(corpus[lo:hi]), dtype=dtype,
+                                   device=local_rank, base=lo)
+    index = ShardedFlatIPIndex(local, n)
+    tq = torch.from_numpy(queries).to(dev)
+
+    def step():
+        return index.search_device(tq, k)
+
+    # ---- verification on the very arrays that are timed ------------------------------------
+    recall = None
+    if not args.no_verify and rank == 0:
+        from oracle import oracle
+
+        s, i = step()
+        local.check()
+        nv = min(nq, 16)
+        Dr, Ir = oracle.c_search(corpus, queries[:nv], k, f16=(dtype == "f16"))
+        _, _, S = oracle.np_search(corpus, queries[:nv], k, f16=(dtype == "f16"))
+        rep = oracle.compare_topk(s[:nv].cpu().numpy(), i[:nv].cpu().numpy(), Dr, Ir, S)
+        recall = rep["recall"]
+    elif not args.no_verify:
+        step()
+        local.check()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    local.check()  # synchronises the stream
+    barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([dt, dev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, dev_ms = t.tolist()
+
+    # ---- dominant-kernel duration, HIP events on the search stream (separate pass) ---------
+    local.set_profiling(True)
+    scan_ms = []
+    for _ in range(50):
+        step()
+        torch.cuda.synchronize()
+        scan_ms.append(local.last_kernel_ms()[0])
+    local.set_profiling(False)
+    scan_ms_avg = float(np.mean(scan_ms)) / (nq if nq <= 16 else 1)  # events bracket one query's scan
+    n_local = hi - lo
+    if args.workload == "c3":
+        flops = 2.0 * nq * n_local * d
+        ach = flops / (scan_ms_avg * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F16_PEAK_TF,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TF, 4), "traffic": None}
+    else:
+        ab = algorithmic_bytes(n_local, d, elem, 1, k)
+        ach = ab / (scan_ms_avg * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+    roof["kernel"] = "ls_scan_kernel"
+    roof["kernel_ms"] = round(scan_ms_avg, 5)
+    roof["algorithmic_bytes"] = algorithmic_bytes(n_local, d, elem, 1 if nq <= 16 else nq, k)
+
+    if rank == 0:
+        qps = nq * args.steps / dt
+        out = {
+            "metric": "queries/sec (exact inner-product top-k, recall vs FAISS-flat restatement)",
+            "value": round(qps, 1),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt * 1e3 / args.steps, 5),
+            "device_ms_per_step": round(dev_ms / args.steps, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": dtype,
+            "data": "synthetic (standard-normal rows, L2-normalised; corpus seed 1234, query seed 5678)",
+            "config": {"workload": f"{args.workload}: N={n} d={d} {dtype} nq={nq} k={k}",
+                       "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}"},
+            "recall_at_k": recall,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(corpus, queries, k, dtype == "f16")
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

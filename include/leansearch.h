@@ -1,0 +1,126 @@
+/*
+ * leansearch.h — C ABI of libleansearch.so, the MI355X (gfx950) exact inner-product
+ * top-k search that replaces the FAISS lookup of LeanExplore's local search backend.
+ *
+ * The reference has no FFI of its own for this path: it reaches FAISS through the faiss
+ * Python module, duck-typed on one attribute (reference src/lean_explore/search/engine.py:99).
+ * Each entry point below therefore cites the faiss call (reference file:line) it stands in for.
+ *
+ *   reference call                                                    replaced by
+ *   ---------------------------------------------------------------  -------------------------
+ *   faiss.read_index(path)            search/engine.py:159            ls_create (+ Python loader)
+ *   faiss.IndexFlatIP(d); index.add(x)   extract/index.py:103,116     ls_create
+ *   faiss.normalize_L2(x)             search/engine.py:242            ls_normalize_l2
+ *   index.search(x, k) -> (D, I)      search/engine.py:250            ls_search
+ *   index.ntotal / index.d            tests/extract/index_test.py:172-173   ls_ntotal / ls_dim
+ *
+ * Conventions
+ *   - every function returns LS_OK (0) or a negative LS_ERR_* code and never throws; the message
+ *     for the last failure on the calling thread is available from ls_last_error().
+ *   - the caller owns every buffer it passes. ls_create copies the corpus into HBM and does
+ *     not keep the host pointer.
+ *   - result order is the total order (score descending, row index ascending). Slots past the
+ *     number of valid rows hold index -1 and score -FLT_MAX (IndexFlat's heap-neutral padding,
+ *     which the reference relies on at search/engine.py:254). Rows whose score is NaN or
+ *     <= -FLT_MAX are never returned.
+ *   - ls_search / ls_search_device may be called concurrently on one handle (serialised inside).
+ *   - there is no CPU fallback: with no usable HIP device every compute entry point fails with
+ *     LS_ERR_NO_DEVICE.
+ */
+#ifndef LEANSEARCH_H
+#define LEANSEARCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LS_OK 0
+#define LS_ERR_INVALID_ARG (-1)   /* null pointer, bad shape, unknown dtype/flag              */
+#define LS_ERR_NO_DEVICE (-2)     /* no HIP device / device id out of range                   */
+#define LS_ERR_HIP (-3)           /* a HIP runtime call failed (message has the HIP string)   */
+#define LS_ERR_K_TOO_LARGE (-4)   /* min(k, ntotal) exceeds LS_MAX_K                          */
+#define LS_ERR_OVERFLOW (-5)      /* ls_check: async batched search needs a synchronous redo  */
+
+#define LS_DTYPE_F32 0 /* corpus stored in HBM as fp32 (what the reference stores)           */
+#define LS_DTYPE_F16 1 /* corpus rounded to fp16 in HBM; queries are rounded to fp16 as well, */
+                       /* products are exact, accumulation is fp32                            */
+
+#define LS_FLAG_NORMALIZE 1u /* L2-normalise a private copy of the queries first (fuses          */
+                             /* faiss.normalize_L2, search/engine.py:242, into the search)     */
+#define LS_FLAG_ASYNC 2u     /* ls_search_device only: do not synchronise; see ls_check       */
+
+#define LS_MAX_K 2048 /* same ceiling as FAISS's GPU k-selection; reference uses k = 1000     */
+
+typedef struct ls_index ls_index; /* opaque */
+
+/* Build a flat inner-product index over `n` rows of dimension `d`.
+ * `corpus` is host memory, row-major float32 [n, d] (the layout index.add receives at
+ * reference extract/index.py:71,116). dtype selects the HBM storage (LS_DTYPE_*).
+ * `device` is the HIP device ordinal. n == 0 is allowed (every search returns padding). */
+int ls_create(ls_index** out, const float* corpus, int64_t n, int32_t d, int32_t dtype,
+              int32_t device);
+
+/* As ls_create, but `d_corpus` is device memory on `device`, row-major float32 [n, d]
+ * (used to build multi-GB synthetic shards without a host round trip). */
+int ls_create_from_device(ls_index** out, const void* d_corpus, int64_t n, int32_t d,
+                          int32_t dtype, int32_t device);
+
+void ls_destroy(ls_index* index);
+
+int64_t ls_ntotal(const ls_index* index); /* index.ntotal */
+int32_t ls_dim(const ls_index* index);    /* index.d      */
+int32_t ls_dtype(const ls_index* index);
+int32_t ls_device(const ls_index* index);
+
+/* Offset added to every returned row index (a shard's first global row). Default 0. */
+int ls_set_base(ls_index* index, int64_t base);
+
+/* index.search(x, k): q is host float32 [nq, d]; out_scores host float32 [nq, k];
+ * out_indices host int64 [nq, k]. Synchronous. */
+int ls_search(ls_index* index, const float* q, int64_t nq, int32_t k, uint32_t flags,
+              float* out_scores, int64_t* out_indices);
+
+/* Same search with queries and outputs already in HBM on the index's device; work is queued
+ * on `stream` (a hipStream_t; NULL = default stream). Without LS_FLAG_ASYNC it synchronises
+ * the stream before returning. With LS_FLAG_ASYNC it returns after queueing and the caller
+ * must call ls_check before trusting the results of batched (MFMA path) searches. */
+int ls_search_device(ls_index* index, const void* d_q, int64_t nq, int32_t k, uint32_t flags,
+                     void* d_out_scores, void* d_out_indices, void* stream);
+
+/* Synchronise `stream` and report on the async searches queued since the last ls_check:
+ * LS_OK if all results are exact, LS_ERR_OVERFLOW if some batched query overflowed its
+ * candidate queues (re-issue those searches without LS_FLAG_ASYNC). */
+int ls_check(ls_index* index, void* stream);
+
+/* faiss.normalize_L2(x): in-place row normalisation of host float32 [nq, d];
+ * rows with zero norm are left unchanged. Runs on `device`. */
+int ls_normalize_l2(float* x, int64_t nq, int32_t d, int32_t device);
+
+/* Merge `n_lists` per-shard results (each [nq, k], sorted by the total order, -1 padded)
+ * into the global top-k. All pointers are device memory on `device`:
+ * d_scores_in float32 [n_lists, nq, k], d_indices_in int64 [n_lists, nq, k]
+ * (the layout an RCCL all-gather of per-rank results produces). */
+int ls_merge_topk(const void* d_scores_in, const void* d_indices_in, int32_t n_lists,
+                  int64_t nq, int32_t k, void* d_out_scores, void* d_out_indices,
+                  int32_t device, void* stream);
+
+/* Name and average duration (ms) bookkeeping for bench.py: time of the dominant kernel of the
+ * most recent search, measured with hipEvents on the search's stream when profiling is on. */
+int ls_set_profiling(ls_index* index, int32_t enabled);
+int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
+
+/* Test / tuning hooks. option 0: force the number of keys k' each scan workgroup emits
+ * (0 = automatic); option 1: force the finalize kernel's exact slow path. counter 0: searches whose finalize step took the exact slow path. */
+int ls_debug_option(ls_index* index, int32_t which, int32_t value);
+int64_t ls_debug_counter(ls_index* index, int32_t which);
+
+const char* ls_last_error(void); /* thread-local; valid until the next call on this thread */
+const char* ls_version(void);
+int32_t ls_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEANSEARCH_H */

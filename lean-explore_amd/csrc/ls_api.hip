@@ -1,0 +1,502 @@
+// ls_api.hip — the C ABI of include/leansearch.h: index lifetime, HBM residency, and the
+// host-side orchestration of one search (prep -> scan -> finalize per query).
+//
+// There is deliberately no CPU path in this library: with no HIP device every compute entry
+// point returns LS_ERR_NO_DEVICE.
+#include "ls_common.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+static thread_local char g_err[512] = "";
+
+void ls_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct ls_index {
+    int32_t device = 0;
+    int32_t n_cu = 256;
+    int64_t n = 0;
+    int32_t dtype = 0;
+    int64_t base = 0;
+    ls_geom g{};
+    void* d_corpus = nullptr;
+    std::mutex mu;
+    hipStream_t own_stream = nullptr;
+
+    // scratch (grown on demand, reused by every search on this handle)
+    float* d_qraw = nullptr;   size_t qraw_cap = 0;   // floats
+    float* d_qprep = nullptr;  size_t qprep_cap = 0;  // floats
+    float* d_S = nullptr;                             // n floats
+    u64* d_cand = nullptr;                            // max_blocks * (LS_KP_MAX-1)
+    u64* d_bound = nullptr;                           // max_blocks
+    int32_t max_blocks = 0;
+    float* d_out_s = nullptr;  int64_t* d_out_i = nullptr;  size_t out_cap = 0;  // nq*k
+    u32* d_counters = nullptr;                        // [0] finalize slow-path count
+    float* h_q = nullptr;      size_t h_q_cap = 0;    // pinned
+    float* h_out_s = nullptr;  int64_t* h_out_i = nullptr;  size_t h_out_cap = 0;
+
+    // options / instrumentation
+    int32_t opt_kprime = 0;  // 0 = automatic
+    int32_t opt_force_slow = 0;
+    bool profiling = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+static int check_device(int32_t device) {
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0) {
+        ls_set_error("no HIP device available (%s); libleansearch has no CPU path",
+                     e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return LS_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= cnt) {
+        ls_set_error("device %d out of range (have %d)", device, cnt);
+        return LS_ERR_NO_DEVICE;
+    }
+    return LS_OK;
+}
+
+template <typename T>
+static int grow(T** p, size_t* cap, size_t need) {
+    if (need <= *cap) return LS_OK;
+    if (*p) LS_HIP(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    size_t want = need + need / 2;
+    LS_HIP(hipMalloc((void**)p, want * sizeof(T)));
+    *cap = want;
+    return LS_OK;
+}
+template <typename T>
+static int grow_pinned(T** p, size_t* cap, size_t need) {
+    if (need <= *cap) return LS_OK;
+    if (*p) LS_HIP(hipHostFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    size_t want = need + need / 2;
+    LS_HIP(hipHostMalloc((void**)p, want * sizeof(T), hipHostMallocDefault));
+    *cap = want;
+    return LS_OK;
+}
+
+static int create_common(ls_index** out, int64_t n, int32_t d, int32_t dtype, int32_t device,
+                         ls_index** pidx) {
+    if (!out) {
+        ls_set_error("ls_create: out is null");
+        return LS_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    if (n < 0 || d <= 0) {
+        ls_set_error("ls_create: bad shape n=%lld d=%d", (long long)n, d);
+        return LS_ERR_INVALID_ARG;
+    }
+    if (n >= 0xffffffffll) {
+        ls_set_error("ls_create: n=%lld exceeds the 2^32-1 rows one shard can index", (long long)n);
+        return LS_ERR_INVALID_ARG;
+    }
+    ls_geom g;
+    if (ls_pick_geom(d, dtype, &g) != LS_OK) {
+        ls_set_error("ls_create: unsupported d=%d / dtype=%d (max stored row is 4096 bytes)", d,
+                     dtype);
+        return LS_ERR_INVALID_ARG;
+    }
+    int rc = check_device(device);
+    if (rc != LS_OK) return rc;
+    LS_HIP(hipSetDevice(device));
+    ls_index* ix = new (std::nothrow) ls_index();
+    if (!ix) {
+        ls_set_error("ls_create: out of host memory");
+        return LS_ERR_INVALID_ARG;
+    }
+    ix->device = device;
+    ix->n = n;
+    ix->dtype = dtype;
+    ix->g = g;
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
+        cu > 0)
+        ix->n_cu = cu;
+    *pidx = ix;
+    return LS_OK;
+}
+
+static int alloc_index_buffers(ls_index* ix) {
+    const size_t row_bytes = (size_t)ix->g.chunks * 16;
+    if (ix->n > 0) LS_HIP(hipMalloc(&ix->d_corpus, (size_t)ix->n * row_bytes));
+    LS_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
+    ix->max_blocks = ls_scan_blocks(ix->n > 0 ? ix->n : 1, ix->g, ix->n_cu);
+    LS_HIP(hipMalloc((void**)&ix->d_S, sizeof(float) * (size_t)(ix->n > 0 ? ix->n : 1)));
+    LS_HIP(hipMalloc((void**)&ix->d_cand, sizeof(u64) * (size_t)ix->max_blocks * LS_KP_MAX));
+    LS_HIP(hipMalloc((void**)&ix->d_bound, sizeof(u64) * (size_t)ix->max_blocks));
+    LS_HIP(hipMalloc((void**)&ix->d_counters, sizeof(u32) * 8));
+    LS_HIP(hipMemset(ix->d_counters, 0, sizeof(u32) * 8));
+    for (int i = 0; i < 3; ++i) LS_HIP(hipEventCreate(&ix->ev[i]));
+    return LS_OK;
+}
+
+extern "C" {
+
+void ls_destroy(ls_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->own_stream) (void)hipStreamSynchronize(ix->own_stream);
+    (void)hipFree(ix->d_corpus);
+    (void)hipFree(ix->d_qraw);
+    (void)hipFree(ix->d_qprep);
+    (void)hipFree(ix->d_S);
+    (void)hipFree(ix->d_cand);
+    (void)hipFree(ix->d_bound);
+    (void)hipFree(ix->d_out_s);
+    (void)hipFree(ix->d_out_i);
+    (void)hipFree(ix->d_counters);
+    if (ix->h_q) (void)hipHostFree(ix->h_q);
+    if (ix->h_out_s) (void)hipHostFree(ix->h_out_s);
+    if (ix->h_out_i) (void)hipHostFree(ix->h_out_i);
+    for (int i = 0; i < 3; ++i)
+        if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
+    if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
+    delete ix;
+}
+
+int ls_create(ls_index** out, const float* corpus, int64_t n, int32_t d, int32_t dtype,
+              int32_t device) {
+    if (n > 0 && !corpus) {
+        ls_set_error("ls_create: corpus is null");
+        return LS_ERR_INVALID_ARG;
+    }
+    ls_index* ix = nullptr;
+    int rc = create_common(out, n, d, dtype, device, &ix);
+    if (rc != LS_OK) return rc;
+    rc = alloc_index_buffers(ix);
+    if (rc == LS_OK && n > 0) {
+        const ls_geom& g = ix->g;
+        if (dtype == LS_DTYPE_F32 && g.d_pad == d) {
+            // stored layout == caller's layout: one straight copy into HBM
+            hipError_t e = hipMemcpy(ix->d_corpus, corpus, (size_t)n * d * sizeof(float),
+                                     hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                ls_set_error("corpus upload failed: %s", hipGetErrorString(e));
+                rc = LS_ERR_HIP;
+            }
+        } else {
+            // upload in slabs of rows through a staging buffer, converting on the device
+            const int64_t slab = std::max<int64_t>(1, (int64_t)(256ll << 20) / ((int64_t)d * 4));
+            float* stage = nullptr;
+            hipError_t e = hipMalloc((void**)&stage, (size_t)std::min(slab, n) * d * sizeof(float));
+            if (e != hipSuccess) {
+                ls_set_error("staging alloc failed: %s", hipGetErrorString(e));
+                rc = LS_ERR_HIP;
+            }
+            for (int64_t r0 = 0; rc == LS_OK && r0 < n; r0 += slab) {
+                const int64_t rows = std::min(slab, n - r0);
+                e = hipMemcpy(stage, corpus + r0 * d, (size_t)rows * d * sizeof(float),
+                              hipMemcpyHostToDevice);
+                if (e != hipSuccess) {
+                    ls_set_error("corpus upload failed: %s", hipGetErrorString(e));
+                    rc = LS_ERR_HIP;
+                    break;
+                }
+                rc = ls_launch_convert(stage, (char*)ix->d_corpus + (size_t)r0 * g.chunks * 16,
+                                       rows, g, ix->own_stream);
+                if (rc == LS_OK && hipStreamSynchronize(ix->own_stream) != hipSuccess) {
+                    ls_set_error("corpus conversion failed");
+                    rc = LS_ERR_HIP;
+                }
+            }
+            if (stage) (void)hipFree(stage);
+        }
+    }
+    if (rc != LS_OK) {
+        ls_destroy(ix);
+        return rc;
+    }
+    *out = ix;
+    return LS_OK;
+}
+
+int ls_create_from_device(ls_index** out, const void* d_corpus, int64_t n, int32_t d,
+                          int32_t dtype, int32_t device) {
+    if (n > 0 && !d_corpus) {
+        ls_set_error("ls_create_from_device: corpus is null");
+        return LS_ERR_INVALID_ARG;
+    }
+    ls_index* ix = nullptr;
+    int rc = create_common(out, n, d, dtype, device, &ix);
+    if (rc != LS_OK) return rc;
+    rc = alloc_index_buffers(ix);
+    if (rc == LS_OK && n > 0) {
+        rc = ls_launch_convert((const float*)d_corpus, ix->d_corpus, n, ix->g, ix->own_stream);
+        if (rc == LS_OK && hipStreamSynchronize(ix->own_stream) != hipSuccess) {
+            ls_set_error("corpus conversion failed");
+            rc = LS_ERR_HIP;
+        }
+    }
+    if (rc != LS_OK) {
+        ls_destroy(ix);
+        return rc;
+    }
+    *out = ix;
+    return LS_OK;
+}
+
+int64_t ls_ntotal(const ls_index* ix) { return ix ? ix->n : -1; }
+int32_t ls_dim(const ls_index* ix) { return ix ? ix->g.d : -1; }
+int32_t ls_dtype(const ls_index* ix) { return ix ? ix->dtype : -1; }
+int32_t ls_device(const ls_index* ix) { return ix ? ix->device : -1; }
+
+int ls_set_base(ls_index* ix, int64_t base) {
+    if (!ix || base < 0) {
+        ls_set_error("ls_set_base: bad argument");
+        return LS_ERR_INVALID_ARG;
+    }
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->base = base;
+    return LS_OK;
+}
+
+}  // extern "C"
+
+// choose k' (keys each scan workgroup emits) from lambda = expected top-k rows per workgroup
+static int pick_kprime(const ls_index* ix, int blocks, int keff) {
+    if (ix->opt_kprime > 0) return std::min(ix->opt_kprime, LS_KP_MAX - 1);
+    const double lam = (double)keff / (double)blocks;
+    int kp = (int)(lam + 5.0 * __builtin_sqrt(lam) + 3.0);
+    kp = std::max(kp, 2);
+    kp = std::min(kp, LS_KP_MAX - 1);
+    while (kp > 1 && (int64_t)blocks * kp > LS_FINAL_CAP) --kp;
+    return kp;
+}
+
+// Queue one search on stream `s`. d_q: device fp32 [nq, d]; outputs device [nq, k].
+static int search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
+                            float* d_out_s, int64_t* d_out_i, hipStream_t s) {
+    const ls_geom& g = ix->g;
+    int rc = grow(&ix->d_qprep, &ix->qprep_cap, (size_t)nq * g.d_pad);
+    if (rc != LS_OK) return rc;
+    rc = ls_launch_prep(d_q, ix->d_qprep, nq, g, (flags & LS_FLAG_NORMALIZE) != 0,
+                        ix->dtype == LS_DTYPE_F16, s);
+    if (rc != LS_OK) return rc;
+    const int64_t keff = std::min<int64_t>(k, ix->n);
+    const int blocks = ls_scan_blocks(ix->n > 0 ? ix->n : 1, g, ix->n_cu);
+    const int kprime = pick_kprime(ix, blocks, (int)std::max<int64_t>(keff, 1));
+    for (int64_t qi = 0; qi < nq; ++qi) {
+        const bool prof = ix->profiling && qi == nq - 1;
+        if (prof) LS_HIP(hipEventRecord(ix->ev[0], s));
+        rc = ls_launch_scan(ix->d_corpus, ix->n, g, ix->d_qprep + qi * g.d_pad, ix->d_S,
+                            ix->d_cand, ix->d_bound, blocks, kprime, s);
+        if (rc != LS_OK) return rc;
+        if (prof) LS_HIP(hipEventRecord(ix->ev[1], s));
+        rc = ls_launch_finalize(ix->d_S, ix->n, ix->d_cand, ix->d_bound, blocks, kprime, k,
+                                ix->base, d_out_s + qi * k, d_out_i + qi * k, ix->d_counters,
+                                ix->opt_force_slow, s);
+        if (rc != LS_OK) return rc;
+        if (prof) {
+            LS_HIP(hipEventRecord(ix->ev[2], s));
+            ix->ev_valid = true;
+        }
+    }
+    return LS_OK;
+}
+
+static int check_search_args(const ls_index* ix, const void* q, int64_t nq, int32_t k,
+                             uint32_t flags, const void* os, const void* oi) {
+    if (!ix) {
+        ls_set_error("search: index is null");
+        return LS_ERR_INVALID_ARG;
+    }
+    if (nq < 0 || k <= 0 || (nq > 0 && (!q || !os || !oi))) {
+        ls_set_error("search: bad argument (nq=%lld k=%d)", (long long)nq, k);
+        return LS_ERR_INVALID_ARG;
+    }
+    if (flags & ~(LS_FLAG_NORMALIZE | LS_FLAG_ASYNC)) {
+        ls_set_error("search: unknown flags 0x%x", flags);
+        return LS_ERR_INVALID_ARG;
+    }
+    if (std::min<int64_t>(k, ix->n) > LS_MAX_K || k > (1 << 20)) {
+        ls_set_error("search: min(k, ntotal) = %lld exceeds LS_MAX_K = %d",
+                     (long long)std::min<int64_t>(k, ix->n), LS_MAX_K);
+        return LS_ERR_K_TOO_LARGE;
+    }
+    return LS_OK;
+}
+
+extern "C" {
+
+int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flags,
+              float* out_scores, int64_t* out_indices) {
+    int rc = check_search_args(ix, q, nq, k, flags & ~LS_FLAG_ASYNC, out_scores, out_indices);
+    if (rc != LS_OK) return rc;
+    if (nq == 0) return LS_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    LS_HIP(hipSetDevice(ix->device));
+    hipStream_t s = ix->own_stream;
+    const size_t qn = (size_t)nq * ix->g.d, on = (size_t)nq * k;
+    if ((rc = grow(&ix->d_qraw, &ix->qraw_cap, qn)) != LS_OK) return rc;
+    if ((rc = grow_pinned(&ix->h_q, &ix->h_q_cap, qn)) != LS_OK) return rc;
+    if (on > ix->out_cap) {
+        size_t c1 = ix->out_cap, c2 = ix->out_cap;
+        if ((rc = grow(&ix->d_out_s, &c1, on)) != LS_OK) return rc;
+        if ((rc = grow(&ix->d_out_i, &c2, on)) != LS_OK) return rc;
+        ix->out_cap = std::min(c1, c2);
+    }
+    if (on > ix->h_out_cap) {
+        size_t c1 = ix->h_out_cap, c2 = ix->h_out_cap;
+        if ((rc = grow_pinned(&ix->h_out_s, &c1, on)) != LS_OK) return rc;
+        if ((rc = grow_pinned(&ix->h_out_i, &c2, on)) != LS_OK) return rc;
+        ix->h_out_cap = std::min(c1, c2);
+    }
+    memcpy(ix->h_q, q, qn * sizeof(float));
+    LS_HIP(hipMemcpyAsync(ix->d_qraw, ix->h_q, qn * sizeof(float), hipMemcpyHostToDevice, s));
+    rc = search_on_stream(ix, ix->d_qraw, nq, k, flags & LS_FLAG_NORMALIZE, ix->d_out_s,
+                          ix->d_out_i, s);
+    if (rc != LS_OK) return rc;
+    LS_HIP(hipMemcpyAsync(ix->h_out_s, ix->d_out_s, on * sizeof(float), hipMemcpyDeviceToHost, s));
+    LS_HIP(hipMemcpyAsync(ix->h_out_i, ix->d_out_i, on * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    LS_HIP(hipStreamSynchronize(s));
+    memcpy(out_scores, ix->h_out_s, on * sizeof(float));
+    memcpy(out_indices, ix->h_out_i, on * sizeof(int64_t));
+    return LS_OK;
+}
+
+int ls_search_device(ls_index* ix, const void* d_q, int64_t nq, int32_t k, uint32_t flags,
+                     void* d_out_scores, void* d_out_indices, void* stream) {
+    int rc = check_search_args(ix, d_q, nq, k, flags, d_out_scores, d_out_indices);
+    if (rc != LS_OK) return rc;
+    if (nq == 0) return LS_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    LS_HIP(hipSetDevice(ix->device));
+    hipStream_t s = (hipStream_t)stream;
+    rc = search_on_stream(ix, (const float*)d_q, nq, k, flags, (float*)d_out_scores,
+                          (int64_t*)d_out_indices, s);
+    if (rc != LS_OK) return rc;
+    if (!(flags & LS_FLAG_ASYNC)) LS_HIP(hipStreamSynchronize(s));
+    return LS_OK;
+}
+
+int ls_check(ls_index* ix, void* stream) {
+    if (!ix) {
+        ls_set_error("ls_check: index is null");
+        return LS_ERR_INVALID_ARG;
+    }
+    std::lock_guard<std::mutex> lk(ix->mu);
+    LS_HIP(hipSetDevice(ix->device));
+    LS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return LS_OK;  // the per-query scan path is exact by construction (finalize slow path)
+}
+
+int ls_normalize_l2(float* x, int64_t nq, int32_t d, int32_t device) {
+    if (nq < 0 || d <= 0 || (nq > 0 && !x)) {
+        ls_set_error("ls_normalize_l2: bad argument");
+        return LS_ERR_INVALID_ARG;
+    }
+    int rc = check_device(device);
+    if (rc != LS_OK) return rc;
+    if (nq == 0) return LS_OK;
+    LS_HIP(hipSetDevice(device));
+    float *din = nullptr, *dout = nullptr;
+    const size_t bytes = (size_t)nq * d * sizeof(float);
+    LS_HIP(hipMalloc((void**)&din, bytes));
+    hipError_t e = hipMalloc((void**)&dout, bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(din);
+        ls_set_error("ls_normalize_l2: hipMalloc failed: %s", hipGetErrorString(e));
+        return LS_ERR_HIP;
+    }
+    ls_geom g{};
+    g.d = d;
+    g.d_pad = d;
+    rc = LS_OK;
+    if (hipMemcpy(din, x, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = LS_ERR_HIP;
+    if (rc == LS_OK) rc = ls_launch_prep(din, dout, nq, g, true, false, nullptr);
+    if (rc == LS_OK && hipMemcpy(x, dout, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = LS_ERR_HIP;
+    if (rc == LS_ERR_HIP) ls_set_error("ls_normalize_l2: HIP copy/launch failed");
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    return rc;
+}
+
+int ls_merge_topk(const void* d_scores_in, const void* d_indices_in, int32_t n_lists, int64_t nq,
+                  int32_t k, void* d_out_scores, void* d_out_indices, int32_t device,
+                  void* stream) {
+    if (n_lists <= 0 || nq < 0 || k <= 0 ||
+        (nq > 0 && (!d_scores_in || !d_indices_in || !d_out_scores || !d_out_indices))) {
+        ls_set_error("ls_merge_topk: bad argument");
+        return LS_ERR_INVALID_ARG;
+    }
+    int rc = check_device(device);
+    if (rc != LS_OK) return rc;
+    LS_HIP(hipSetDevice(device));
+    return ls_launch_merge((const float*)d_scores_in, (const int64_t*)d_indices_in, n_lists, nq, k,
+                           (float*)d_out_scores, (int64_t*)d_out_indices, (hipStream_t)stream);
+}
+
+int ls_set_profiling(ls_index* ix, int32_t enabled) {
+    if (!ix) return LS_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->profiling = enabled != 0;
+    ix->ev_valid = false;
+    return LS_OK;
+}
+
+int ls_last_kernel_ms(ls_index* ix, float* scan_ms, float* total_ms) {
+    if (!ix || !scan_ms || !total_ms) return LS_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (!ix->ev_valid) {
+        ls_set_error("ls_last_kernel_ms: no profiled search recorded");
+        return LS_ERR_INVALID_ARG;
+    }
+    LS_HIP(hipSetDevice(ix->device));
+    LS_HIP(hipEventSynchronize(ix->ev[2]));
+    LS_HIP(hipEventElapsedTime(scan_ms, ix->ev[0], ix->ev[1]));
+    LS_HIP(hipEventElapsedTime(total_ms, ix->ev[0], ix->ev[2]));
+    return LS_OK;
+}
+
+// test / tuning hooks -------------------------------------------------------------------------
+int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
+    if (!ix) return LS_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (which == 0) {  // force k' (0 = automatic)
+        ix->opt_kprime = value;
+        return LS_OK;
+    }
+    if (which == 1) {  // force the finalize kernel's exact slow path
+        ix->opt_force_slow = value != 0;
+        return LS_OK;
+    }
+    ls_set_error("ls_debug_option: unknown option %d", which);
+    return LS_ERR_INVALID_ARG;
+}
+
+int64_t ls_debug_counter(ls_index* ix, int32_t which) {
+    if (!ix || which < 0 || which >= 8) return -1;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (hipSetDevice(ix->device) != hipSuccess) return -1;
+    u32 v = 0;
+    if (hipMemcpy(&v, ix->d_counters + which, sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    return (int64_t)v;
+}
+
+const char* ls_last_error(void) { return g_err; }
+const char* ls_version(void) { return "leansearch-mi355x 0.1.0 (gfx950)"; }
+int32_t ls_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// ls_common.h — shared definitions of libleansearch (gfx950 only).
+//
+// Result keys. Every candidate row is carried as one 64-bit key
+//     key = ord(score) << 32 | (0xffffffff - row)
+// where ord() is the order-preserving map float -> uint32. A larger key is a better result
+// under the library's total order (score descending, row ascending), so every selection,
+// merge and sort below is a plain unsigned 64-bit comparison. key == 0 means "no result"
+// (score NaN or <= -FLT_MAX, padding): FAISS's IndexFlat heap never admits such rows either
+// (its admission test is `score > heap_top`, heap_top initialised to -FLT_MAX).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cfloat>
+
+#include "../../include/leansearch.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define LS_WAVE 64
+#define LS_SCAN_THREADS 256          // 4 waves per scan workgroup
+#define LS_SCAN_WAVES (LS_SCAN_THREADS / LS_WAVE)
+#define LS_KP_MAX 16                 // per-workgroup emitted candidates (k') + 1 bound
+#define LS_FINAL_THREADS 1024
+#define LS_FINAL_CAP 8192            // keys the finalize workgroup sorts in LDS (64 KiB)
+#define LS_SCAN_MAX_NQ 16            // nq <= this: per-query HBM-bound scan path
+
+__host__ __device__ __forceinline__ u32 ls_ord(float f) {
+    f = f + 0.0f;  // folds -0.0 into +0.0
+    u32 u = __builtin_bit_cast(u32, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ls_unord(u32 k) {
+    u32 u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __builtin_bit_cast(float, u);
+}
+__host__ __device__ __forceinline__ u64 ls_make_key(float s, u32 row) {
+    return (s > -FLT_MAX) ? (((u64)ls_ord(s) << 32) | (u64)(0xffffffffu - row)) : 0ull;
+}
+__host__ __device__ __forceinline__ float ls_key_score(u64 key) {
+    return key ? ls_unord((u32)(key >> 32)) : -FLT_MAX;
+}
+__host__ __device__ __forceinline__ int64_t ls_key_index(u64 key, int64_t base) {
+    return key ? base + (int64_t)(0xffffffffu - (u32)(key & 0xffffffffull)) : (int64_t)-1;
+}
+
+// ---- error plumbing (host) -----------------------------------------------------------------
+void ls_set_error(const char* fmt, ...);
+#define LS_HIP(call)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            ls_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                      \
+            return LS_ERR_HIP;                                                           \
+        }                                                                                \
+    } while (0)
+
+// ---- geometry of the HBM-resident corpus -----------------------------------------------------
+// A row is stored as `chunks` 16-byte chunks (4 fp32 or 8 fp16), zero padded so that
+// chunks = L * V with L lanes sharing a row and V chunks per lane.
+struct ls_geom {
+    int32_t d;        // logical dimension
+    int32_t d_pad;    // elements per stored row (multiple of 4 / 8)
+    int32_t chunks;   // 16-byte chunks per stored row
+    int32_t L;        // lanes per row (16, 32 or 64)
+    int32_t V;        // chunks per lane (1..4)
+    int32_t elem;     // bytes per element (4 or 2)
+};
+int ls_pick_geom(int32_t d, int32_t dtype, ls_geom* g);
+
+// ---- kernel launchers (defined in the .hip files) ---------------------------------------------
+// prep: q_out[nq, d_pad] = pad(round(normalise(q_in[nq, d]))), fp32
+int ls_launch_prep(const float* d_q_in, float* d_q_out, int64_t nq, const ls_geom& g,
+                   bool normalize, bool round_f16, hipStream_t s);
+// corpus conversion: dst[n, d_pad] (fp32 or fp16) from src fp32 [n, d]
+int ls_launch_convert(const float* d_src, void* d_dst, int64_t n, const ls_geom& g,
+                      hipStream_t s);
+// scan: scores S[n] for one query + per-workgroup best kprime keys and bound
+int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu);
+int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const float* d_q,
+                   float* d_S, u64* d_cand, u64* d_bound, int32_t blocks, int32_t kprime,
+                   hipStream_t s);
+// finalize: exact top-k from the scan's candidates (or, if they cannot be proven complete,
+// from S itself) -> out_scores[k], out_indices[k]
+int ls_launch_finalize(const float* d_S, int64_t n, const u64* d_cand, const u64* d_bound,
+                       int32_t blocks, int32_t kprime, int32_t k, int64_t base,
+                       float* d_out_scores, int64_t* d_out_indices, u32* d_slow_count,
+                       int32_t force_slow, hipStream_t s);
+// merge of per-shard lists
+int ls_launch_merge(const float* d_scores_in, const int64_t* d_indices_in, int32_t n_lists,
+                    int64_t nq, int32_t k, float* d_out_scores, int64_t* d_out_indices,
+                    hipStream_t s);

@@ -1,0 +1,230 @@
+"""FlatIPIndex — the faiss-shaped object the local search backend holds.
+
+It offers exactly the members the reference uses on its FAISS index
+(reference src/lean_explore/search/engine.py:247-250 and tests/extract/index_test.py:172-173):
+``search(x, k) -> (D, I)``, ``ntotal``, ``d``, ``add(x)``; it has no ``nprobe`` attribute (the
+reference sets it only ``if hasattr(index, "nprobe")``, engine.py:247). All arithmetic happens in
+libleansearch.so on the MI355X; this class only owns the handle and marshals numpy / torch
+buffers across the C ABI.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Any
+
+import numpy as np
+
+from . import native
+
+_DTYPES = {"f32": native.LS_DTYPE_F32, "float32": native.LS_DTYPE_F32,
+           "f16": native.LS_DTYPE_F16, "float16": native.LS_DTYPE_F16}
+
+
+def _dtype_code(dtype: Any) -> int:
+    if isinstance(dtype, int):
+        return dtype
+    try:
+        return _DTYPES[str(np.dtype(dtype)) if not isinstance(dtype, str) else dtype]
+    except (KeyError, TypeError):
+        raise ValueError(f"unsupported storage dtype {dtype!r} (use 'f32' or 'f16')") from None
+
+
+def normalize_L2(x: np.ndarray, device: int = 0) -> None:
+    """In-place row L2 normalisation of a C-contiguous float32 [nq, d] array.
+
+    Counterpart of ``faiss.normalize_L2`` (reference search/engine.py:242): returns None,
+    rows with zero norm are left unchanged.
+    """
+    if not isinstance(x, np.ndarray) or x.dtype != np.float32 or x.ndim != 2 \
+            or not x.flags.c_contiguous:
+        raise ValueError("normalize_L2 expects a C-contiguous float32 array of shape [nq, d]")
+    lib = native.load()
+    native.check(lib.ls_normalize_l2(x.ctypes.data, x.shape[0], x.shape[1], device))
+
+
+class FlatIPIndex:
+    """Exact inner-product index resident in one GPU's HBM."""
+
+    def __init__(self, d: int, dtype: Any = "f32", device: int = 0, base: int = 0):
+        if d <= 0:
+            raise ValueError("d must be positive")
+        self.d = int(d)
+        self._dtype = _dtype_code(dtype)
+        self.device = int(device)
+        self._base = int(base)
+        self._handle: ctypes.c_void_p | None = None
+        self._pending: list[np.ndarray] = []   # rows added since the handle was built
+        self._host_rows: list[np.ndarray] = []  # everything ever added (for re-build / save)
+        self._ntotal = 0
+        self._device_built = False             # built straight from device memory
+        self.is_trained = True
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_array(cls, corpus: np.ndarray, dtype: Any = "f32", device: int = 0,
+                   base: int = 0) -> "FlatIPIndex":
+        corpus = np.asarray(corpus)
+        if corpus.ndim != 2:
+            raise ValueError("corpus must be [n, d]")
+        ix = cls(corpus.shape[1], dtype=dtype, device=device, base=base)
+        ix.add(corpus)
+        ix._ensure_built()
+        return ix
+
+    @classmethod
+    def from_device_tensor(cls, corpus, dtype: Any = "f32", base: int = 0) -> "FlatIPIndex":
+        """Build from a torch float32 CUDA tensor [n, d] without a host round trip."""
+        import torch
+
+        if not (isinstance(corpus, torch.Tensor) and corpus.is_cuda and corpus.dim() == 2
+                and corpus.dtype == torch.float32 and corpus.is_contiguous()):
+            raise ValueError("expected a contiguous float32 CUDA tensor [n, d]")
+        ix = cls(corpus.shape[1], dtype=dtype, device=corpus.device.index or 0, base=base)
+        lib = native.load()
+        h = ctypes.c_void_p()
+        torch.cuda.synchronize(corpus.device)
+        native.check(lib.ls_create_from_device(ctypes.byref(h), corpus.data_ptr(),
+                                               corpus.shape[0], ix.d, ix._dtype, ix.device))
+        ix._handle = h
+        ix._ntotal = int(corpus.shape[0])
+        ix._device_built = True
+        if base:
+            native.check(lib.ls_set_base(h, base))
+        return ix
+
+    def add(self, x: np.ndarray) -> None:
+        """index.add(x) (reference extract/index.py:116): append float32 rows."""
+        if self._device_built:
+            raise RuntimeError("cannot add to an index built from device memory")
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError(f"add expects [n, {self.d}] float32")
+        if x.shape[0] == 0:
+            return
+        self._host_rows.append(x)
+        self._ntotal += x.shape[0]
+        self._drop_handle()
+
+    def _drop_handle(self) -> None:
+        if self._handle is not None:
+            native.load().ls_destroy(self._handle)
+            self._handle = None
+
+    def _ensure_built(self) -> ctypes.c_void_p:
+        if self._handle is not None:
+            return self._handle
+        lib = native.load()
+        if len(self._host_rows) > 1:
+            self._host_rows = [np.concatenate(self._host_rows, axis=0)]
+        corpus = self._host_rows[0] if self._host_rows else np.zeros((0, self.d), np.float32)
+        h = ctypes.c_void_p()
+        native.check(lib.ls_create(ctypes.byref(h), corpus.ctypes.data if corpus.size else None,
+                                   corpus.shape[0], self.d, self._dtype, self.device))
+        self._handle = h
+        if self._base:
+            native.check(lib.ls_set_base(h, self._base))
+        return h
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def ntotal(self) -> int:
+        return self._ntotal
+
+    @property
+    def storage_dtype(self) -> str:
+        return "f16" if self._dtype == native.LS_DTYPE_F16 else "f32"
+
+    @property
+    def base(self) -> int:
+        return self._base
+
+    def host_corpus(self) -> np.ndarray:
+        """The float32 rows this index was built from (host copy), [ntotal, d]."""
+        if self._device_built:
+            raise RuntimeError("index was built from device memory; no host copy exists")
+        if len(self._host_rows) > 1:
+            self._host_rows = [np.concatenate(self._host_rows, axis=0)]
+        return self._host_rows[0] if self._host_rows else np.zeros((0, self.d), np.float32)
+
+    # ------------------------------------------------------------------ search
+    def search(self, x: np.ndarray, k: int, *, normalize: bool = False
+               ) -> tuple[np.ndarray, np.ndarray]:
+        """index.search(x, k) (reference search/engine.py:250).
+
+        x: float32 [nq, d]. Returns (D float32 [nq, k], I int64 [nq, k]) best first under
+        (score desc, row asc); unfilled slots are (-FLT_MAX, -1).
+        """
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError(f"search expects [nq, {self.d}] float32, got {x.shape}")
+        k = int(k)
+        if k <= 0:
+            raise ValueError("k must be positive")
+        h = self._ensure_built()
+        nq = x.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        flags = native.LS_FLAG_NORMALIZE if normalize else 0
+        native.check(native.load().ls_search(h, x.ctypes.data if nq else None, nq, k, flags,
+                                             D.ctypes.data if nq else None,
+                                             I.ctypes.data if nq else None))
+        return D, I
+
+    def search_device(self, q, k: int, out_scores=None, out_indices=None, *,
+                      normalize: bool = False, asynchronous: bool = False, stream=None):
+        """Search with torch CUDA tensors (queries and results stay in HBM).
+
+        q: float32 CUDA tensor [nq, d]. Work is queued on ``stream`` (default: torch's current
+        stream). Returns (scores float32 [nq, k], indices int64 [nq, k]) CUDA tensors.
+        """
+        import torch
+
+        if not (q.is_cuda and q.dtype == torch.float32 and q.dim() == 2 and q.is_contiguous()
+                and q.shape[1] == self.d):
+            raise ValueError(f"search_device expects a contiguous float32 CUDA tensor [nq, {self.d}]")
+        nq = q.shape[0]
+        if out_scores is None:
+            out_scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        if out_indices is None:
+            out_indices = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        h = self._ensure_built()
+        s = stream if stream is not None else torch.cuda.current_stream(q.device)
+        flags = (native.LS_FLAG_NORMALIZE if normalize else 0) | \
+                (native.LS_FLAG_ASYNC if asynchronous else 0)
+        native.check(native.load().ls_search_device(h, q.data_ptr(), nq, int(k), flags,
+                                                    out_scores.data_ptr(), out_indices.data_ptr(),
+                                                    s.cuda_stream))
+        return out_scores, out_indices
+
+    def check(self, stream=None) -> None:
+        """Synchronise and validate async searches (see ls_check)."""
+        import torch
+
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        native.check(native.load().ls_check(self._ensure_built(), s.cuda_stream))
+
+    # ------------------------------------------------------------------ instrumentation
+    def set_profiling(self, enabled: bool) -> None:
+        native.check(native.load().ls_set_profiling(self._ensure_built(), 1 if enabled else 0))
+
+    def last_kernel_ms(self) -> tuple[float, float]:
+        a, b = ctypes.c_float(), ctypes.c_float()
+        native.check(native.load().ls_last_kernel_ms(self._ensure_built(), ctypes.byref(a),
+                                                     ctypes.byref(b)))
+        return a.value, b.value
+
+    def debug_option(self, which: int, value: int) -> None:
+        native.check(native.load().ls_debug_option(self._ensure_built(), which, value))
+
+    def debug_counter(self, which: int) -> int:
+        return int(native.load().ls_debug_counter(self._ensure_built(), which))
+
+    def close(self) -> None:
+        self._drop_handle()
+
+    def __del__(self):
+        try:
+            self._drop_handle()
+        except Exception:
+            pass

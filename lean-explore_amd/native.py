@@ -1,0 +1,105 @@
+"""ctypes binding of libleansearch.so (include/leansearch.h) — the only way Python reaches the
+HIP kernels. There is no fallback: if the shared library is missing, or no MI355X is visible,
+every compute call raises.
+
+The reference reaches its dense index through the faiss SWIG module
+(reference src/lean_explore/search/engine.py:156,240); this module is the counterpart of that
+import for the HIP library.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+LS_OK = 0
+LS_ERR_INVALID_ARG = -1
+LS_ERR_NO_DEVICE = -2
+LS_ERR_HIP = -3
+LS_ERR_K_TOO_LARGE = -4
+LS_ERR_OVERFLOW = -5
+
+LS_DTYPE_F32 = 0
+LS_DTYPE_F16 = 1
+LS_FLAG_NORMALIZE = 1
+LS_FLAG_ASYNC = 2
+LS_MAX_K = 2048
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("LEANSEARCH_LIB", _PKG_DIR / "libleansearch.so"))
+
+# every symbol include/leansearch.h declares: (restype, argtypes)
+_vp = ctypes.c_void_p
+_i32 = ctypes.c_int32
+_i64 = ctypes.c_int64
+_u32 = ctypes.c_uint32
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+SYMBOLS: dict[str, tuple] = {
+    "ls_create": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _i64, _i32, _i32, _i32]),
+    "ls_create_from_device": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _i64, _i32, _i32, _i32]),
+    "ls_destroy": (None, [_vp]),
+    "ls_ntotal": (_i64, [_vp]),
+    "ls_dim": (_i32, [_vp]),
+    "ls_dtype": (_i32, [_vp]),
+    "ls_device": (_i32, [_vp]),
+    "ls_set_base": (ctypes.c_int, [_vp, _i64]),
+    "ls_search": (ctypes.c_int, [_vp, _vp, _i64, _i32, _u32, _vp, _vp]),
+    "ls_search_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _u32, _vp, _vp, _vp]),
+    "ls_check": (ctypes.c_int, [_vp, _vp]),
+    "ls_normalize_l2": (ctypes.c_int, [_vp, _i64, _i32, _i32]),
+    "ls_merge_topk": (ctypes.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
+    "ls_set_profiling": (ctypes.c_int, [_vp, _i32]),
+    "ls_last_kernel_ms": (ctypes.c_int, [_vp, _f32p, _f32p]),
+    "ls_debug_option": (ctypes.c_int, [_vp, _i32, _i32]),
+    "ls_debug_counter": (_i64, [_vp, _i32]),
+    "ls_last_error": (ctypes.c_char_p, []),
+    "ls_version": (ctypes.c_char_p, []),
+    "ls_device_count": (_i32, []),
+}
+
+_lib: ctypes.CDLL | None = None
+
+
+class LeanSearchError(RuntimeError):
+    """A libleansearch call failed (carries the library's thread-local message)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libleansearch error {code}: {message}")
+        self.code = code
+
+
+def load() -> ctypes.CDLL:
+    """Load libleansearch.so and bind every declared symbol. Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc, gfx950). There is no CPU fallback for the dense search path.")
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc == LS_OK:
+        return
+    msg = load().ls_last_error().decode("utf-8", "replace")
+    if rc == LS_ERR_INVALID_ARG:
+        raise ValueError(f"libleansearch: {msg}")
+    raise LeanSearchError(rc, msg)
+
+
+def device_count() -> int:
+    return int(load().ls_device_count())
+
+
+def version() -> str:
+    return load().ls_version().decode()

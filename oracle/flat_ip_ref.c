@@ -1,0 +1,270 @@
+/*
+ * oracle/flat_ip_ref.c — TEST INFRASTRUCTURE ONLY. CPU restatement of the dense-retrieval
+ * arithmetic of LeanExplore's local backend. Nothing under lean-explore_amd/ may link, load
+ * or call this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * What it restates
+ *   - faiss.normalize_L2(x)            reference src/lean_explore/search/engine.py:242
+ *   - index.search(x, k) on an exact inner-product index
+ *                                      reference src/lean_explore/search/engine.py:250
+ *     (the reference's shipped index is IndexIVFFlat over an IndexFlatIP quantiser,
+ *      src/lean_explore/extract/index.py:103-104; BASELINE.json's metric is FAISS-*flat*,
+ *      i.e. what IVF approximates, so this file computes S = X * C^T and the per-row top-k)
+ *   - the fp32 corpus layout           reference src/lean_explore/extract/index.py:71
+ *
+ * Where the algorithm really lives: the third-party dependency faiss-cpu, constraint ">=1.7"
+ * in the reference's pyproject.toml:36, NOT pinned by any lockfile and NOT present under
+ * /root/reference or in this image. Its published algorithm for IndexFlat + METRIC_INNER_PRODUCT
+ * is: for every query, fp32 inner product against every stored row, keep the k largest in a
+ * heap whose empty slots hold (label -1, distance -FLT_MAX), return them best-first with int64
+ * labels. That is what is restated here.
+ *
+ * PARITY UNPINNED beyond the reference's own tests: the only fixtures the reference holds for
+ * this path are the known-answer test tests/extract/index_test.py:186-205 (row 0 = e0, query e0,
+ * k = 1 -> label 0) and the structural asserts at :164-183 (ntotal, d); tests/test_oracle.py
+ * checks this file against those. FAISS's own summation order and tie behaviour cannot be
+ * observed here (no faiss), so they are fixed by definition:
+ *   summation  : plain left-to-right fp32, one rounding per multiply and one per add
+ *                (compiled with -ffp-contract=off so no FMA contraction sneaks in)
+ *   total order: score descending, then row index ascending
+ *   not returned: rows whose score is NaN or <= -FLT_MAX (a FAISS heap never admits them:
+ *                 its test is `score > heap_top` with heap_top initialised to -FLT_MAX)
+ *   padding    : label -1, score -FLT_MAX
+ *
+ * fp16 mode restates the build's LS_DTYPE_F16 storage: corpus AND query are rounded to IEEE
+ * binary16 (round-to-nearest-even) and widened back to fp32 before the same arithmetic.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- order-preserving key: larger key == better result ------------------------------- */
+static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* monotone map float -> uint32 for all non-NaN values */
+static inline uint32_t ord_u32(float f) {
+    uint32_t u = f32_bits(f + 0.0f); /* +0.0f folds -0 into +0 */
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static inline float unord_u32(uint32_t k) {
+    return bits_f32((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+/* composite key: (score desc, row asc). 0 is reserved for "not a result". */
+static inline uint64_t make_key(float s, int64_t row) {
+    if (!(s > -FLT_MAX)) return 0; /* NaN, -inf and -FLT_MAX are never admitted */
+    return ((uint64_t)ord_u32(s) << 32) | (uint64_t)(0xffffffffu - (uint32_t)row);
+}
+
+/* ---- IEEE binary16 rounding (gcc 11 has no _Float16 on x86) ---------------------------- */
+static inline uint16_t f32_to_f16_bits(float f) {
+    uint32_t x = f32_bits(f);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t mant = x & 0x007fffffu;
+    int32_t exp = (int32_t)((x >> 23) & 0xff);
+    if (exp == 0xff) return (uint16_t)(sign | 0x7c00u | (mant ? 0x200u | (mant >> 13) : 0));
+    exp = exp - 127 + 15;
+    if (exp >= 0x1f) return (uint16_t)(sign | 0x7c00u); /* overflow -> inf */
+    if (exp <= 0) {                                     /* subnormal or zero */
+        if (exp < -10) return (uint16_t)sign;
+        mant |= 0x00800000u;
+        uint32_t shift = (uint32_t)(14 - exp);
+        uint32_t half = mant >> shift;
+        uint32_t rem = mant & ((1u << shift) - 1u);
+        uint32_t halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (half & 1u))) half++;
+        return (uint16_t)(sign | half);
+    }
+    uint32_t half = ((uint32_t)exp << 10) | (mant >> 13);
+    uint32_t rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) half++; /* may carry into exp: ok */
+    return (uint16_t)(sign | half);
+}
+static inline float f16_bits_to_f32(uint16_t h) {
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1f;
+    uint32_t mant = h & 0x3ffu;
+    if (exp == 0) {
+        if (mant == 0) return bits_f32(sign);
+        float v = (float)mant * 5.9604644775390625e-08f; /* 2^-24 */
+        return sign ? -v : v;
+    }
+    if (exp == 0x1f) return bits_f32(sign | 0x7f800000u | (mant << 13));
+    return bits_f32(sign | ((exp - 15 + 127) << 23) | (mant << 13));
+}
+
+/* x <- fp32(fp16(x)), elementwise */
+void oracle_round_f16(float* x, int64_t count) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < count; ++i) x[i] = f16_bits_to_f32(f32_to_f16_bits(x[i]));
+}
+
+/* faiss.normalize_L2 (engine.py:242): x_i *= 1/sqrt(sum x^2); zero-norm rows untouched.
+ * The squared norm is a plain left-to-right fp32 sum. */
+void oracle_normalize_l2(float* x, int64_t nq, int32_t d) {
+    for (int64_t i = 0; i < nq; ++i) {
+        float* r = x + i * (int64_t)d;
+        float nr = 0.0f;
+        for (int32_t j = 0; j < d; ++j) nr += r[j] * r[j];
+        if (nr > 0.0f) {
+            float inv = 1.0f / sqrtf(nr);
+            for (int32_t j = 0; j < d; ++j) r[j] *= inv;
+        }
+    }
+}
+
+/* one inner product, left-to-right fp32 */
+static inline float dot_f32(const float* a, const float* b, int32_t d) {
+    float acc = 0.0f;
+    for (int32_t j = 0; j < d; ++j) acc += a[j] * b[j];
+    return acc;
+}
+
+/* all scores of one query: out[r] = <corpus[r], q> */
+void oracle_scores(const float* corpus, int64_t n, int32_t d, const float* q, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r) out[r] = dot_f32(corpus + r * (int64_t)d, q, d);
+}
+
+/* ---- k largest keys with a binary min-heap -------------------------------------------- */
+static void heap_sift_down(uint64_t* h, int32_t n, int32_t i) {
+    for (;;) {
+        int32_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < n && h[l] < h[m]) m = l;
+        if (r < n && h[r] < h[m]) m = r;
+        if (m == i) return;
+        uint64_t t = h[i]; h[i] = h[m]; h[m] = t;
+        i = m;
+    }
+}
+static int cmp_key_desc(const void* a, const void* b) {
+    uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return (x < y) - (x > y);
+}
+
+/* select the k best of scores[0..n) into (D, I) best-first; pads with (-FLT_MAX, -1) */
+static void select_topk(const float* scores, int64_t n, int32_t k, int64_t base, float* D,
+                        int64_t* I, uint64_t* heap) {
+    int32_t hn = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        uint64_t key = make_key(scores[r], r);
+        if (key == 0) continue;
+        if (hn < k) {
+            heap[hn++] = key;
+            if (hn == k)
+                for (int32_t i = k / 2 - 1; i >= 0; --i) heap_sift_down(heap, k, i);
+        } else if (key > heap[0]) {
+            heap[0] = key;
+            heap_sift_down(heap, k, 0);
+        }
+    }
+    qsort(heap, (size_t)hn, sizeof(uint64_t), cmp_key_desc);
+    for (int32_t i = 0; i < k; ++i) {
+        if (i < hn) {
+            D[i] = unord_u32((uint32_t)(heap[i] >> 32));
+            I[i] = base + (int64_t)(0xffffffffu - (uint32_t)(heap[i] & 0xffffffffu));
+        } else {
+            D[i] = -FLT_MAX;
+            I[i] = -1;
+        }
+    }
+}
+
+/*
+ * index.search(x, k) for an exact inner-product index (engine.py:250).
+ *   corpus f32 [n, d] row-major, q f32 [nq, d]; D f32 [nq, k]; I i64 [nq, k].
+ * Parallelism is over rows for one query and over queries for a batch; neither changes any
+ * result because every score is one sequential dot product.
+ * Returns 0, or -1 on bad arguments / allocation failure.
+ */
+int oracle_flat_ip_topk(const float* corpus, int64_t n, int32_t d, const float* q, int64_t nq,
+                        int32_t k, int64_t base, float* D, int64_t* I) {
+    if (n < 0 || d <= 0 || nq < 0 || k <= 0 || (n > 0 && !corpus) || (nq > 0 && (!q || !D || !I)))
+        return -1;
+    if (nq == 0) return 0;
+    int fail = 0;
+    if (nq == 1) {
+        float* s = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+        uint64_t* heap = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)k);
+        if (!s || !heap) { free(s); free(heap); return -1; }
+        oracle_scores(corpus, n, d, q, s);
+        select_topk(s, n, k, base, D, I, heap);
+        free(s); free(heap);
+        return 0;
+    }
+#pragma omp parallel
+    {
+        float* s = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+        uint64_t* heap = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)k);
+        if (!s || !heap) {
+#pragma omp atomic write
+            fail = 1;
+        } else {
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t i = 0; i < nq; ++i) {
+                const float* qi = q + i * (int64_t)d;
+                for (int64_t r = 0; r < n; ++r) s[r] = dot_f32(corpus + r * (int64_t)d, qi, d);
+                select_topk(s, n, k, base, D + i * (int64_t)k, I + i * (int64_t)k, heap);
+            }
+        }
+        free(s); free(heap);
+    }
+    return fail ? -1 : 0;
+}
+
+/*
+ * G-way merge of per-shard results under the same total order: inputs
+ * D_in f32 [g, nq, k], I_in i64 [g, nq, k] with -1 padding; output the k best per query.
+ */
+int oracle_merge_topk(const float* D_in, const int64_t* I_in, int32_t g, int64_t nq, int32_t k,
+                      float* D, int64_t* I) {
+    if (g <= 0 || nq < 0 || k <= 0) return -1;
+    int64_t m = (int64_t)g * k;
+    typedef struct { float s; int64_t i; } ent;
+    ent* buf = (ent*)malloc(sizeof(ent) * (size_t)m);
+    if (!buf) return -1;
+    for (int64_t qi = 0; qi < nq; ++qi) {
+        int64_t c = 0;
+        for (int32_t s = 0; s < g; ++s)
+            for (int32_t j = 0; j < k; ++j) {
+                int64_t off = ((int64_t)s * nq + qi) * k + j;
+                if (I_in[off] >= 0) { buf[c].s = D_in[off]; buf[c].i = I_in[off]; ++c; }
+            }
+        /* insertion sort by (score desc, index asc): m is small */
+        for (int64_t a = 1; a < c; ++a) {
+            ent e = buf[a];
+            int64_t b = a - 1;
+            while (b >= 0 && (buf[b].s < e.s || (buf[b].s == e.s && buf[b].i > e.i))) {
+                buf[b + 1] = buf[b];
+                --b;
+            }
+            buf[b + 1] = e;
+        }
+        for (int32_t j = 0; j < k; ++j) {
+            if (j < c) { D[qi * k + j] = buf[j].s; I[qi * k + j] = buf[j].i; }
+            else { D[qi * k + j] = -FLT_MAX; I[qi * k + j] = -1; }
+        }
+    }
+    free(buf);
+    return 0;
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

@@ -1,0 +1,31 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Make sure the native pieces exist (hipcc cross-compiles on CPU-only hosts)."""
+    import __graft_entry__ as g
+
+    lib = ROOT / "lean-explore_amd" / "libleansearch.so"
+    ora = ROOT / "oracle" / "_build" / "liboracle.so"
+    if not lib.exists() or not ora.exists():
+        g.build()
+    yield
+
+
+@pytest.fixture(scope="session")
+def gpu_available():
+    from lean_explore_amd import native
+
+    return native.device_count() > 0

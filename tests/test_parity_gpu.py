@@ -1,0 +1,278 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle. Needs an MI355X.
+
+Bars (BASELINE.json north_star): indices bit-exact under (score desc, row asc); fp32 scores
+within 1e-5. On continuous random data an index may differ only where the oracle's own scores
+of the two rows are within 2e-6 (a near-tie whose order depends on fp32 summation order);
+`oracle.compare_topk` enforces exactly that. On integer-valued data every summation order is
+exact, so scores and indices must match bit for bit, ties included.
+"""
+
+import numpy as np
+import pytest
+
+from lean_explore_amd import native
+from lean_explore_amd.index import FlatIPIndex, normalize_L2
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+NEG = oracle.NEG_FLT_MAX
+SCORE_TOL = 1e-5
+
+
+def check(corpus, q, k, dtype="f32", normalize=False, ix=None, base=0):
+    own = ix is None
+    if own:
+        ix = FlatIPIndex.from_array(corpus, dtype=dtype, base=base)
+    D, I = ix.search(q, k, normalize=normalize)
+    f16 = dtype == "f16"
+    qn = oracle.c_normalize_l2(q) if normalize else q
+    Dr, Ir = oracle.c_search(corpus, qn, k, f16=f16, base=base)
+    _, _, S = oracle.np_search(corpus, qn, k, f16=f16)
+    rep = oracle.compare_topk(D, I, Dr, Ir, S, score_tol=SCORE_TOL, base=base)
+    assert rep["recall"] == 1.0, rep
+    if own:
+        ix.close()
+    return rep
+
+
+def test_device_present():
+    assert native.device_count() >= 1
+
+
+def test_reference_known_answer_e0():
+    """reference tests/extract/index_test.py:186-205 through the HIP path."""
+    for seed in (0, 20240611):
+        emb, q = H.kat_inputs(seed)
+        ix = FlatIPIndex.from_array(emb)
+        assert ix.ntotal == 300 and ix.d == 768  # index_test.py:172-173
+        D, I = ix.search(q, 1)
+        assert I[0][0] == 0 and D[0][0] == 1.0
+        ix.close()
+
+
+def test_golden_vectors():
+    meta, arr = H.load_golden()
+    for name, m in meta.items():
+        if name in ("kat", "tie"):
+            continue
+        c = H.gauss(m["corpus_seed"], m["n"], m["d"])
+        q = H.gauss(m["query_seed"], m["nq"], m["d"])
+        ix = FlatIPIndex.from_array(c, dtype="f16" if m["f16"] else "f32")
+        D, I = ix.search(q, m["k"])
+        _, _, S = oracle.np_search(c, q, m["k"], f16=m["f16"])
+        rep = oracle.compare_topk(D, I, arr[f"{name}__D"], arr[f"{name}__I"], S,
+                                  score_tol=SCORE_TOL)
+        assert rep["recall"] == 1.0, (name, rep)
+        ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_golden_tie_case_bit_exact(dtype):
+    meta, arr = H.load_golden()
+    c = H.int_corpus(99, 4096, 64)
+    rng = np.random.default_rng(99)
+    _ = rng.integers(-3, 4, size=(4096, 64))
+    q = rng.integers(-3, 4, size=(3, 64)).astype(np.float32)
+    ix = FlatIPIndex.from_array(c, dtype=dtype)
+    D, I = ix.search(q, 100)
+    assert np.array_equal(I, arr["tie__I"]) and np.array_equal(D, arr["tie__D"])
+    ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("d", [384, 768, 1024, 64, 100, 36, 1000])
+def test_dims(d, dtype):
+    c = H.gauss(1234, 5000, d)
+    q = H.gauss(5678, 3, d)
+    check(c, q, 50, dtype=dtype)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 63, 64, 65, 300, 1023, 4097])
+def test_small_and_ragged_n(n):
+    c = H.gauss(1, n, 384)
+    q = H.gauss(2, 2, 384)
+    check(c, q, 10)
+    check(c, q, 1000)  # reference default faiss_k = 1000 > n -> -1 padding
+
+
+def test_empty_index_and_empty_query_batch():
+    ix = FlatIPIndex(384)
+    D, I = ix.search(H.gauss(2, 2, 384), 5)
+    assert (I == -1).all() and (D == NEG).all()
+    ix2 = FlatIPIndex.from_array(H.gauss(1, 10, 384))
+    D, I = ix2.search(np.zeros((0, 384), np.float32), 5)
+    assert D.shape == (0, 5) and I.shape == (0, 5)
+
+
+@pytest.mark.parametrize("k", [1, 2, 50, 100, 1000, 2048])
+def test_k_values_config1(k):
+    """BASELINE config 1 shape: 10k x 384, single query."""
+    c = H.gauss(1234, 10_000, 384)
+    q = H.gauss(5678, 1, 384)
+    check(c, q, k)
+
+
+def test_k_too_large_is_an_error():
+    ix = FlatIPIndex.from_array(H.gauss(1, 5000, 64))
+    with pytest.raises(native.LeanSearchError) as e:
+        ix.search(H.gauss(2, 1, 64), 4096)
+    assert e.value.code == native.LS_ERR_K_TOO_LARGE
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_config2_full_size(dtype):
+    """BASELINE config 2: N=200k, d=384, nq=1 (here 4 queries), k=50 — full size vs oracle."""
+    c = H.gauss(1234, 200_000, 384)
+    q = H.gauss(5678, 4, 384)
+    ix = FlatIPIndex.from_array(c, dtype=dtype)
+    rep = check(c, q, 50, dtype=dtype, ix=ix)
+    assert ix.debug_counter(0) == 0, "random data must stay on the finalize fast path"
+    rep2 = check(c, q, 1000, dtype=dtype, ix=ix)
+    print("config2", dtype, rep, rep2)
+    ix.close()
+
+
+def test_real_call_shape_d1024_k1000():
+    """The reference's production call: d=1024 (Qwen3-Embedding), faiss_k=1000."""
+    c = H.gauss(1234, 50_000, 1024)
+    q = H.gauss(5678, 2, 1024)
+    check(c, q, 1000, normalize=True)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_integer_corpus_full_size_bit_exact(dtype):
+    """Exact arithmetic at full size: bit-exact scores and indices, thousands of ties."""
+    c = H.int_corpus(7, 200_000, 384)
+    q = H.int_corpus(8, 3, 384)
+    ix = FlatIPIndex.from_array(c, dtype=dtype)
+    for k in (50, 1000):
+        D, I = ix.search(q, k)
+        Dr, Ir = oracle.c_search(c, q, k, f16=(dtype == "f16"))
+        assert np.array_equal(D, Dr) and np.array_equal(I, Ir)
+    ix.close()
+
+
+def test_duplicates_and_all_equal_scores():
+    c = H.gauss(7, 20_000, 384)
+    c[1234] = c[77]
+    c[19_999] = c[77]
+    ix = FlatIPIndex.from_array(c)
+    D, I = ix.search(c[77:78], 4)
+    assert list(I[0, :3]) == [77, 1234, 19_999] and D[0, 0] == D[0, 1] == D[0, 2]
+    ix.close()
+    ones = np.ones((30_000, 64), np.float32)  # every score identical: pure tie-break
+    ix = FlatIPIndex.from_array(ones)
+    D, I = ix.search(np.ones((1, 64), np.float32), 100)
+    assert np.array_equal(I[0], np.arange(100)) and (D == 64.0).all()
+    assert ix.debug_counter(0) >= 1  # the bound cannot be beaten: exact slow path
+    ix.close()
+
+
+def test_clustered_corpus_takes_slow_path_and_stays_exact():
+    """All good rows adjacent (sorted corpus): candidates cannot be proven complete."""
+    c = H.gauss(3, 60_000, 384)
+    q = H.gauss(4, 1, 384)
+    order = np.argsort(c @ q[0])
+    c = np.ascontiguousarray(c[order])  # ascending score: best rows are the last ones
+    ix = FlatIPIndex.from_array(c)
+    ix.debug_option(0, 1)  # k' = 1: at most one emitted key per workgroup
+    rep = check(c, q, 200, ix=ix)
+    assert ix.debug_counter(0) >= 1
+    ix.debug_option(0, 0)
+    rep = check(c, q, 200, ix=ix)
+    print("clustered", rep, "slow-path count", ix.debug_counter(0))
+    ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_forced_slow_path_equals_fast_path(dtype):
+    c = H.gauss(5, 100_000, 384)
+    q = H.gauss(6, 3, 384)
+    ix = FlatIPIndex.from_array(c, dtype=dtype)
+    Df, If = ix.search(q, 100)
+    ix.debug_option(1, 1)
+    Ds, Is = ix.search(q, 100)
+    assert ix.debug_counter(0) == 3
+    assert np.array_equal(Df, Ds) and np.array_equal(If, Is)
+    check(c, q, 1000, dtype=dtype, ix=ix)
+    ix.close()
+
+
+def test_negative_zero_nan():
+    c = H.gauss(8, 5000, 64)
+    check(-np.abs(c), np.abs(c[:2]), 20)
+    ix = FlatIPIndex.from_array(c)
+    D, I = ix.search(np.zeros((1, 64), np.float32), 5)
+    assert (D == 0).all() and list(I[0]) == [0, 1, 2, 3, 4]
+    ix.close()
+    c2 = c.copy()
+    c2[10, 0] = np.nan
+    c2[11, 0] = -np.inf
+    c2[12, 0] = np.inf
+    ix = FlatIPIndex.from_array(c2[:2000])
+    D, I = ix.search(np.ones((1, 64), np.float32), 2000)
+    Dr, Ir = oracle.c_search(c2[:2000], np.ones((1, 64), np.float32), 2000)
+    assert 10 not in I[0] and 11 not in I[0] and I[0, 0] == 12
+    assert np.array_equal(I < 0, Ir < 0) and (I[0, -2:] == -1).all()
+    assert np.array_equal(D[0, -2:], np.array([NEG, NEG], np.float32))
+    ix.close()
+
+
+def test_normalize_l2():
+    x = H.gauss(9, 6, 1024, normalize=False) * 3.0
+    x[2] = 0.0
+    want = oracle.c_normalize_l2(x)
+    got = x.copy()
+    assert normalize_L2(got) is None  # faiss.normalize_L2 returns None, works in place
+    assert np.allclose(got, want, atol=1e-6) and (got[2] == 0).all()
+    # fused flag == separate call
+    c = H.gauss(1, 3000, 1024)
+    ix = FlatIPIndex.from_array(c)
+    D1, I1 = ix.search(x, 20, normalize=True)
+    D2, I2 = ix.search(got, 20)
+    assert np.array_equal(I1, I2) and np.allclose(D1, D2, atol=1e-6)
+    ix.close()
+
+
+def test_base_offset_and_add_incremental():
+    c = H.gauss(1, 3000, 384)
+    q = H.gauss(2, 2, 384)
+    check(c, q, 10, base=1_000_000)
+    ix = FlatIPIndex(384)
+    ix.add(c[:1000])
+    ix.add(c[1000:])
+    assert ix.ntotal == 3000
+    check(c, q, 10, ix=ix)
+    ix.close()
+
+
+def test_device_resident_api_and_merge():
+    import torch
+
+    c = H.int_corpus(21, 50_000, 128)
+    q = H.int_corpus(22, 4, 128)
+    k = 64
+    Dref, Iref = oracle.c_search(c, q, k)
+    dev = torch.device("cuda:0")
+    tq = torch.from_numpy(q).to(dev)
+    # build from device memory, sharded 3 ways with global row offsets
+    bounds = [0, 16_000, 33_333, 50_000]
+    outs_s, outs_i = [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        ix = FlatIPIndex.from_device_tensor(torch.from_numpy(c[a:b]).to(dev), base=a)
+        s, i = ix.search_device(tq, k, asynchronous=True)
+        ix.check()
+        outs_s.append(s)
+        outs_i.append(i)
+        Dp, Ip = oracle.c_search(c[a:b], q, k, base=a)
+        assert np.array_equal(s.cpu().numpy(), Dp) and np.array_equal(i.cpu().numpy(), Ip)
+    S_in = torch.stack(outs_s).contiguous()
+    I_in = torch.stack(outs_i).contiguous()
+    So = torch.empty((4, k), dtype=torch.float32, device=dev)
+    Io = torch.empty((4, k), dtype=torch.int64, device=dev)
+    lib = native.load()
+    native.check(lib.ls_merge_topk(S_in.data_ptr(), I_in.data_ptr(), 3, 4, k, So.data_ptr(),
+                                   Io.data_ptr(), 0, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert np.array_equal(So.cpu().numpy(), Dref) and np.array_equal(Io.cpu().numpy(), Iref)

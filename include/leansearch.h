@@ -115,6 +115,8 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * (0 = automatic); option 1: force the finalize kernel's exact slow path. counter 0: searches whose finalize step took the exact slow path. */
 int ls_debug_option(ls_index* index, int32_t which, int32_t value);
 int64_t ls_debug_counter(ls_index* index, int32_t which);
+/* Copy the score vector S[0..count) of the most recent per-query scan to host memory. */
+int ls_debug_read_scores(ls_index* index, float* out, int64_t count);
 
 const char* ls_last_error(void); /* thread-local; valid until the next call on this thread */
 const char* ls_version(void);

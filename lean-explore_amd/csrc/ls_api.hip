@@ -48,6 +48,8 @@ struct ls_index {
     // options / instrumentation
     int32_t opt_kprime = 0;  // 0 = automatic
     int32_t opt_force_slow = 0;
+    int32_t opt_alternate = 1;  // alternate sweep direction between consecutive scans
+    uint64_t sweep_count = 0;
     bool profiling = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool ev_valid = false;
@@ -124,6 +126,7 @@ static int create_common(ls_index** out, int64_t n, int32_t d, int32_t dtype, in
     ix->n = n;
     ix->dtype = dtype;
     ix->g = g;
+    if (const char* e = getenv("LS_SCAN_ALT")) ix->opt_alternate = atoi(e) != 0;
     int cu = 0;
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
         cu > 0)
@@ -283,18 +286,16 @@ static int pick_kprime(const ls_index* ix, int blocks, int keff) {
 static int search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
                             float* d_out_s, int64_t* d_out_i, hipStream_t s) {
     const ls_geom& g = ix->g;
-    int rc = grow(&ix->d_qprep, &ix->qprep_cap, (size_t)nq * g.d_pad);
-    if (rc != LS_OK) return rc;
-    rc = ls_launch_prep(d_q, ix->d_qprep, nq, g, (flags & LS_FLAG_NORMALIZE) != 0,
-                        ix->dtype == LS_DTYPE_F16, s);
-    if (rc != LS_OK) return rc;
+    int rc = LS_OK;
+    const bool normalize = (flags & LS_FLAG_NORMALIZE) != 0;
     const int64_t keff = std::min<int64_t>(k, ix->n);
     const int blocks = ls_scan_blocks(ix->n > 0 ? ix->n : 1, g, ix->n_cu);
     const int kprime = pick_kprime(ix, blocks, (int)std::max<int64_t>(keff, 1));
     for (int64_t qi = 0; qi < nq; ++qi) {
         const bool prof = ix->profiling && qi == nq - 1;
         if (prof) LS_HIP(hipEventRecord(ix->ev[0], s));
-        rc = ls_launch_scan(ix->d_corpus, ix->n, g, ix->d_qprep + qi * g.d_pad, ix->d_S,
+        const bool reverse = ix->opt_alternate && (ix->sweep_count++ & 1);
+        rc = ls_launch_scan(ix->d_corpus, ix->n, g, d_q + qi * g.d, normalize, reverse, ix->d_S,
                             ix->d_cand, ix->d_bound, blocks, kprime, s);
         if (rc != LS_OK) return rc;
         if (prof) LS_HIP(hipEventRecord(ix->ev[1], s));
@@ -473,12 +474,25 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->opt_kprime = value;
         return LS_OK;
     }
+    if (which == 2) {  // alternate the sweep direction of consecutive scans (default on)
+        ix->opt_alternate = value != 0;
+        return LS_OK;
+    }
     if (which == 1) {  // force the finalize kernel's exact slow path
         ix->opt_force_slow = value != 0;
         return LS_OK;
     }
     ls_set_error("ls_debug_option: unknown option %d", which);
     return LS_ERR_INVALID_ARG;
+}
+
+int ls_debug_read_scores(ls_index* ix, float* out, int64_t count) {
+    if (!ix || !out || count < 0 || count > ix->n) return LS_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    LS_HIP(hipSetDevice(ix->device));
+    LS_HIP(hipDeviceSynchronize());
+    LS_HIP(hipMemcpy(out, ix->d_S, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost));
+    return LS_OK;
 }
 
 int64_t ls_debug_counter(ls_index* ix, int32_t which) {

@@ -78,11 +78,12 @@ int ls_launch_prep(const float* d_q_in, float* d_q_out, int64_t nq, const ls_geo
 // corpus conversion: dst[n, d_pad] (fp32 or fp16) from src fp32 [n, d]
 int ls_launch_convert(const float* d_src, void* d_dst, int64_t n, const ls_geom& g,
                       hipStream_t s);
-// scan: scores S[n] for one query + per-workgroup best kprime keys and bound
+// scan: scores S[n] for one RAW query (d floats; normalisation / fp16 rounding fused in)
+// + per-workgroup best kprime keys and bound
 int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu);
 int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const float* d_q,
-                   float* d_S, u64* d_cand, u64* d_bound, int32_t blocks, int32_t kprime,
-                   hipStream_t s);
+                   bool normalize, bool reverse, float* d_S, u64* d_cand, u64* d_bound,
+                   int32_t blocks, int32_t kprime, hipStream_t s);
 // finalize: exact top-k from the scan's candidates (or, if they cannot be proven complete,
 // from S itself) -> out_scores[k], out_indices[k]
 int ls_launch_finalize(const float* d_S, int64_t n, const u64* d_cand, const u64* d_bound,

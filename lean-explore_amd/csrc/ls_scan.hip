@@ -26,7 +26,11 @@
 #include <hip/hip_fp16.h>
 
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte chunk
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // one 16-byte chunk
+
+// NOTE: never __builtin_bit_cast an ext-vector ELEMENT expression (x.y): clang reads the first
+// lane. Copy the element to a scalar first.
+__device__ __forceinline__ h2_t as_h2(float f) { return __builtin_bit_cast(h2_t, f); }
 
 template <bool F16, int V>
 struct QueryRegs;
@@ -34,18 +38,38 @@ struct QueryRegs;
 template <int V>
 struct QueryRegs<false, V> {
     float4 q[V];
-    __device__ __forceinline__ void load(const float* qp, int sub, int L) {
+    // raw query (d floats, any alignment) -> zero-padded registers; returns this lane's sum of squares
+    __device__ __forceinline__ float load(const float* qp, int d, int sub, int L) {
+        float ss = 0.0f;
 #pragma unroll
-        for (int v = 0; v < V; ++v) q[v] = *reinterpret_cast<const float4*>(qp + 4 * (sub + L * v));
+        for (int v = 0; v < V; ++v) {
+            const int e = 4 * (sub + L * v);
+            q[v].x = e + 0 < d ? qp[e + 0] : 0.0f;
+            q[v].y = e + 1 < d ? qp[e + 1] : 0.0f;
+            q[v].z = e + 2 < d ? qp[e + 2] : 0.0f;
+            q[v].w = e + 3 < d ? qp[e + 3] : 0.0f;
+            ss = fmaf(q[v].x, q[v].x, ss);
+            ss = fmaf(q[v].y, q[v].y, ss);
+            ss = fmaf(q[v].z, q[v].z, ss);
+            ss = fmaf(q[v].w, q[v].w, ss);
+        }
+        return ss;
     }
-    __device__ __forceinline__ float dot(const u32x4 (&x)[V]) const {
+    __device__ __forceinline__ void scale(float f) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            q[v].x *= f; q[v].y *= f; q[v].z *= f; q[v].w *= f;
+        }
+    }
+    __device__ __forceinline__ float dot(const f32x4 (&x)[V]) const {
         float acc = 0.0f;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            acc = fmaf(__builtin_bit_cast(float, x[v].x), q[v].x, acc);
-            acc = fmaf(__builtin_bit_cast(float, x[v].y), q[v].y, acc);
-            acc = fmaf(__builtin_bit_cast(float, x[v].z), q[v].z, acc);
-            acc = fmaf(__builtin_bit_cast(float, x[v].w), q[v].w, acc);
+            const float a = x[v].x, b = x[v].y, c = x[v].z, e = x[v].w;
+            acc = fmaf(a, q[v].x, acc);
+            acc = fmaf(b, q[v].y, acc);
+            acc = fmaf(c, q[v].z, acc);
+            acc = fmaf(e, q[v].w, acc);
         }
         return acc;
     }
@@ -54,27 +78,37 @@ struct QueryRegs<false, V> {
 template <int V>
 struct QueryRegs<true, V> {
     h2_t q[V][4];
-    __device__ __forceinline__ void load(const float* qp, int sub, int L) {
+    float f[V][8];  // fp32 staging, dead after scale()
+    __device__ __forceinline__ float load(const float* qp, int d, int sub, int L) {
+        float ss = 0.0f;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const float* p = qp + 8 * (sub + L * v);
-            const float4 a = *reinterpret_cast<const float4*>(p);
-            const float4 b = *reinterpret_cast<const float4*>(p + 4);
-            // the prepared query already holds fp16-representable values: exact narrowing
-            q[v][0] = h2_t{(_Float16)a.x, (_Float16)a.y};
-            q[v][1] = h2_t{(_Float16)a.z, (_Float16)a.w};
-            q[v][2] = h2_t{(_Float16)b.x, (_Float16)b.y};
-            q[v][3] = h2_t{(_Float16)b.z, (_Float16)b.w};
+            const int e = 8 * (sub + L * v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f[v][j] = e + j < d ? qp[e + j] : 0.0f;
+                ss = fmaf(f[v][j], f[v][j], ss);
+            }
         }
+        return ss;
     }
-    __device__ __forceinline__ float dot(const u32x4 (&x)[V]) const {
+    // scale, then round the query to fp16 (LS_DTYPE_F16 semantics: both operands are fp16)
+    __device__ __forceinline__ void scale(float s) {
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                q[v][j] = h2_t{(_Float16)(f[v][2 * j] * s), (_Float16)(f[v][2 * j + 1] * s)};
+    }
+    __device__ __forceinline__ float dot(const f32x4 (&x)[V]) const {
         float acc = 0.0f;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, x[v].x), q[v][0], acc, false);
-            acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, x[v].y), q[v][1], acc, false);
-            acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, x[v].z), q[v][2], acc, false);
-            acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, x[v].w), q[v][3], acc, false);
+            const float a = x[v].x, b = x[v].y, c = x[v].z, e = x[v].w;
+            acc = __builtin_amdgcn_fdot2(as_h2(a), q[v][0], acc, false);
+            acc = __builtin_amdgcn_fdot2(as_h2(b), q[v][1], acc, false);
+            acc = __builtin_amdgcn_fdot2(as_h2(c), q[v][2], acc, false);
+            acc = __builtin_amdgcn_fdot2(as_h2(e), q[v][3], acc, false);
         }
         return acc;
     }
@@ -87,6 +121,12 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ u64 readlane64(u64 v, int l) {  // l must be wave-uniform
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
 // Insert key `v` (wave-uniform) into the wave's sorted list (lanes 0..kp-1, descending).
 __device__ __forceinline__ void wave_insert(u64& lst, u64 v, int lane, int kp) {
     const int cnt = __popcll(__ballot(lst > v));  // lanes >= kp hold 0 and never count
@@ -97,57 +137,78 @@ __device__ __forceinline__ void wave_insert(u64& lst, u64 v, int lane, int kp) {
     }
 }
 
-template <bool F16, int L, int V, int U, bool NT>
+template <bool F16, int L, int V, int U, int MODE>
 __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
-    const u32x4* __restrict__ corpus, long long n, int chunks, const float* __restrict__ qprep,
-    float* __restrict__ S, u64* __restrict__ cand, u64* __restrict__ bound, int kprime) {
-    constexpr int R = LS_WAVE / L;  // rows per wave step
+    const f32x4* __restrict__ corpus, long long n, int chunks, const float* __restrict__ qraw,
+    int d, int normalize, int reverse, float* __restrict__ S, u64* __restrict__ cand,
+    u64* __restrict__ bound, int kprime) {
+    constexpr int R = LS_WAVE / L;  // rows per wave load step
+    constexpr int TR = U * R;       // rows per tile: one tile = U steps = TR contiguous rows
+    static_assert(TR <= LS_WAVE, "a tile's scores must fit one per lane");
     const int lane = threadIdx.x & (LS_WAVE - 1);
     const int wave = threadIdx.x / LS_WAVE;
     const int sub = lane & (L - 1);
     const int grp = lane / L;
     const int kp = kprime + 1;
 
-    QueryRegs<F16, V> qr;
-    qr.load(qprep, sub, L);
-
+    // Tiles are dealt round-robin to waves; the 4 waves of a workgroup take 4 adjacent tiles,
+    // so one workgroup iteration covers 4*TR contiguous rows and its S stores fill whole lines.
     const long long W = (long long)gridDim.x * LS_SCAN_WAVES;
-    const long long gw = (long long)wave * gridDim.x + blockIdx.x;
-    const long long NG = (n + R - 1) / R;
+    const long long gw = (long long)blockIdx.x * LS_SCAN_WAVES + wave;
+    const long long NT = (n + TR - 1) / TR;
+
+    f32x4 x[U][V];
+    auto issue_loads = [&](long long t) {
+        if (reverse) t = NT - 1 - t;  // optional back-to-front sweep (see ls_api.hip)
+        const long long r0 = t * TR + grp;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            long long r = r0 + u * R;
+            r = r < n ? r : n - 1;  // ragged last tile: re-read the last row, masked out below
+            const f32x4* p = corpus + r * chunks + sub;
+#pragma unroll
+            for (int v = 0; v < V; ++v) x[u][v] = __builtin_nontemporal_load(p + L * v);
+        }
+    };
+    long long t = gw;
+    if (t < NT) issue_loads(t);  // first tile's loads fly while the query is prepared
+
+    // query -> registers, with faiss.normalize_L2 (reference search/engine.py:242) fused in:
+    // x *= 1/sqrt(sum x^2), rows of zero norm untouched
+    QueryRegs<F16, V> qr;
+    {
+        const float ss = group_sum<L>(qr.load(qraw, d, sub, L));
+        const float inv = (normalize && ss > 0.0f) ? 1.0f / sqrtf(ss) : 1.0f;
+        qr.scale(inv);
+    }
 
     u64 lst = 0;  // lanes 0..kp-1: this wave's best keys, descending
     u64 thr = 0;  // key in lane kp-1 (wave-uniform): a row must beat it to matter
 
-    for (long long g0 = gw; g0 < NG; g0 += W * U) {
-        u32x4 x[U][V];
-        long long row[U];
+    while (t < NT) {
+        // lane i < TR collects the score of tile row i
+        float sc = 0.0f;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            row[u] = (g0 + (long long)u * W) * R + grp;
-            const long long rc = row[u] < n ? row[u] : n - 1;  // clamp: tail re-reads last row
-            const u32x4* p = corpus + rc * chunks + sub;
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-                if (NT)
-                    x[u][v] = __builtin_nontemporal_load(p + L * v);
-                else
-                    x[u][v] = p[L * v];
-            }
+            const float s = group_sum<L>(qr.dot(x[u]));         // valid in all L lanes of a group
+            const float sel = __shfl(s, (lane % R) * L, 64);    // lane i <- group (i % R)
+            if (lane / R == u) sc = sel;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float s = group_sum<L>(qr.dot(x[u]));
-            const bool valid = row[u] < n;
-            if (valid && sub == 0) S[row[u]] = s;
-            const u64 key = valid ? ls_make_key(s, (u32)row[u]) : 0ull;
-            u64 mask = __ballot(sub == 0 && key > thr);
-            while (mask) {  // rare once the threshold has warmed up
-                const int j = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const u64 v = __shfl(key, j, 64);
-                wave_insert(lst, v, lane, kp);
-                thr = __shfl(lst, kp - 1, 64);
-            }
+        const long long tt = reverse ? NT - 1 - t : t;
+        const long long row = tt * TR + lane;
+        t += W;
+        if (t < NT) issue_loads(t);  // next tile's loads overlap the selection below
+        const bool valid = lane < TR && row < n;
+        if (MODE != 1 && MODE != 2 && valid) S[row] = sc;  // TR contiguous floats
+        u64 key = valid ? ls_make_key(sc, (u32)row) : 0ull;
+        if (MODE == 2) { key = key == 12345ull ? key : 0ull; }
+        u64 mask = __ballot(key > thr);
+        while (mask) {  // rare once the threshold has warmed up
+            const int j = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const u64 v = readlane64(key, j);
+            wave_insert(lst, v, lane, kp);
+            thr = readlane64(lst, kp - 1);
         }
     }
 
@@ -169,6 +230,8 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+static constexpr int scan_unroll(int V) { return (V >= 3) ? 4 : 8; }  // >= 8 loads in flight
+
 int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu) {
     static int bpc = -1;
     if (bpc < 0) {
@@ -176,9 +239,9 @@ int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu) {
         bpc = e ? atoi(e) : 2;
         if (bpc < 1) bpc = 1;
     }
-    const int64_t R = LS_WAVE / g.L;
-    const int64_t NG = (n + R - 1) / R;
-    int64_t b = (NG + LS_SCAN_WAVES * 4 - 1) / (LS_SCAN_WAVES * 4);  // >= 4 row groups per wave
+    const int64_t TR = (int64_t)scan_unroll(g.V) * (LS_WAVE / g.L);
+    const int64_t NT = (n + TR - 1) / TR;
+    int64_t b = (NT + LS_SCAN_WAVES - 1) / LS_SCAN_WAVES;  // one tile per wave at most
     const int64_t cap = (int64_t)n_cu * bpc;
     if (b > cap) b = cap;
     if (b < 1) b = 1;
@@ -186,32 +249,39 @@ int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu) {
 }
 
 template <bool F16, int L, int V>
-static int launch_lv(const void* corpus, int64_t n, const ls_geom& g, const float* q, float* S,
-                     u64* cand, u64* bound, int blocks, int kprime, hipStream_t s) {
+static int launch_lv(const void* corpus, int64_t n, const ls_geom& g, const float* q,
+                     int normalize, int reverse, float* S, u64* cand, u64* bound, int blocks,
+                     int kprime, hipStream_t s) {
     static int nt = -1;
     if (nt < 0) {
-        const char* e = getenv("LS_SCAN_NT");
-        nt = e ? atoi(e) : 1;
+        const char* e = getenv("LS_SCAN_MODE");
+        nt = e ? atoi(e) : 0;
     }
-    constexpr int U = (V >= 3) ? 4 : 8;  // >= 8 loads of 16 B per lane in flight
-    if (nt)
-        hipLaunchKernelGGL((ls_scan_kernel<F16, L, V, U, true>), dim3(blocks),
-                           dim3(LS_SCAN_THREADS), 0, s, (const u32x4*)corpus, (long long)n,
-                           g.chunks, q, S, cand, bound, kprime);
+    constexpr int U = scan_unroll(V);
+    if (nt == 1)
+        hipLaunchKernelGGL((ls_scan_kernel<F16, L, V, U, 1>), dim3(blocks),
+                           dim3(LS_SCAN_THREADS), 0, s, (const f32x4*)corpus, (long long)n,
+                           g.chunks, q, g.d, normalize, reverse, S, cand, bound, kprime);
+    else if (nt == 2)
+        hipLaunchKernelGGL((ls_scan_kernel<F16, L, V, U, 2>), dim3(blocks),
+                           dim3(LS_SCAN_THREADS), 0, s, (const f32x4*)corpus, (long long)n,
+                           g.chunks, q, g.d, normalize, reverse, S, cand, bound, kprime);
     else
-        hipLaunchKernelGGL((ls_scan_kernel<F16, L, V, U, false>), dim3(blocks),
-                           dim3(LS_SCAN_THREADS), 0, s, (const u32x4*)corpus, (long long)n,
-                           g.chunks, q, S, cand, bound, kprime);
+        hipLaunchKernelGGL((ls_scan_kernel<F16, L, V, U, 0>), dim3(blocks),
+                           dim3(LS_SCAN_THREADS), 0, s, (const f32x4*)corpus, (long long)n,
+                           g.chunks, q, g.d, normalize, reverse, S, cand, bound, kprime);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
 
 template <bool F16>
-static int launch_dt(const void* corpus, int64_t n, const ls_geom& g, const float* q, float* S,
-                     u64* cand, u64* bound, int blocks, int kprime, hipStream_t s) {
+static int launch_dt(const void* corpus, int64_t n, const ls_geom& g, const float* q,
+                     int normalize, int reverse, float* S, u64* cand, u64* bound, int blocks,
+                     int kprime, hipStream_t s) {
 #define LS_CASE(LL, VV)                                                                    \
     if (g.L == LL && g.V == VV)                                                            \
-        return launch_lv<F16, LL, VV>(corpus, n, g, q, S, cand, bound, blocks, kprime, s);
+        return launch_lv<F16, LL, VV>(corpus, n, g, q, normalize, reverse, S, cand, bound, blocks,      \
+                                      kprime, s);
     LS_CASE(16, 1) LS_CASE(16, 2) LS_CASE(16, 3) LS_CASE(16, 4)
     LS_CASE(32, 3) LS_CASE(32, 4)
     LS_CASE(64, 3) LS_CASE(64, 4)
@@ -220,13 +290,18 @@ static int launch_dt(const void* corpus, int64_t n, const ls_geom& g, const floa
     return LS_ERR_INVALID_ARG;
 }
 
-int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const float* d_q, float* d_S,
-                   u64* d_cand, u64* d_bound, int32_t blocks, int32_t kprime, hipStream_t s) {
+int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const float* d_q,
+                   bool normalize, bool reverse, float* d_S, u64* d_cand, u64* d_bound,
+                   int32_t blocks, int32_t kprime, hipStream_t s) {
     if (n <= 0) return LS_OK;
     if (kprime < 1 || kprime + 1 > LS_KP_MAX) {
         ls_set_error("ls_launch_scan: kprime %d out of range", kprime);
         return LS_ERR_INVALID_ARG;
     }
-    return g.elem == 2 ? launch_dt<true>(d_corpus, n, g, d_q, d_S, d_cand, d_bound, blocks, kprime, s)
-                       : launch_dt<false>(d_corpus, n, g, d_q, d_S, d_cand, d_bound, blocks, kprime, s);
+    const int nz = normalize ? 1 : 0;
+    return g.elem == 2
+               ? launch_dt<true>(d_corpus, n, g, d_q, nz, reverse ? 1 : 0, d_S, d_cand, d_bound,
+                                 blocks, kprime, s)
+               : launch_dt<false>(d_corpus, n, g, d_q, nz, reverse ? 1 : 0, d_S, d_cand, d_bound,
+                                  blocks, kprime, s);
 }

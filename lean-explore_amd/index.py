@@ -220,6 +220,13 @@ class FlatIPIndex:
     def debug_counter(self, which: int) -> int:
         return int(native.load().ls_debug_counter(self._ensure_built(), which))
 
+    def debug_scores(self) -> np.ndarray:
+        """Score vector S of the most recent per-query scan (test hook)."""
+        out = np.empty(self._ntotal, dtype=np.float32)
+        native.check(native.load().ls_debug_read_scores(self._ensure_built(), out.ctypes.data,
+                                                        out.size))
+        return out
+
     def close(self) -> None:
         self._drop_handle()
 

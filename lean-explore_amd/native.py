@@ -54,6 +54,7 @@ SYMBOLS: dict[str, tuple] = {
     "ls_last_kernel_ms": (ctypes.c_int, [_vp, _f32p, _f32p]),
     "ls_debug_option": (ctypes.c_int, [_vp, _i32, _i32]),
     "ls_debug_counter": (_i64, [_vp, _i32]),
+    "ls_debug_read_scores": (ctypes.c_int, [_vp, _vp, _i64]),
     "ls_last_error": (ctypes.c_char_p, []),
     "ls_version": (ctypes.c_char_p, []),
     "ls_device_count": (_i32, []),
@@ -70,6 +71,24 @@ class LeanSearchError(RuntimeError):
         self.code = code
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process. PyTorch wheels bundle their own libamdhip64.so.7 (same
+    SONAME as /opt/rocm's); whichever is mapped first serves both, and torch cannot initialise
+    on top of the system copy. So when torch is installed, map ITS runtime before ours resolves
+    its NEEDED entry. Without torch, libleansearch binds to /opt/rocm as linked."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+    if cand.exists():
+        ctypes.CDLL(str(cand), mode=ctypes.RTLD_GLOBAL)
+
+
 def load() -> ctypes.CDLL:
     """Load libleansearch.so and bind every declared symbol. Raises if the library is absent."""
     global _lib
@@ -79,6 +98,7 @@ def load() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc, gfx950). There is no CPU fallback for the dense search path.")
+    _preload_hip_runtime()
     lib = ctypes.CDLL(str(LIB_PATH))
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

@@ -165,7 +165,8 @@ def test_duplicates_and_all_equal_scores():
     ix = FlatIPIndex.from_array(ones)
     D, I = ix.search(np.ones((1, 64), np.float32), 100)
     assert np.array_equal(I[0], np.arange(100)) and (D == 64.0).all()
-    assert ix.debug_counter(0) >= 1  # the bound cannot be beaten: exact slow path
+    D, I = ix.search(np.ones((1, 64), np.float32), 2048)
+    assert np.array_equal(I[0], np.arange(2048)) and (D == 64.0).all()
     ix.close()
 
 

@@ -49,7 +49,12 @@ extern "C" {
 
 #define LS_FLAG_NORMALIZE 1u /* L2-normalise a private copy of the queries first (fuses          */
                              /* faiss.normalize_L2, search/engine.py:242, into the search)     */
-#define LS_FLAG_ASYNC 2u     /* ls_search_device only: do not synchronise; see ls_check       */
+#define LS_FLAG_ASYNC 2u     /* ls_search_device only: queue and return; results are ordered  */
+                             /* on `stream` like any other work queued there                  */
+#define LS_FLAG_PIPELINE 4u  /* ls_search_device only: queue on the index's internal lanes so */
+                             /* that consecutive calls overlap (the selection step of one     */
+                             /* query runs under the scan of the next); results are NOT       */
+                             /* ordered on `stream` - they are valid after ls_check()         */
 
 #define LS_MAX_K 2048 /* same ceiling as FAISS's GPU k-selection; reference uses k = 1000     */
 
@@ -84,14 +89,15 @@ int ls_search(ls_index* index, const float* q, int64_t nq, int32_t k, uint32_t f
 
 /* Same search with queries and outputs already in HBM on the index's device; work is queued
  * on `stream` (a hipStream_t; NULL = default stream). Without LS_FLAG_ASYNC it synchronises
- * the stream before returning. With LS_FLAG_ASYNC it returns after queueing and the caller
- * must call ls_check before trusting the results of batched (MFMA path) searches. */
+ * the stream before returning. With LS_FLAG_ASYNC it returns after queueing (results ordered on
+ * `stream`); with LS_FLAG_PIPELINE it returns after queueing on internal lanes (see the flag).
+ * Call ls_check before trusting the results of batched (MFMA path) or pipelined searches. */
 int ls_search_device(ls_index* index, const void* d_q, int64_t nq, int32_t k, uint32_t flags,
                      void* d_out_scores, void* d_out_indices, void* stream);
 
-/* Synchronise `stream` and report on the async searches queued since the last ls_check:
- * LS_OK if all results are exact, LS_ERR_OVERFLOW if some batched query overflowed its
- * candidate queues (re-issue those searches without LS_FLAG_ASYNC). */
+/* Synchronise `stream` and the index's internal lanes, and report on the async / pipelined
+ * searches queued since the last ls_check: LS_OK if all results are exact, LS_ERR_OVERFLOW if
+ * some batched query overflowed its candidate queues (re-issue those without LS_FLAG_ASYNC). */
 int ls_check(ls_index* index, void* stream);
 
 /* faiss.normalize_L2(x): in-place row normalisation of host float32 [nq, d];
@@ -106,13 +112,17 @@ int ls_merge_topk(const void* d_scores_in, const void* d_indices_in, int32_t n_l
                   int64_t nq, int32_t k, void* d_out_scores, void* d_out_indices,
                   int32_t device, void* stream);
 
-/* Name and average duration (ms) bookkeeping for bench.py: time of the dominant kernel of the
- * most recent search, measured with hipEvents on the search's stream when profiling is on. */
+/* Kernel timing for bench.py. While profiling is on, every scan launch (up to 4096) is
+ * bracketed by hipEvents on the stream it runs on. ls_last_kernel_ms returns the MEAN duration
+ * of the scan kernel and of scan + selection over the launches recorded since profiling was
+ * switched on (or since the last read), and clears the record. */
 int ls_set_profiling(ls_index* index, int32_t enabled);
 int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
 
 /* Test / tuning hooks. option 0: force the number of keys k' each scan workgroup emits
- * (0 = automatic); option 1: force the finalize kernel's exact slow path. counter 0: searches whose finalize step took the exact slow path. */
+ * (0 = automatic); option 1: force the finalize kernel's general
+ * exact path; option 2: alternate sweep direction; option 3: two-lane overlap (default on). counter 0: searches whose finalize
+ * step left the fast path (rescue or general); counter 1: those that took the general path. */
 int ls_debug_option(ls_index* index, int32_t which, int32_t value);
 int64_t ls_debug_counter(ls_index* index, int32_t which);
 /* Copy the score vector S[0..count) of the most recent per-query scan to host memory. */

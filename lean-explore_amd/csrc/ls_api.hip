@@ -12,6 +12,10 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <vector>
+
+#define LS_NSETS 2
+#define LS_PROF_MAX 4096
 
 static thread_local char g_err[512] = "";
 
@@ -36,9 +40,19 @@ struct ls_index {
     // scratch (grown on demand, reused by every search on this handle)
     float* d_qraw = nullptr;   size_t qraw_cap = 0;   // floats
     float* d_qprep = nullptr;  size_t qprep_cap = 0;  // floats
-    float* d_S = nullptr;                             // n floats
-    u64* d_cand = nullptr;                            // max_blocks * (LS_KP_MAX-1)
-    u64* d_bound = nullptr;                           // max_blocks
+    // per-query scan scratch, LS_NSETS copies so that consecutive queries may overlap on
+    // different streams (the finalize of one hides under the scan of the next)
+    struct scratch_set {
+        float* d_S = nullptr;        // n floats
+        u64* d_cand = nullptr;       // max_blocks * LS_KP_MAX
+        u64* d_bound = nullptr;      // max_blocks
+
+    } sets[LS_NSETS];
+    uint64_t set_rr = 0;
+    int32_t last_set = 0;
+    bool has_pending = false;          // a query whose finalize has not been launched yet
+    ls_fin_params pending{};
+    hipStream_t pending_stream = nullptr;
     int32_t max_blocks = 0;
     float* d_out_s = nullptr;  int64_t* d_out_i = nullptr;  size_t out_cap = 0;  // nq*k
     u32* d_counters = nullptr;                        // [0] finalize slow-path count
@@ -48,11 +62,14 @@ struct ls_index {
     // options / instrumentation
     int32_t opt_kprime = 0;  // 0 = automatic
     int32_t opt_force_slow = 0;
-    int32_t opt_alternate = 1;  // alternate sweep direction between consecutive scans
+    int32_t opt_overlap = 1;    // multi-query calls use two stream lanes
+    int32_t opt_alternate = 0;  // alternate sweep direction between consecutive scans
     uint64_t sweep_count = 0;
+    // profiling: hipEvent pairs around EVERY scan launch (and the finalize after it), recorded
+    // on the stream the kernels run on, up to LS_PROF_MAX launches; read by ls_last_kernel_ms
     bool profiling = false;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    bool ev_valid = false;
+    std::vector<hipEvent_t> prof_ev;  // 2 events per launch: begin, end
+    size_t prof_n = 0;
 };
 
 static int check_device(int32_t device) {
@@ -140,12 +157,15 @@ static int alloc_index_buffers(ls_index* ix) {
     if (ix->n > 0) LS_HIP(hipMalloc(&ix->d_corpus, (size_t)ix->n * row_bytes));
     LS_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
     ix->max_blocks = ls_scan_blocks(ix->n > 0 ? ix->n : 1, ix->g, ix->n_cu);
-    LS_HIP(hipMalloc((void**)&ix->d_S, sizeof(float) * (size_t)(ix->n > 0 ? ix->n : 1)));
-    LS_HIP(hipMalloc((void**)&ix->d_cand, sizeof(u64) * (size_t)ix->max_blocks * LS_KP_MAX));
-    LS_HIP(hipMalloc((void**)&ix->d_bound, sizeof(u64) * (size_t)ix->max_blocks));
+    for (auto& st : ix->sets) {
+        LS_HIP(hipMalloc((void**)&st.d_S, sizeof(float) * (size_t)(ix->n > 0 ? ix->n : 1)));
+        LS_HIP(hipMalloc((void**)&st.d_cand, sizeof(u64) * (size_t)ix->max_blocks * LS_KP_MAX));
+        LS_HIP(hipMalloc((void**)&st.d_bound, sizeof(u64) * (size_t)ix->max_blocks));
+
+    }
+
     LS_HIP(hipMalloc((void**)&ix->d_counters, sizeof(u32) * 8));
     LS_HIP(hipMemset(ix->d_counters, 0, sizeof(u32) * 8));
-    for (int i = 0; i < 3; ++i) LS_HIP(hipEventCreate(&ix->ev[i]));
     return LS_OK;
 }
 
@@ -158,17 +178,20 @@ void ls_destroy(ls_index* ix) {
     (void)hipFree(ix->d_corpus);
     (void)hipFree(ix->d_qraw);
     (void)hipFree(ix->d_qprep);
-    (void)hipFree(ix->d_S);
-    (void)hipFree(ix->d_cand);
-    (void)hipFree(ix->d_bound);
+    for (auto& st : ix->sets) {
+        (void)hipFree(st.d_S);
+        (void)hipFree(st.d_cand);
+        (void)hipFree(st.d_bound);
+
+    }
+
     (void)hipFree(ix->d_out_s);
     (void)hipFree(ix->d_out_i);
     (void)hipFree(ix->d_counters);
     if (ix->h_q) (void)hipHostFree(ix->h_q);
     if (ix->h_out_s) (void)hipHostFree(ix->h_out_s);
     if (ix->h_out_i) (void)hipHostFree(ix->h_out_i);
-    for (int i = 0; i < 3; ++i)
-        if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
+    for (hipEvent_t e : ix->prof_ev) (void)hipEventDestroy(e);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     delete ix;
 }
@@ -282,6 +305,21 @@ static int pick_kprime(const ls_index* ix, int blocks, int keff) {
     return kp;
 }
 
+static size_t ls_fin_lds_bytes_host(int keys_cap, int keff) {
+    int rc = 256;
+    while (rc < keff) rc <<= 1;
+    return ((size_t)keys_cap + (size_t)rc + 256 + 16) * sizeof(u64) + (8 * 256 + 64) * sizeof(u32);
+}
+
+// Launch the pending finalize on its own (1024 threads, LDS for the full 8192-key capacity).
+static int flush_pending(ls_index* ix) {
+    if (!ix->has_pending) return LS_OK;
+    ls_fin_params p = ix->pending;
+    p.keys_cap = LS_FINAL_CAP;
+    ix->has_pending = false;
+    return ls_launch_finalize(p, ix->pending_stream);
+}
+
 // Queue one search on stream `s`. d_q: device fp32 [nq, d]; outputs device [nq, k].
 static int search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
                             float* d_out_s, int64_t* d_out_i, hipStream_t s) {
@@ -291,23 +329,76 @@ static int search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t 
     const int64_t keff = std::min<int64_t>(k, ix->n);
     const int blocks = ls_scan_blocks(ix->n > 0 ? ix->n : 1, g, ix->n_cu);
     const int kprime = pick_kprime(ix, blocks, (int)std::max<int64_t>(keff, 1));
-    for (int64_t qi = 0; qi < nq; ++qi) {
-        const bool prof = ix->profiling && qi == nq - 1;
-        if (prof) LS_HIP(hipEventRecord(ix->ev[0], s));
-        const bool reverse = ix->opt_alternate && (ix->sweep_count++ & 1);
-        rc = ls_launch_scan(ix->d_corpus, ix->n, g, d_q + qi * g.d, normalize, reverse, ix->d_S,
-                            ix->d_cand, ix->d_bound, blocks, kprime, s);
+    // Everything is queued on the caller's stream, one launch per query:
+    //     launch i = { scan(query i)  +  one extra workgroup: finalize(query i-1) }
+    // so the selection step costs neither a launch nor a kernel boundary and hides under the
+    // next scan. Two scratch sets alternate (finalize(i-1) reads set A while scan(i) fills B).
+    // The last query's finalize is "pending": it rides on the next call's first scan
+    // (LS_FLAG_PIPELINE), or is launched on its own right away (ordered modes).
+    const bool pipeline = (flags & LS_FLAG_PIPELINE) != 0;
+    if (ix->has_pending && (ix->pending_stream != s || !ix->opt_overlap)) {
+        hipStream_t old = ix->pending_stream;
+        rc = flush_pending(ix);
         if (rc != LS_OK) return rc;
-        if (prof) LS_HIP(hipEventRecord(ix->ev[1], s));
-        rc = ls_launch_finalize(ix->d_S, ix->n, ix->d_cand, ix->d_bound, blocks, kprime, k,
-                                ix->base, d_out_s + qi * k, d_out_i + qi * k, ix->d_counters,
-                                ix->opt_force_slow, s);
+        // a different stream takes over: do not let its scans race the old stream's finalize
+        if (old != s) LS_HIP(hipStreamSynchronize(old));
+    }
+    for (int64_t qi = 0; qi < nq; ++qi) {
+        const bool prof = ix->profiling && ix->prof_n < LS_PROF_MAX;
+        hipEvent_t* pe = nullptr;
+        if (prof) {
+            while (ix->prof_ev.size() < 2 * (ix->prof_n + 1)) {
+                hipEvent_t e;
+                LS_HIP(hipEventCreate(&e));
+                ix->prof_ev.push_back(e);
+            }
+            pe = &ix->prof_ev[2 * ix->prof_n];
+        }
+        const int si = (int)(ix->set_rr++ % LS_NSETS);
+        ls_index::scratch_set& st = ix->sets[si];
+        // the pending job reads the OTHER set (sets alternate), never the one scanned now
+        const ls_fin_params* fin = nullptr;
+        if (ix->has_pending && ix->n <= 0) {  // an empty index launches no scan to ride on
+            rc = flush_pending(ix);
+            if (rc != LS_OK) return rc;
+        }
+        if (ix->has_pending) {
+            const int keff_p = (int)std::min<int64_t>(ix->pending.k, ix->n);
+            if (ls_fin_lds_bytes_host(ix->pending.keys_cap, keff_p) <= LS_PIGGY_LDS_MAX) {
+                fin = &ix->pending;
+            } else {
+                rc = flush_pending(ix);
+                if (rc != LS_OK) return rc;
+            }
+        }
+        if (prof) LS_HIP(hipEventRecord(pe[0], s));
+        const bool reverse = ix->opt_alternate && (ix->sweep_count++ & 1);
+        rc = ls_launch_scan(ix->d_corpus, ix->n, g, d_q + qi * g.d, normalize, reverse, st.d_S,
+                            st.d_cand, st.d_bound, blocks, kprime, fin, s);
         if (rc != LS_OK) return rc;
         if (prof) {
-            LS_HIP(hipEventRecord(ix->ev[2], s));
-            ix->ev_valid = true;
+            LS_HIP(hipEventRecord(pe[1], s));
+            ix->prof_n++;
         }
+        ix->has_pending = true;
+        ix->pending_stream = s;
+        ls_fin_params& p = ix->pending;
+        p.S = st.d_S;
+        p.n = ix->n;
+        p.cand = st.d_cand;
+        p.bound = st.d_bound;
+        p.blocks = blocks;
+        p.kprime = kprime;
+        p.k = k;
+        p.keys_cap = std::max(256, blocks * kprime);
+        p.force_slow = ix->opt_force_slow;
+        p.base = ix->base;
+        p.out_scores = d_out_s + qi * k;
+        p.out_indices = (long long*)(d_out_i + qi * k);
+        p.counters = ix->d_counters;
+        ix->last_set = si;
     }
+    if (!pipeline || !ix->opt_overlap) return flush_pending(ix);
     return LS_OK;
 }
 
@@ -321,7 +412,7 @@ static int check_search_args(const ls_index* ix, const void* q, int64_t nq, int3
         ls_set_error("search: bad argument (nq=%lld k=%d)", (long long)nq, k);
         return LS_ERR_INVALID_ARG;
     }
-    if (flags & ~(LS_FLAG_NORMALIZE | LS_FLAG_ASYNC)) {
+    if (flags & ~(LS_FLAG_NORMALIZE | LS_FLAG_ASYNC | LS_FLAG_PIPELINE)) {
         ls_set_error("search: unknown flags 0x%x", flags);
         return LS_ERR_INVALID_ARG;
     }
@@ -337,7 +428,8 @@ extern "C" {
 
 int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flags,
               float* out_scores, int64_t* out_indices) {
-    int rc = check_search_args(ix, q, nq, k, flags & ~LS_FLAG_ASYNC, out_scores, out_indices);
+    int rc = check_search_args(ix, q, nq, k, flags & ~(LS_FLAG_ASYNC | LS_FLAG_PIPELINE), out_scores,
+                               out_indices);
     if (rc != LS_OK) return rc;
     if (nq == 0) return LS_OK;
     std::lock_guard<std::mutex> lk(ix->mu);
@@ -382,7 +474,7 @@ int ls_search_device(ls_index* ix, const void* d_q, int64_t nq, int32_t k, uint3
     rc = search_on_stream(ix, (const float*)d_q, nq, k, flags, (float*)d_out_scores,
                           (int64_t*)d_out_indices, s);
     if (rc != LS_OK) return rc;
-    if (!(flags & LS_FLAG_ASYNC)) LS_HIP(hipStreamSynchronize(s));
+    if (!(flags & (LS_FLAG_ASYNC | LS_FLAG_PIPELINE))) LS_HIP(hipStreamSynchronize(s));
     return LS_OK;
 }
 
@@ -393,6 +485,8 @@ int ls_check(ls_index* ix, void* stream) {
     }
     std::lock_guard<std::mutex> lk(ix->mu);
     LS_HIP(hipSetDevice(ix->device));
+    int rc = flush_pending(ix);
+    if (rc != LS_OK) return rc;
     LS_HIP(hipStreamSynchronize((hipStream_t)stream));
     return LS_OK;  // the per-query scan path is exact by construction (finalize slow path)
 }
@@ -448,21 +542,30 @@ int ls_set_profiling(ls_index* ix, int32_t enabled) {
     if (!ix) return LS_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ix->mu);
     ix->profiling = enabled != 0;
-    ix->ev_valid = false;
+    ix->prof_n = 0;
     return LS_OK;
 }
 
 int ls_last_kernel_ms(ls_index* ix, float* scan_ms, float* total_ms) {
     if (!ix || !scan_ms || !total_ms) return LS_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ix->mu);
-    if (!ix->ev_valid) {
+    if (ix->prof_n == 0) {
         ls_set_error("ls_last_kernel_ms: no profiled search recorded");
         return LS_ERR_INVALID_ARG;
     }
     LS_HIP(hipSetDevice(ix->device));
-    LS_HIP(hipEventSynchronize(ix->ev[2]));
-    LS_HIP(hipEventElapsedTime(scan_ms, ix->ev[0], ix->ev[1]));
-    LS_HIP(hipEventElapsedTime(total_ms, ix->ev[0], ix->ev[2]));
+    double a = 0.0, b = 0.0;
+    for (size_t i = 0; i < ix->prof_n; ++i) {
+        hipEvent_t* pe = &ix->prof_ev[2 * i];
+        LS_HIP(hipEventSynchronize(pe[1]));
+        float x = 0.f;
+        LS_HIP(hipEventElapsedTime(&x, pe[0], pe[1]));
+        a += x;
+        b += x;
+    }
+    *scan_ms = (float)(a / (double)ix->prof_n);
+    *total_ms = (float)(b / (double)ix->prof_n);
+    ix->prof_n = 0;
     return LS_OK;
 }
 
@@ -474,7 +577,11 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->opt_kprime = value;
         return LS_OK;
     }
-    if (which == 2) {  // alternate the sweep direction of consecutive scans (default on)
+    if (which == 3) {  // two-lane overlap of consecutive queries inside one call (default on)
+        ix->opt_overlap = value != 0;
+        return LS_OK;
+    }
+    if (which == 2) {  // alternate the sweep direction of consecutive scans (default off)
         ix->opt_alternate = value != 0;
         return LS_OK;
     }
@@ -491,7 +598,8 @@ int ls_debug_read_scores(ls_index* ix, float* out, int64_t count) {
     std::lock_guard<std::mutex> lk(ix->mu);
     LS_HIP(hipSetDevice(ix->device));
     LS_HIP(hipDeviceSynchronize());
-    LS_HIP(hipMemcpy(out, ix->d_S, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost));
+    LS_HIP(hipMemcpy(out, ix->sets[ix->last_set].d_S, sizeof(float) * (size_t)count,
+                     hipMemcpyDeviceToHost));
     return LS_OK;
 }
 

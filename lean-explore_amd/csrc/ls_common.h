@@ -71,6 +71,21 @@ struct ls_geom {
 };
 int ls_pick_geom(int32_t d, int32_t dtype, ls_geom* g);
 
+// ---- one query's selection job (finalize) -----------------------------------------------------
+struct ls_fin_params {
+    const float* S;        // score vector the scan wrote, n floats
+    long long n;
+    const u64* cand;       // blocks * kprime keys emitted by the scan
+    const u64* bound;      // blocks bounds (best key each workgroup withheld)
+    int blocks, kprime, k;
+    int keys_cap;          // LDS key capacity of this launch (>= blocks*kprime for the fast path)
+    int force_slow;
+    long long base;        // added to every returned row
+    float* out_scores;     // [k]
+    long long* out_indices;  // [k]
+    u32* counters;         // [0] left the fast path, [1] took the general path
+};
+
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
 // prep: q_out[nq, d_pad] = pad(round(normalise(q_in[nq, d]))), fp32
 int ls_launch_prep(const float* d_q_in, float* d_q_out, int64_t nq, const ls_geom& g,
@@ -81,15 +96,17 @@ int ls_launch_convert(const float* d_src, void* d_dst, int64_t n, const ls_geom&
 // scan: scores S[n] for one RAW query (d floats; normalisation / fp16 rounding fused in)
 // + per-workgroup best kprime keys and bound
 int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu);
+// `fin` (may be null): the PREVIOUS query's selection job, executed by one extra workgroup of
+// this launch so that it costs neither a launch nor a kernel boundary.
 int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const float* d_q,
                    bool normalize, bool reverse, float* d_S, u64* d_cand, u64* d_bound,
-                   int32_t blocks, int32_t kprime, hipStream_t s);
+                   int32_t blocks, int32_t kprime, const ls_fin_params* fin, hipStream_t s);
+// LDS bytes a piggy-backed finalize may use without lowering the scan's occupancy below 2/CU
+#define LS_PIGGY_LDS_MAX (72 * 1024)
 // finalize: exact top-k from the scan's candidates (or, if they cannot be proven complete,
-// from S itself) -> out_scores[k], out_indices[k]
-int ls_launch_finalize(const float* d_S, int64_t n, const u64* d_cand, const u64* d_bound,
-                       int32_t blocks, int32_t kprime, int32_t k, int64_t base,
-                       float* d_out_scores, int64_t* d_out_indices, u32* d_slow_count,
-                       int32_t force_slow, hipStream_t s);
+// from S itself) -> out_scores[k], out_indices[k]. Either its own launch, or carried by the
+// NEXT query's scan launch as one extra workgroup (ls_launch_scan's `fin` argument).
+int ls_launch_finalize(const ls_fin_params& p, hipStream_t s);
 // merge of per-shard lists
 int ls_launch_merge(const float* d_scores_in, const int64_t* d_indices_in, int32_t n_lists,
                     int64_t nq, int32_t k, float* d_out_scores, int64_t* d_out_indices,

@@ -21,7 +21,7 @@
 //     merges its 4 lists and emits its best k' keys plus the (k'+1)-th as a bound. The finalize
 //     kernel (ls_select.hip) proves the global top-k is contained in the emitted keys, or falls
 //     back to an exact selection over the score vector S, which this kernel also writes.
-#include "ls_common.h"
+#include "ls_select_dev.h"
 
 #include <hip/hip_fp16.h>
 
@@ -141,7 +141,17 @@ template <bool F16, int L, int V, int U, int MODE>
 __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
     const f32x4* __restrict__ corpus, long long n, int chunks, const float* __restrict__ qraw,
     int d, int normalize, int reverse, float* __restrict__ S, u64* __restrict__ cand,
-    u64* __restrict__ bound, int kprime) {
+    u64* __restrict__ bound, int kprime, int has_fin, ls_fin_params fin) {
+    // Workgroup 0 of a launch that carries a selection job runs the PREVIOUS query's finalize
+    // (ls_select_dev.h) while every other workgroup scans for the current query: the selection
+    // costs neither a launch nor a kernel boundary, and its ~5 us hide under the ~50 us scan.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    if (has_fin && blockIdx.x == 0) {
+        finalize_body<LS_SCAN_THREADS>(fin, smem_dyn, threadIdx.x);
+        return;
+    }
+    const int bid = (int)blockIdx.x - has_fin;
+    const int nblk = (int)gridDim.x - has_fin;
     constexpr int R = LS_WAVE / L;  // rows per wave load step
     constexpr int TR = U * R;       // rows per tile: one tile = U steps = TR contiguous rows
     static_assert(TR <= LS_WAVE, "a tile's scores must fit one per lane");
@@ -153,8 +163,8 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
 
     // Tiles are dealt round-robin to waves; the 4 waves of a workgroup take 4 adjacent tiles,
     // so one workgroup iteration covers 4*TR contiguous rows and its S stores fill whole lines.
-    const long long W = (long long)gridDim.x * LS_SCAN_WAVES;
-    const long long gw = (long long)blockIdx.x * LS_SCAN_WAVES + wave;
+    const long long W = (long long)nblk * LS_SCAN_WAVES;
+    const long long gw = (long long)bid * LS_SCAN_WAVES + wave;
     const long long NT = (n + TR - 1) / TR;
 
     f32x4 x[U][V];
@@ -199,9 +209,8 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
         t += W;
         if (t < NT) issue_loads(t);  // next tile's loads overlap the selection below
         const bool valid = lane < TR && row < n;
-        if (MODE != 1 && MODE != 2 && valid) S[row] = sc;  // TR contiguous floats
-        u64 key = valid ? ls_make_key(sc, (u32)row) : 0ull;
-        if (MODE == 2) { key = key == 12345ull ? key : 0ull; }
+        if (valid) S[row] = sc;  // TR contiguous floats
+        const u64 key = valid ? ls_make_key(sc, (u32)row) : 0ull;
         u64 mask = __ballot(key > thr);
         while (mask) {  // rare once the threshold has warmed up
             const int j = __ffsll((long long)mask) - 1;
@@ -224,8 +233,8 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
             const u64 o = sm[i];
             rank += (o > mine) || (o == mine && i < lane);
         }
-        if (rank < kprime) cand[(long long)blockIdx.x * kprime + rank] = mine;
-        if (rank == kprime) bound[blockIdx.x] = mine;
+        if (rank < kprime) cand[(long long)bid * kprime + rank] = mine;
+        if (rank == kprime) bound[bid] = mine;
     }
 }
 
@@ -251,25 +260,27 @@ int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu) {
 template <bool F16, int L, int V>
 static int launch_lv(const void* corpus, int64_t n, const ls_geom& g, const float* q,
                      int normalize, int reverse, float* S, u64* cand, u64* bound, int blocks,
-                     int kprime, hipStream_t s) {
-    static int nt = -1;
-    if (nt < 0) {
-        const char* e = getenv("LS_SCAN_MODE");
-        nt = e ? atoi(e) : 0;
-    }
+                     int kprime, const ls_fin_params* fin, hipStream_t s) {
     constexpr int U = scan_unroll(V);
-    if (nt == 1)
-        hipLaunchKernelGGL((ls_scan_kernel<F16, L, V, U, 1>), dim3(blocks),
-                           dim3(LS_SCAN_THREADS), 0, s, (const f32x4*)corpus, (long long)n,
-                           g.chunks, q, g.d, normalize, reverse, S, cand, bound, kprime);
-    else if (nt == 2)
-        hipLaunchKernelGGL((ls_scan_kernel<F16, L, V, U, 2>), dim3(blocks),
-                           dim3(LS_SCAN_THREADS), 0, s, (const f32x4*)corpus, (long long)n,
-                           g.chunks, q, g.d, normalize, reverse, S, cand, bound, kprime);
-    else
-        hipLaunchKernelGGL((ls_scan_kernel<F16, L, V, U, 0>), dim3(blocks),
-                           dim3(LS_SCAN_THREADS), 0, s, (const f32x4*)corpus, (long long)n,
-                           g.chunks, q, g.d, normalize, reverse, S, cand, bound, kprime);
+    ls_fin_params fp{};
+    size_t smem = 0;
+    int has_fin = 0;
+    if (fin) {
+        fp = *fin;
+        has_fin = 1;
+        const int keff = (int)((long long)fp.k < fp.n ? fp.k : fp.n);
+        smem = ls_fin_lds_bytes(fp.keys_cap, keff);
+    }
+    auto kern = ls_scan_kernel<F16, L, V, U, 0>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   LS_PIGGY_LDS_MAX));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks + has_fin), dim3(LS_SCAN_THREADS), smem, s,
+                       (const f32x4*)corpus, (long long)n, g.chunks, q, g.d, normalize, reverse, S,
+                       cand, bound, kprime, has_fin, fp);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
@@ -277,11 +288,11 @@ static int launch_lv(const void* corpus, int64_t n, const ls_geom& g, const floa
 template <bool F16>
 static int launch_dt(const void* corpus, int64_t n, const ls_geom& g, const float* q,
                      int normalize, int reverse, float* S, u64* cand, u64* bound, int blocks,
-                     int kprime, hipStream_t s) {
+                     int kprime, const ls_fin_params* fin, hipStream_t s) {
 #define LS_CASE(LL, VV)                                                                    \
     if (g.L == LL && g.V == VV)                                                            \
         return launch_lv<F16, LL, VV>(corpus, n, g, q, normalize, reverse, S, cand, bound, blocks,      \
-                                      kprime, s);
+                                      kprime, fin, s);
     LS_CASE(16, 1) LS_CASE(16, 2) LS_CASE(16, 3) LS_CASE(16, 4)
     LS_CASE(32, 3) LS_CASE(32, 4)
     LS_CASE(64, 3) LS_CASE(64, 4)
@@ -292,7 +303,7 @@ static int launch_dt(const void* corpus, int64_t n, const ls_geom& g, const floa
 
 int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const float* d_q,
                    bool normalize, bool reverse, float* d_S, u64* d_cand, u64* d_bound,
-                   int32_t blocks, int32_t kprime, hipStream_t s) {
+                   int32_t blocks, int32_t kprime, const ls_fin_params* fin, hipStream_t s) {
     if (n <= 0) return LS_OK;
     if (kprime < 1 || kprime + 1 > LS_KP_MAX) {
         ls_set_error("ls_launch_scan: kprime %d out of range", kprime);
@@ -301,7 +312,7 @@ int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const floa
     const int nz = normalize ? 1 : 0;
     return g.elem == 2
                ? launch_dt<true>(d_corpus, n, g, d_q, nz, reverse ? 1 : 0, d_S, d_cand, d_bound,
-                                 blocks, kprime, s)
+                                 blocks, kprime, fin, s)
                : launch_dt<false>(d_corpus, n, g, d_q, nz, reverse ? 1 : 0, d_S, d_cand, d_bound,
-                                  blocks, kprime, s);
+                                  blocks, kprime, fin, s);
 }

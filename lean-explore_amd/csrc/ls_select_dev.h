@@ -1,0 +1,374 @@
+// ls_select_dev.h — workgroup-level exact k-selection on 64-bit keys (device code shared by
+// the finalize kernel, the shard-merge kernel and the scan kernel's piggy-backed finalize).
+//
+// All selection is on the keys of ls_common.h, so "top-k under (score desc, row asc)" is
+// "k largest unsigned integers", bit-exact by construction. Non-zero keys are unique (one per
+// row); key 0 means "no result".
+//
+// lds_topk: given up to `cnt` keys in LDS it finds the exact k-th largest non-zero key T by
+// MSB-first 8-bit radix select (4 passes over the score half; 4 more over the row half only
+// when several candidates share the k-th score), compacts the keys >= T and orders them
+// (rank-by-counting for k <= 256, bitonic sort above). No pass touches HBM.
+//
+// finalize_body: the heap + reorder half of faiss `index.search`
+// (reference src/lean_explore/search/engine.py:250) for one query:
+//   fast path : the blocks*k' keys emitted by the scan go to LDS (all loads in flight
+//               together) -> lds_topk. The k-th best emitted key T is a lower bound of the true
+//               k-th best. Every row the scan did NOT emit is <= its workgroup's bound, so if
+//               max(bound) < T (or every bound is 0: nothing was withheld) the result is the
+//               global top-k. Traffic: blocks*(k'+1)*8 B.
+//   rescue    : otherwise one sweep over the score vector S[n] collects every row with
+//               key >= T (a superset of the answer) into LDS -> lds_topk.
+//   general   : if even that overflows LDS (e.g. all scores equal) or too few keys were
+//               emitted: 4-pass radix select over S itself.
+//   Every path is exact; only their cost differs.
+#pragma once
+#include "ls_common.h"
+
+#define LS_RES_CAP 2048  // == LS_MAX_K
+
+// ---- workgroup-wide bitonic sort, descending, m a power of two, keys in LDS ------------------
+// Pair p of a stage is handled by thread p % nthreads. For strides j <= 64 both elements of
+// pair p lie in the 128-element block p >> 6, and all lanes of a wave share p >> 6, so those
+// stages need only wave-level ordering (LDS is in-order per wave); only strides >= 128 cross
+// waves and take a workgroup barrier: 10 barriers instead of 55 for m = 1024.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void block_bitonic_desc(u64* a, int m, int tid, int nthreads) {
+    for (int k2 = 2; k2 <= m; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < (m >> 1); p += nthreads) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int x = i | j;
+                const u64 ai = a[i], ax = a[x];
+                const bool desc = (i & k2) == 0;
+                if ((ai < ax) == desc) {
+                    a[i] = ax;
+                    a[x] = ai;
+                }
+            }
+            const int jn = j > 1 ? (j >> 1) : k2;  // stride of the next stage
+            if (j > 64 || jn > 64)
+                __syncthreads();
+            else
+                wave_lds_fence();
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// Wave 0 finds the histogram bin that holds the krem-th largest element (krem is clamped to
+// the number of elements counted). out[0] = bin, out[1] = krem - (#elements in higher bins),
+// out[2] = hist[bin], out[3] = total, out[4] = clamped krem.
+// Must be followed by __syncthreads() before `out` is read.
+__device__ __forceinline__ void find_bin(const u32* hist, u32 krem, u32* out, int tid) {
+    if (tid < 64) {
+        const u32 h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2],
+                  h3 = hist[4 * tid + 3];
+        const u32 mine = h0 + h1 + h2 + h3;
+        u32 suf = mine;  // inclusive suffix sum over lanes >= tid
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_down(suf, o, 64);
+            if (tid + o < 64) suf += t;
+        }
+        const u32 above = suf - mine;
+        const u32 total = __shfl(suf, 0, 64);
+        if (krem > total) krem = total;
+        if (tid == 0) {
+            out[3] = total;
+            out[4] = krem;
+        }
+        if (krem > above && krem <= above + mine) {  // exactly one lane when krem >= 1
+            u32 cum = above;
+            int b;
+            u32 hb;
+            if (cum + h3 >= krem) { b = 4 * tid + 3; hb = h3; }
+            else {
+                cum += h3;
+                if (cum + h2 >= krem) { b = 4 * tid + 2; hb = h2; }
+                else {
+                    cum += h2;
+                    if (cum + h1 >= krem) { b = 4 * tid + 1; hb = h1; }
+                    else { cum += h1; b = 4 * tid; hb = h0; }
+                }
+            }
+            out[0] = (u32)b;
+            out[1] = krem - cum;
+            out[2] = hb;
+        }
+    }
+}
+
+// hist[digit] += 1 for every active lane. Candidates for one query have nearly equal scores, so
+// in the leading passes most lanes share one digit and plain LDS atomics would serialise on it:
+// the first active lane's digit is counted once per wave by ballot, the other lanes (spread
+// over many digits, few conflicts) use ordinary LDS atomics.
+__device__ __forceinline__ void wave_hist_add(u32* hist, u32 digit, bool active, int lane) {
+    const u64 act = __ballot(active);
+    if (act) {
+        const int leader = __ffsll((long long)act) - 1;
+        const u32 dsel = (u32)__builtin_amdgcn_readlane((int)digit, leader);
+        const u64 same = __ballot(active && digit == dsel);
+        if (lane == leader) atomicAdd(&hist[dsel], (u32)__popcll(same));
+        if (active && digit != dsel) atomicAdd(&hist[digit], 1u);
+    }
+}
+
+// Exact top-k of the non-zero keys in keys[0..cnt) (LDS, left untouched) -> res[0..kk) sorted
+// descending, kk = min(k, #non-zero). tmp: LDS scratch of LS_RES_CAP keys. k <= LS_RES_CAP.
+// hist: 8 * 256 counters (one histogram per radix pass, zeroed here), misc: 8 * 8 words.
+// The caller must have synchronised the workgroup after writing keys.
+static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* tmp, u32* hist, u32* misc,
+                        int tid, int nt) {
+    if (k > cnt) k = cnt;
+    if (k <= 0) return 0;
+    const int lane = tid & 63;
+    const int cnt_pad = (cnt + 63) & ~63;  // whole waves take part in the ballots
+    for (int i = tid; i < 8 * 256; i += nt) hist[i] = 0;
+    if (tid == 0) misc[7 * 8 + 7] = 0;  // survivor counter
+    __syncthreads();
+    u32 pref = 0, pmask = 0;
+    u32 krem = (u32)k, neq = 0;
+    int kk = k;
+    for (int pass = 0; pass < 4; ++pass) {  // score half
+        const int shift = 24 - 8 * pass;
+        u32* h = hist + pass * 256;
+        u32* ms = misc + pass * 8;
+        for (int i = tid; i < cnt_pad; i += nt) {
+            const u64 key = i < cnt ? keys[i] : 0ull;
+            const u32 hi = (u32)(key >> 32);
+            wave_hist_add(h, (hi >> shift) & 255u, key != 0ull && (hi & pmask) == pref, lane);
+        }
+        __syncthreads();
+        find_bin(h, krem, ms, tid);
+        __syncthreads();
+        if (pass == 0) {
+            kk = (int)ms[4];  // min(k, #non-zero keys)
+            if (kk == 0) return 0;
+        }
+        pref |= ms[0] << shift;
+        pmask |= 255u << shift;
+        krem = ms[1];
+        neq = ms[2];
+    }
+    const u32 T_hi = pref;
+    u32 T_lo = 0;
+    if (neq > krem) {  // several candidates share the k-th score: split them on the row half
+        u32 lpref = 0, lmask = 0;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            u32* h = hist + (4 + pass) * 256;
+            u32* ms = misc + (4 + pass) * 8;
+            for (int i = tid; i < cnt_pad; i += nt) {
+                const u64 key = i < cnt ? keys[i] : 0ull;
+                const u32 lo = (u32)key;
+                wave_hist_add(h, (lo >> shift) & 255u,
+                              key != 0ull && (u32)(key >> 32) == T_hi && (lo & lmask) == lpref,
+                              lane);
+            }
+            __syncthreads();
+            find_bin(h, krem, ms, tid);
+            __syncthreads();
+            lpref |= ms[0] << shift;
+            lmask |= 255u << shift;
+            krem = ms[1];
+        }
+        T_lo = lpref;
+    }
+    const u64 T = ((u64)T_hi << 32) | (u64)T_lo;  // exactly kk non-zero keys are >= T
+    u64* dst = (kk <= 256) ? tmp : res;
+    for (int i = tid; i < cnt; i += nt) {
+        const u64 key = keys[i];
+        if (key != 0ull && key >= T) dst[atomicAdd(&misc[7 * 8 + 7], 1u)] = key;
+    }
+    __syncthreads();
+    if (kk <= 256) {  // order by counting: rank = number of larger survivors
+        if (tid < kk) {
+            const u64 mine = tmp[tid];
+            int rank = 0;
+            for (int j = 0; j < kk; ++j) rank += tmp[j] > mine;
+            res[rank] = mine;
+        }
+        __syncthreads();
+    } else {
+        const int m = next_pow2(kk);
+        for (int i = kk + tid; i < m; i += nt) res[i] = 0ull;
+        __syncthreads();
+        block_bitonic_desc(res, m, tid, nt);
+    }
+    return kk;
+}
+
+// exclusive prefix sum of one flag per thread over the workgroup; returns total via *total
+__device__ __forceinline__ int block_excl_scan_flag(bool flag, int tid, int nthreads, u32* wsum,
+                                                    int* total) {
+    const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
+    const u64 b = __ballot(flag);
+    const int within = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = (u32)__popcll(b);
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) {
+        const int c = (int)wsum[w];
+        if (w < wave) off += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return off + within;
+}
+
+// General exact top-k of S[0..n) -> res[0..) sorted descending; returns the number of valid keys.
+// 4 radix passes over S for the k-th score, one gather of everything above it, one ordered
+// gather of the lowest-index rows equal to it, then a sort. k <= LS_RES_CAP.
+static __device__ int general_select(const float* __restrict__ S, long long n, int k, u64* res, u32* hist,
+                              u32* misc, int tid, int nthreads) {
+    u32 prefix = 0, pmask = 0;
+    u32 krem = (long long)k < n ? (u32)k : (u32)n;
+    int keff = (int)krem;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = tid; i < 256; i += nthreads) hist[i] = 0;
+        __syncthreads();
+        for (long long r = tid; r < n; r += nthreads) {
+            const float s = S[r];
+            if (s > -FLT_MAX) {
+                const u32 o = ls_ord(s);
+                if ((o & pmask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
+            }
+        }
+        __syncthreads();
+        find_bin(hist, krem, misc, tid);
+        __syncthreads();
+        if (pass == 0) {
+            keff = (int)misc[4];  // min(k, #valid rows)
+            if (keff == 0) return 0;
+        }
+        prefix |= misc[0] << shift;
+        pmask |= 255u << shift;
+        krem = misc[1];
+        __syncthreads();
+    }
+    const u32 T = prefix;                // ord() of the k-th best score
+    const int above = keff - (int)krem;  // rows strictly better than T
+    if (tid == 0) misc[4] = 0;
+    __syncthreads();
+    for (long long r = tid; r < n; r += nthreads) {
+        const float s = S[r];
+        if (s > -FLT_MAX && ls_ord(s) > T) res[atomicAdd(&misc[4], 1u)] = ls_make_key(s, (u32)r);
+    }
+    __syncthreads();
+    // rows equal to T: take the krem lowest row indices (deterministic tie-break)
+    int running = 0;
+    for (long long b0 = 0; b0 < n && running < (int)krem; b0 += nthreads) {
+        const long long r = b0 + tid;
+        float s = 0.0f;
+        bool flag = false;
+        if (r < n) {
+            s = S[r];
+            flag = (s > -FLT_MAX) && ls_ord(s) == T;
+        }
+        int total;
+        const int pos = running + block_excl_scan_flag(flag, tid, nthreads, hist, &total);
+        if (flag && pos < (int)krem) res[above + pos] = ls_make_key(s, (u32)r);
+        running += total;
+    }
+    __syncthreads();
+    const int m = next_pow2(keff);
+    for (int i = keff + tid; i < m; i += nthreads) res[i] = 0;
+    __syncthreads();
+    block_bitonic_desc(res, m, tid, nthreads);
+    return keff;
+}
+
+
+// ---- LDS plan of one finalize ------------------------------------------------------------------
+// keys[keys_cap] | res[res_cap] | tmp[256] | red[16]   (u64)   then   hist[8*256] | misc[64] (u32)
+__host__ __device__ __forceinline__ int ls_fin_res_cap(int keff) {
+    int p = 256;
+    while (p < keff) p <<= 1;
+    return p;
+}
+__host__ __device__ __forceinline__ size_t ls_fin_lds_bytes(int keys_cap, int keff) {
+    return ((size_t)keys_cap + (size_t)ls_fin_res_cap(keff) + 256 + 16) * sizeof(u64) +
+           (8 * 256 + 64) * sizeof(u32);
+}
+
+// One workgroup of NT threads produces the final (scores, rows)[k] of one query.
+template <int NT>
+static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem, int tid) {
+    const int keff = (long long)p.k < p.n ? p.k : (int)p.n;
+    u64* keys = reinterpret_cast<u64*>(smem);
+    u64* res = keys + p.keys_cap;
+    u64* tmp = res + ls_fin_res_cap(keff);
+    u64* red = tmp + 256;
+    u32* hist = reinterpret_cast<u32*>(red + 16);
+    u32* misc = hist + 8 * 256;
+
+    const int mc = p.blocks * p.kprime;
+    int nvalid = 0;
+    bool done = (p.n <= 0);
+    u64 T = 0;  // k-th best emitted key: a lower bound of the true k-th best key
+
+    if (!done && !p.force_slow && mc >= keff && mc <= p.keys_cap) {
+        u64 mb = 0;  // max over workgroups of the best key each one withheld
+        for (int i = tid; i < p.blocks; i += NT) {
+            const u64 b = p.bound[i];
+            mb = b > mb ? b : mb;
+        }
+        for (int i = tid; i < mc; i += NT) keys[i] = p.cand[i];
+        for (int o = 32; o >= 1; o >>= 1) {
+            const u64 other = __shfl_xor(mb, o, 64);
+            mb = other > mb ? other : mb;
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = mb;
+        __syncthreads();
+        mb = 0;
+        for (int w = 0; w < NT / 64; ++w) mb = red[w] > mb ? red[w] : mb;
+        nvalid = lds_topk(keys, mc, keff, res, tmp, hist, misc, tid, NT);
+        T = (nvalid == keff && keff > 0) ? res[keff - 1] : 0ull;
+        done = (mb == 0ull) || (T != 0ull && mb < T);
+        __syncthreads();
+    }
+    if (!done) {
+        if (tid == 0 && p.counters) atomicAdd(&p.counters[0], 1u);
+        bool rescued = false;
+        if (T != 0ull && !p.force_slow) {
+            // rescue: every row with key >= T is a candidate; the answer is among them
+            if (tid == 0) misc[5] = 0;
+            __syncthreads();
+            for (long long r = tid; r < p.n; r += NT) {
+                const u64 key = ls_make_key(p.S[r], (u32)r);
+                if (key >= T) {
+                    const u32 pos = atomicAdd(&misc[5], 1u);
+                    if (pos < (u32)p.keys_cap) keys[pos] = key;
+                }
+            }
+            __syncthreads();
+            const int c = (int)misc[5];
+            __syncthreads();
+            if (c <= p.keys_cap) {
+                nvalid = lds_topk(keys, c, keff, res, tmp, hist, misc, tid, NT);
+                rescued = true;
+            }
+        }
+        if (!rescued) {
+            if (tid == 0 && p.counters) atomicAdd(&p.counters[1], 1u);
+            nvalid = general_select(p.S, p.n, p.k, res, hist, misc, tid, NT);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < p.k; i += NT) {
+        const u64 key = (i < nvalid) ? res[i] : 0ull;
+        p.out_scores[i] = ls_key_score(key);
+        p.out_indices[i] = ls_key_index(key, p.base);
+    }
+}

@@ -172,11 +172,15 @@ class FlatIPIndex:
         return D, I
 
     def search_device(self, q, k: int, out_scores=None, out_indices=None, *,
-                      normalize: bool = False, asynchronous: bool = False, stream=None):
+                      normalize: bool = False, asynchronous: bool = False,
+                      pipeline: bool = False, stream=None):
         """Search with torch CUDA tensors (queries and results stay in HBM).
 
         q: float32 CUDA tensor [nq, d]. Work is queued on ``stream`` (default: torch's current
         stream). Returns (scores float32 [nq, k], indices int64 [nq, k]) CUDA tensors.
+        ``asynchronous``: queue and return, results ordered on the stream.
+        ``pipeline``: queue on the index's internal lanes so consecutive calls overlap; results
+        are valid only after :meth:`check`.
         """
         import torch
 
@@ -191,7 +195,8 @@ class FlatIPIndex:
         h = self._ensure_built()
         s = stream if stream is not None else torch.cuda.current_stream(q.device)
         flags = (native.LS_FLAG_NORMALIZE if normalize else 0) | \
-                (native.LS_FLAG_ASYNC if asynchronous else 0)
+                (native.LS_FLAG_ASYNC if asynchronous else 0) | \
+                (native.LS_FLAG_PIPELINE if pipeline else 0)
         native.check(native.load().ls_search_device(h, q.data_ptr(), nq, int(k), flags,
                                                     out_scores.data_ptr(), out_indices.data_ptr(),
                                                     s.cuda_stream))

@@ -277,3 +277,39 @@ def test_device_resident_api_and_merge():
                                    Io.data_ptr(), 0, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert np.array_equal(So.cpu().numpy(), Dref) and np.array_equal(Io.cpu().numpy(), Iref)
+
+
+def test_pipelined_calls_piggyback_finalize():
+    """LS_FLAG_PIPELINE: launch i carries the finalize of call i-1; results valid after check()."""
+    import torch
+
+    c = H.gauss(41, 30_000, 384)
+    qs = H.gauss(42, 24, 384)
+    dev = torch.device("cuda:0")
+    ix = FlatIPIndex.from_array(c)
+    tq = torch.from_numpy(qs).to(dev)
+    outs = []
+    ks = [10, 50, 50, 7, 300, 50] * 4
+    for i in range(24):
+        outs.append(ix.search_device(tq[i:i + 1], ks[i], pipeline=True))
+    ix.check()
+    for i in range(24):
+        Dr, Ir = oracle.c_search(c, qs[i:i + 1], ks[i])
+        _, _, S = oracle.np_search(c, qs[i:i + 1], ks[i])
+        oracle.compare_topk(outs[i][0].cpu().numpy(), outs[i][1].cpu().numpy(), Dr, Ir, S)
+    # switching streams mid-pipeline and mixing ordered calls must stay correct
+    s2 = torch.cuda.Stream()
+    a = ix.search_device(tq[0:1], 20, pipeline=True)
+    b = ix.search_device(tq[1:2], 20, pipeline=True, stream=s2)
+    cc = ix.search_device(tq[2:5], 20, asynchronous=True)          # ordered, 3 queries
+    d2, i2 = ix.search(qs[5:6], 20)                                 # host API
+    ix.check(s2)
+    torch.cuda.synchronize()
+    for (o, lo, hi) in ((a, 0, 1), (b, 1, 2), (cc, 2, 5)):
+        Dr, Ir = oracle.c_search(c, qs[lo:hi], 20)
+        _, _, S = oracle.np_search(c, qs[lo:hi], 20)
+        oracle.compare_topk(o[0].cpu().numpy(), o[1].cpu().numpy(), Dr, Ir, S)
+    Dr, Ir = oracle.c_search(c, qs[5:6], 20)
+    _, _, S = oracle.np_search(c, qs[5:6], 20)
+    oracle.compare_topk(d2, i2, Dr, Ir, S)
+    ix.close()

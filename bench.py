@@ -193,6 +193,14 @@ def main():
     barrier()
     scan_ms_avg, total_ms_avg = local.last_kernel_ms()
     local.set_profiling(False)
+    ev_ms = scan_ms_avg
+    roof_src = "mean of hipEvent pairs bracketing each launch (second pass of the same steps)"
+    if pipelined and nq == 1:
+        # one launch per step, back to back on one stream: the timed region's own hipEvents give
+        # the average launch duration (kernel boundary included) without per-launch event overhead
+        scan_ms_avg = dev_ms / args.steps
+        roof_src = ("timed region: hipEvent pair around the K back-to-back launches / K "
+                    "(kernel boundary included); event-bracketed mean in kernel_ms_bracketed")
     n_local = hi - lo
     if args.workload == "c3":
         flops = 2.0 * nq * n_local * d
@@ -206,7 +214,9 @@ def main():
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
     roof["kernel"] = "ls_scan_kernel"
     roof["kernel_ms"] = round(scan_ms_avg, 5)
-    roof["launches_timed"] = n_prof * (nq if nq <= 16 else 1)
+    roof["kernel_ms_source"] = roof_src
+    roof["kernel_ms_bracketed"] = round(ev_ms, 5)
+    roof["launches_timed"] = args.steps if (pipelined and nq == 1) else n_prof * (nq if nq <= 16 else 1)
     pmc = ROOT / "profiles" / f"pmc_{args.workload}.json"
     if pmc.exists():  # HBM bytes per launch from rocprofv3 --pmc (profiles/collect_pmc.sh)
         try:

@@ -112,6 +112,14 @@ int ls_merge_topk(const void* d_scores_in, const void* d_indices_in, int32_t n_l
                   int64_t nq, int32_t k, void* d_out_scores, void* d_out_indices,
                   int32_t device, void* stream);
 
+/* As ls_merge_topk for the packed exchange buffer of the sharded path: list l's scores start at
+ * (char*)d_scores_in + l*list_stride_bytes and its rows at (char*)d_indices_in +
+ * l*list_stride_bytes (one all-gather of a per-rank block [scores | rows] yields this layout).
+ * list_stride_bytes must be a multiple of 8. */
+int ls_merge_topk_strided(const void* d_scores_in, const void* d_indices_in,
+                          int64_t list_stride_bytes, int32_t n_lists, int64_t nq, int32_t k,
+                          void* d_out_scores, void* d_out_indices, int32_t device, void* stream);
+
 /* Kernel timing for bench.py. While profiling is on, every scan launch (up to 4096) is
  * bracketed by hipEvents on the stream it runs on. ls_last_kernel_ms returns the MEAN duration
  * of the scan kernel and of scan + selection over the launches recorded since profiling was

@@ -534,7 +534,25 @@ int ls_merge_topk(const void* d_scores_in, const void* d_indices_in, int32_t n_l
     int rc = check_device(device);
     if (rc != LS_OK) return rc;
     LS_HIP(hipSetDevice(device));
-    return ls_launch_merge((const float*)d_scores_in, (const int64_t*)d_indices_in, n_lists, nq, k,
+    return ls_launch_merge((const float*)d_scores_in, (const int64_t*)d_indices_in,
+                           nq * k * (int64_t)sizeof(float), nq * k * (int64_t)sizeof(int64_t),
+                           n_lists, nq, k, (float*)d_out_scores, (int64_t*)d_out_indices,
+                           (hipStream_t)stream);
+}
+
+int ls_merge_topk_strided(const void* d_scores_in, const void* d_indices_in,
+                          int64_t list_stride_bytes, int32_t n_lists, int64_t nq, int32_t k,
+                          void* d_out_scores, void* d_out_indices, int32_t device, void* stream) {
+    if (n_lists <= 0 || nq < 0 || k <= 0 || list_stride_bytes < 0 || (list_stride_bytes & 7) ||
+        (nq > 0 && (!d_scores_in || !d_indices_in || !d_out_scores || !d_out_indices))) {
+        ls_set_error("ls_merge_topk_strided: bad argument");
+        return LS_ERR_INVALID_ARG;
+    }
+    int rc = check_device(device);
+    if (rc != LS_OK) return rc;
+    LS_HIP(hipSetDevice(device));
+    return ls_launch_merge((const float*)d_scores_in, (const int64_t*)d_indices_in,
+                           list_stride_bytes, list_stride_bytes, n_lists, nq, k,
                            (float*)d_out_scores, (int64_t*)d_out_indices, (hipStream_t)stream);
 }
 

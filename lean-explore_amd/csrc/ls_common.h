@@ -108,6 +108,6 @@ int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const floa
 // NEXT query's scan launch as one extra workgroup (ls_launch_scan's `fin` argument).
 int ls_launch_finalize(const ls_fin_params& p, hipStream_t s);
 // merge of per-shard lists
-int ls_launch_merge(const float* d_scores_in, const int64_t* d_indices_in, int32_t n_lists,
-                    int64_t nq, int32_t k, float* d_out_scores, int64_t* d_out_indices,
-                    hipStream_t s);
+int ls_launch_merge(const float* d_scores_in, const int64_t* d_indices_in, int64_t stride_s_bytes,
+                    int64_t stride_i_bytes, int32_t n_lists, int64_t nq, int32_t k,
+                    float* d_out_scores, int64_t* d_out_indices, hipStream_t s);

@@ -27,8 +27,9 @@ int ls_launch_finalize(const ls_fin_params& p, hipStream_t s) {
 // Global rows must be < 2^32 - 1. Padded inputs (index -1) become key 0 and are ignored.
 #define LS_MERGE_THREADS 256
 __global__ __launch_bounds__(LS_MERGE_THREADS) void ls_merge_kernel(
-    const float* __restrict__ sc, const long long* __restrict__ ix, int n_lists, long long nq, int k,
-    float* __restrict__ out_scores, long long* __restrict__ out_indices) {
+    const float* __restrict__ sc, const long long* __restrict__ ix, long long stride_s,
+    long long stride_i, int n_lists, long long nq, int k, float* __restrict__ out_scores,
+    long long* __restrict__ out_indices) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int mc = n_lists * k;
     u64* keys = reinterpret_cast<u64*>(smem_raw);          // mc
@@ -40,9 +41,10 @@ __global__ __launch_bounds__(LS_MERGE_THREADS) void ls_merge_kernel(
     const int tid = threadIdx.x;
     for (int i = tid; i < mc; i += LS_MERGE_THREADS) {
         const int l = i / k, j = i - l * k;
-        const long long off = ((long long)l * nq + q) * k + j;
-        const long long row = ix[off];
-        keys[i] = row >= 0 ? ls_make_key(sc[off], (u32)row) : 0ull;
+        const long long off = q * k + j;  // within list l; lists are stride_* BYTES apart
+        const long long row = *(const long long*)((const char*)(ix + off) + l * stride_i);
+        const float v = *(const float*)((const char*)(sc + off) + l * stride_s);
+        keys[i] = row >= 0 ? ls_make_key(v, (u32)row) : 0ull;
     }
     __syncthreads();
     const int kk = k < LS_RES_CAP ? k : LS_RES_CAP;
@@ -55,9 +57,9 @@ __global__ __launch_bounds__(LS_MERGE_THREADS) void ls_merge_kernel(
     }
 }
 
-int ls_launch_merge(const float* d_scores_in, const int64_t* d_indices_in, int32_t n_lists,
-                    int64_t nq, int32_t k, float* d_out_scores, int64_t* d_out_indices,
-                    hipStream_t s) {
+int ls_launch_merge(const float* d_scores_in, const int64_t* d_indices_in, int64_t stride_s_bytes,
+                    int64_t stride_i_bytes, int32_t n_lists, int64_t nq, int32_t k,
+                    float* d_out_scores, int64_t* d_out_indices, hipStream_t s) {
     if (nq <= 0) return LS_OK;
     const long long mc = (long long)n_lists * k;
     if (mc > LS_FINAL_CAP || k > LS_RES_CAP) {
@@ -73,8 +75,9 @@ int ls_launch_merge(const float* d_scores_in, const int64_t* d_indices_in, int32
         attr_set = true;
     }
     hipLaunchKernelGGL(ls_merge_kernel, dim3((unsigned)nq), dim3(LS_MERGE_THREADS), smem, s,
-                       d_scores_in, (const long long*)d_indices_in, n_lists, (long long)nq, k,
-                       d_out_scores, (long long*)d_out_indices);
+                       d_scores_in, (const long long*)d_indices_in, (long long)stride_s_bytes,
+                       (long long)stride_i_bytes, n_lists, (long long)nq, k, d_out_scores,
+                       (long long*)d_out_indices);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }

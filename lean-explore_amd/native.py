@@ -51,6 +51,7 @@ SYMBOLS: dict[str, tuple] = {
     "ls_check": (ctypes.c_int, [_vp, _vp]),
     "ls_normalize_l2": (ctypes.c_int, [_vp, _i64, _i32, _i32]),
     "ls_merge_topk": (ctypes.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
+    "ls_merge_topk_strided": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
     "ls_set_profiling": (ctypes.c_int, [_vp, _i32]),
     "ls_last_kernel_ms": (ctypes.c_int, [_vp, _f32p, _f32p]),
     "ls_debug_option": (ctypes.c_int, [_vp, _i32, _i32]),

@@ -74,21 +74,28 @@ class ShardedFlatIPIndex:
         return self.local.d
 
     # ------------------------------------------------------------------ HIP defaults
-    def _hip_local_search(self, q, k, normalize):
-        return self.local.search_device(q, k, normalize=normalize, asynchronous=True)
+    def _hip_local_search(self, q, k, normalize, out_scores=None, out_indices=None):
+        return self.local.search_device(q, k, out_scores, out_indices, normalize=normalize,
+                                        asynchronous=True)
 
-    def _hip_merge(self, all_scores, all_rows, k):
+    def _hip_merge(self, all_scores, all_rows, k, list_stride_bytes=None):
         import torch
 
         from . import native
 
-        g, nq, _ = all_scores.shape
+        g, nq = all_scores.shape[0], all_scores.shape[1]
         out_s = torch.empty((nq, k), dtype=torch.float32, device=all_scores.device)
         out_i = torch.empty((nq, k), dtype=torch.int64, device=all_scores.device)
         dev = all_scores.device.index or 0
-        native.check(native.load().ls_merge_topk(
-            all_scores.data_ptr(), all_rows.data_ptr(), g, nq, k, out_s.data_ptr(),
-            out_i.data_ptr(), dev, torch.cuda.current_stream(all_scores.device).cuda_stream))
+        stream = torch.cuda.current_stream(all_scores.device).cuda_stream
+        lib = native.load()
+        if list_stride_bytes is None:
+            native.check(lib.ls_merge_topk(all_scores.data_ptr(), all_rows.data_ptr(), g, nq, k,
+                                           out_s.data_ptr(), out_i.data_ptr(), dev, stream))
+        else:
+            native.check(lib.ls_merge_topk_strided(all_scores.data_ptr(), all_rows.data_ptr(),
+                                                   list_stride_bytes, g, nq, k, out_s.data_ptr(),
+                                                   out_i.data_ptr(), dev, stream))
         return out_s, out_i
 
     # ------------------------------------------------------------------ search
@@ -98,15 +105,45 @@ class ShardedFlatIPIndex:
         import torch
         import torch.distributed as dist
 
-        s_loc, i_loc = self._local_search(q, k, normalize)
         if self.world == 1:
-            return s_loc, i_loc
+            return self._local_search(q, k, normalize)
         nq = q.shape[0]
-        all_s = torch.empty((self.world, nq, k), dtype=torch.float32, device=s_loc.device)
-        all_i = torch.empty((self.world, nq, k), dtype=torch.int64, device=i_loc.device)
-        dist.all_gather_into_tensor(all_s, s_loc.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(all_i, i_loc.contiguous(), group=self.group)
-        return self._merge(all_s, all_i, k)
+        # one packed block per rank: [scores f32 nq*k | pad to 8 B | rows i64 nq*k] -> ONE all-gather
+        sbytes = (nq * k * 4 + 7) & ~7
+        block = sbytes + nq * k * 8
+        packed = torch.empty(block, dtype=torch.uint8, device=q.device)
+        s_loc = packed[: nq * k * 4].view(torch.float32).view(nq, k)
+        i_loc = packed[sbytes:].view(torch.int64).view(nq, k)
+        if self._local_search == self._hip_local_search:
+            self._hip_local_search(q, k, normalize, s_loc, i_loc)
+        else:  # injected (CPU tests): copy its result into the packed block
+            s_tmp, i_tmp = self._local_search(q, k, normalize)
+            s_loc.copy_(s_tmp)
+            i_loc.copy_(i_tmp)
+        gathered = torch.empty(self.world * block, dtype=torch.uint8, device=q.device)
+        dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        all_s = gathered.view(self.world, block)[:, : nq * k * 4]
+        all_i = gathered.view(self.world, block)[:, sbytes:]
+        if self._merge == self._hip_merge:
+            # strided views are never materialised: the kernel walks the packed blocks
+            return self._merge_packed(gathered, sbytes, block, nq, k)
+        s_all = all_s.contiguous().view(torch.float32).view(self.world, nq, k)
+        i_all = all_i.contiguous().view(torch.int64).view(self.world, nq, k)
+        return self._merge(s_all, i_all, k)
+
+    def _merge_packed(self, gathered, sbytes, block, nq, k):
+        import torch
+
+        from . import native
+
+        out_s = torch.empty((nq, k), dtype=torch.float32, device=gathered.device)
+        out_i = torch.empty((nq, k), dtype=torch.int64, device=gathered.device)
+        dev = gathered.device.index or 0
+        native.check(native.load().ls_merge_topk_strided(
+            gathered.data_ptr(), gathered.data_ptr() + sbytes, block, self.world, nq, k,
+            out_s.data_ptr(), out_i.data_ptr(), dev,
+            torch.cuda.current_stream(gathered.device).cuda_stream))
+        return out_s, out_i
 
     def search(self, x: np.ndarray, k: int, *, normalize: bool = False
                ) -> tuple[np.ndarray, np.ndarray]:

@@ -277,6 +277,21 @@ def test_device_resident_api_and_merge():
                                    Io.data_ptr(), 0, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert np.array_equal(So.cpu().numpy(), Dref) and np.array_equal(Io.cpu().numpy(), Iref)
+    # the packed exchange layout of the sharded path: per rank [scores | pad | rows]
+    nq = 4
+    sbytes = (nq * k * 4 + 7) & ~7
+    block = sbytes + nq * k * 8
+    gathered = torch.zeros(3 * block, dtype=torch.uint8, device=dev)
+    for r in range(3):
+        gathered[r * block: r * block + nq * k * 4] = outs_s[r].contiguous().view(torch.uint8).view(-1)
+        gathered[r * block + sbytes: (r + 1) * block] = outs_i[r].contiguous().view(torch.uint8).view(-1)
+    So.zero_()
+    Io.zero_()
+    native.check(lib.ls_merge_topk_strided(gathered.data_ptr(), gathered.data_ptr() + sbytes, block,
+                                           3, nq, k, So.data_ptr(), Io.data_ptr(), 0,
+                                           torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert np.array_equal(So.cpu().numpy(), Dref) and np.array_equal(Io.cpu().numpy(), Iref)
 
 
 def test_pipelined_calls_piggyback_finalize():

@@ -50,6 +50,26 @@ struct ls_index {
     } sets[LS_NSETS];
     uint64_t set_rr = 0;
     int32_t last_set = 0;
+    // batched (MFMA) path scratch, allocated on first use
+    void* d_qh = nullptr;      size_t qh_cap = 0;       // bytes: fp16 queries [nq_pad, d_pad]
+    u64* d_queues = nullptr;   size_t queues_cap = 0;   // private candidate queues
+    u32* d_counts = nullptr;   size_t counts_cap = 0;
+    float* d_tau = nullptr;    size_t tau_cap = 0;
+    u32* d_overflow = nullptr; size_t overflow_cap = 0;
+    u32* h_overflow = nullptr; size_t h_overflow_cap = 0;  // pinned
+    struct batched_call {      // last batched call, kept so ls_check can repair flagged queries
+        bool active = false;
+        const float* d_q = nullptr;
+        int64_t nq = 0;
+        int32_t k = 0;
+        uint32_t flags = 0;
+        float* d_out_s = nullptr;
+        int64_t* d_out_i = nullptr;
+        hipStream_t stream = nullptr;
+    } bc;
+    uint64_t n_batched_fallback = 0;  // queries repaired by the scan path (host counter)
+    int32_t opt_gemm = 1;             // allow the batched MFMA path
+
     bool has_pending = false;          // a query whose finalize has not been launched yet
     ls_fin_params pending{};
     hipStream_t pending_stream = nullptr;
@@ -188,6 +208,12 @@ void ls_destroy(ls_index* ix) {
     (void)hipFree(ix->d_out_s);
     (void)hipFree(ix->d_out_i);
     (void)hipFree(ix->d_counters);
+    (void)hipFree(ix->d_qh);
+    (void)hipFree(ix->d_queues);
+    (void)hipFree(ix->d_counts);
+    (void)hipFree(ix->d_tau);
+    (void)hipFree(ix->d_overflow);
+    if (ix->h_overflow) (void)hipHostFree(ix->h_overflow);
     if (ix->h_q) (void)hipHostFree(ix->h_q);
     if (ix->h_out_s) (void)hipHostFree(ix->h_out_s);
     if (ix->h_out_i) (void)hipHostFree(ix->h_out_i);
@@ -321,7 +347,7 @@ static int flush_pending(ls_index* ix) {
 }
 
 // Queue one search on stream `s`. d_q: device fp32 [nq, d]; outputs device [nq, k].
-static int search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
+static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
                             float* d_out_s, int64_t* d_out_i, hipStream_t s) {
     const ls_geom& g = ix->g;
     int rc = LS_OK;
@@ -402,6 +428,121 @@ static int search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t 
     return LS_OK;
 }
 
+// ---- batched MFMA path (ls_gemm.hip) ---------------------------------------------------------------
+static bool batched_eligible(const ls_index* ix, int64_t nq, int32_t k) {
+    return ix->opt_gemm && ix->dtype == LS_DTYPE_F16 && nq > LS_SCAN_MAX_NQ &&
+           k <= LS_GEMM_MAX_K && ix->g.chunks <= LS_GEMM_MAX_CHUNKS && ix->n >= LS_GEMM_MIN_ROWS;
+}
+
+// Re-run the queries of the last batched call whose candidate queues overflowed (or were short)
+// through the exact per-query scan path. Synchronises the stream.
+static int batched_repair(ls_index* ix) {
+    ls_index::batched_call& bc = ix->bc;
+    if (!bc.active) return LS_OK;
+    bc.active = false;
+    const int64_t nq_pad = (bc.nq + 127) / 128 * 128;
+    LS_HIP(hipMemcpyAsync(ix->h_overflow, ix->d_overflow, sizeof(u32) * (size_t)nq_pad,
+                          hipMemcpyDeviceToHost, bc.stream));
+    LS_HIP(hipStreamSynchronize(bc.stream));
+    for (int64_t q = 0; q < bc.nq; ++q) {
+        if (!ix->h_overflow[q]) continue;
+        ix->n_batched_fallback++;
+        int rc = scan_search_on_stream(ix, bc.d_q + q * ix->g.d, 1, bc.k,
+                                       bc.flags & LS_FLAG_NORMALIZE, bc.d_out_s + q * bc.k,
+                                       bc.d_out_i + q * bc.k, bc.stream);
+        if (rc != LS_OK) return rc;
+    }
+    LS_HIP(hipStreamSynchronize(bc.stream));
+    return LS_OK;
+}
+
+static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k,
+                                    uint32_t flags, float* d_out_s, int64_t* d_out_i,
+                                    hipStream_t s) {
+    int rc = flush_pending(ix);
+    if (rc != LS_OK) return rc;
+    if (ix->bc.active) {  // an earlier async batched call has not been checked yet
+        rc = batched_repair(ix);
+        if (rc != LS_OK) return rc;
+    }
+    const ls_geom& g = ix->g;
+    const int64_t nq_pad = (nq + 127) / 128 * 128;
+    const int nqt = (int)(nq_pad / 128);
+    // corpus slices: about two workgroups per CU in total, a multiple of the 8 XCDs
+    int nsplits = (2 * ix->n_cu / nqt) / 8 * 8;
+    nsplits = std::max(8, std::min(nsplits, LS_GEMM_MAX_SPLITS));
+    int64_t rps = (ix->n + nsplits - 1) / nsplits;
+    rps = (rps + LS_GEMM_TM - 1) / LS_GEMM_TM * LS_GEMM_TM;
+    const int tiles_per_split = (int)(rps / LS_GEMM_TM);
+    const int sample_stride = std::max(1, (tiles_per_split + LS_GEMM_SAMPLE_TILES - 1) /
+                                              LS_GEMM_SAMPLE_TILES);
+    const int cap = LS_GEMM_QCAP;
+    const size_t nwg = (size_t)nsplits * nqt;
+
+    size_t c;
+    c = ix->qh_cap;
+    if ((rc = grow((unsigned char**)&ix->d_qh, &c, (size_t)nq_pad * g.d_pad * 2)) != LS_OK) return rc;
+    ix->qh_cap = c;
+    if ((rc = grow(&ix->d_queues, &ix->queues_cap, nwg * LS_GEMM_THREADS * cap)) != LS_OK) return rc;
+    if ((rc = grow(&ix->d_counts, &ix->counts_cap, nwg * LS_GEMM_THREADS)) != LS_OK) return rc;
+    if ((rc = grow(&ix->d_tau, &ix->tau_cap, (size_t)nq_pad)) != LS_OK) return rc;
+    if ((rc = grow(&ix->d_overflow, &ix->overflow_cap, (size_t)nq_pad)) != LS_OK) return rc;
+    if ((rc = grow_pinned(&ix->h_overflow, &ix->h_overflow_cap, (size_t)nq_pad)) != LS_OK) return rc;
+
+    const bool prof = ix->profiling && ix->prof_n < LS_PROF_MAX;
+    hipEvent_t* pe = nullptr;
+    if (prof) {
+        while (ix->prof_ev.size() < 2 * (ix->prof_n + 1)) {
+            hipEvent_t e;
+            LS_HIP(hipEventCreate(&e));
+            ix->prof_ev.push_back(e);
+        }
+        pe = &ix->prof_ev[2 * ix->prof_n];
+    }
+    LS_HIP(hipMemsetAsync(ix->d_overflow, 0, sizeof(u32) * (size_t)nq_pad, s));
+    rc = ls_launch_prep_f16(d_q, ix->d_qh, nq, nq_pad, g, (flags & LS_FLAG_NORMALIZE) != 0, s);
+    if (rc != LS_OK) return rc;
+    // sample pass: tau[q] = k-th best score over ~LS_GEMM_SAMPLE_TILES tiles of every slice
+    rc = ls_launch_gemm_filter(ix->d_corpus, ix->n, g, ix->d_qh, nq, nq_pad, nullptr, nsplits, rps,
+                               sample_stride, ix->d_queues, ix->d_counts, cap, ix->d_overflow, s);
+    if (rc != LS_OK) return rc;
+    rc = ls_launch_tau(ix->d_queues, ix->d_counts, cap, nsplits, nq, nq_pad, k, ix->d_tau, s);
+    if (rc != LS_OK) return rc;
+    LS_HIP(hipMemsetAsync(ix->d_overflow, 0, sizeof(u32) * (size_t)nq_pad, s));
+    // full pass
+    if (prof) LS_HIP(hipEventRecord(pe[0], s));
+    rc = ls_launch_gemm_filter(ix->d_corpus, ix->n, g, ix->d_qh, nq, nq_pad, ix->d_tau, nsplits,
+                               rps, 1, ix->d_queues, ix->d_counts, cap, ix->d_overflow, s);
+    if (rc != LS_OK) return rc;
+    if (prof) {
+        LS_HIP(hipEventRecord(pe[1], s));
+        ix->prof_n++;
+    }
+    rc = ls_launch_batch_select(ix->d_queues, ix->d_counts, cap, nsplits, nq, nq_pad, k, ix->base,
+                                ix->d_overflow, d_out_s, d_out_i, s);
+    if (rc != LS_OK) return rc;
+    ix->bc.active = true;
+    ix->bc.d_q = d_q;
+    ix->bc.nq = nq;
+    ix->bc.k = k;
+    ix->bc.flags = flags;
+    ix->bc.d_out_s = d_out_s;
+    ix->bc.d_out_i = d_out_i;
+    ix->bc.stream = s;
+    if (!(flags & (LS_FLAG_ASYNC | LS_FLAG_PIPELINE))) return batched_repair(ix);
+    return LS_OK;
+}
+
+static int search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
+                            float* d_out_s, int64_t* d_out_i, hipStream_t s, bool host_api) {
+    if (batched_eligible(ix, nq, k)) {
+        // the host API synchronises anyway: repair right away
+        uint32_t f = host_api ? (flags & ~(LS_FLAG_ASYNC | LS_FLAG_PIPELINE)) : flags;
+        return batched_search_on_stream(ix, d_q, nq, k, f, d_out_s, d_out_i, s);
+    }
+    return scan_search_on_stream(ix, d_q, nq, k, flags, d_out_s, d_out_i, s);
+}
+
 static int check_search_args(const ls_index* ix, const void* q, int64_t nq, int32_t k,
                              uint32_t flags, const void* os, const void* oi) {
     if (!ix) {
@@ -453,7 +594,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
     memcpy(ix->h_q, q, qn * sizeof(float));
     LS_HIP(hipMemcpyAsync(ix->d_qraw, ix->h_q, qn * sizeof(float), hipMemcpyHostToDevice, s));
     rc = search_on_stream(ix, ix->d_qraw, nq, k, flags & LS_FLAG_NORMALIZE, ix->d_out_s,
-                          ix->d_out_i, s);
+                          ix->d_out_i, s, true);
     if (rc != LS_OK) return rc;
     LS_HIP(hipMemcpyAsync(ix->h_out_s, ix->d_out_s, on * sizeof(float), hipMemcpyDeviceToHost, s));
     LS_HIP(hipMemcpyAsync(ix->h_out_i, ix->d_out_i, on * sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -472,7 +613,7 @@ int ls_search_device(ls_index* ix, const void* d_q, int64_t nq, int32_t k, uint3
     LS_HIP(hipSetDevice(ix->device));
     hipStream_t s = (hipStream_t)stream;
     rc = search_on_stream(ix, (const float*)d_q, nq, k, flags, (float*)d_out_scores,
-                          (int64_t*)d_out_indices, s);
+                          (int64_t*)d_out_indices, s, false);
     if (rc != LS_OK) return rc;
     if (!(flags & (LS_FLAG_ASYNC | LS_FLAG_PIPELINE))) LS_HIP(hipStreamSynchronize(s));
     return LS_OK;
@@ -487,8 +628,10 @@ int ls_check(ls_index* ix, void* stream) {
     LS_HIP(hipSetDevice(ix->device));
     int rc = flush_pending(ix);
     if (rc != LS_OK) return rc;
+    rc = batched_repair(ix);  // queries whose candidate queues overflowed: exact scan path
+    if (rc != LS_OK) return rc;
     LS_HIP(hipStreamSynchronize((hipStream_t)stream));
-    return LS_OK;  // the per-query scan path is exact by construction (finalize slow path)
+    return LS_OK;
 }
 
 int ls_normalize_l2(float* x, int64_t nq, int32_t d, int32_t device) {
@@ -595,6 +738,10 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->opt_kprime = value;
         return LS_OK;
     }
+    if (which == 4) {  // allow the batched MFMA path (default on)
+        ix->opt_gemm = value != 0;
+        return LS_OK;
+    }
     if (which == 3) {  // two-lane overlap of consecutive queries inside one call (default on)
         ix->opt_overlap = value != 0;
         return LS_OK;
@@ -622,8 +769,9 @@ int ls_debug_read_scores(ls_index* ix, float* out, int64_t count) {
 }
 
 int64_t ls_debug_counter(ls_index* ix, int32_t which) {
-    if (!ix || which < 0 || which >= 8) return -1;
+    if (!ix || which < 0 || which > 8) return -1;
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (which == 8) return (int64_t)ix->n_batched_fallback;
     if (hipSetDevice(ix->device) != hipSuccess) return -1;
     u32 v = 0;
     if (hipMemcpy(&v, ix->d_counters + which, sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess)

@@ -26,6 +26,14 @@ typedef unsigned int u32;
 #define LS_FINAL_THREADS 1024
 #define LS_FINAL_CAP 8192            // keys the finalize workgroup sorts in LDS (64 KiB)
 #define LS_SCAN_MAX_NQ 16            // nq <= this: per-query HBM-bound scan path
+#define LS_GEMM_THREADS 256          // batched path: 4 waves x 32 queries per workgroup
+#define LS_GEMM_TM 32                // corpus rows per LDS tile (one MFMA row block)
+#define LS_GEMM_MAX_K 128            // batched path handles k <= this (larger k: scan path)
+#define LS_GEMM_MAX_CHUNKS 64        // ... and stored rows <= 1 KiB (d <= 512 fp16)
+#define LS_GEMM_MIN_ROWS 32768       // ... and shards at least this big
+#define LS_GEMM_QCAP 64              // entries per private candidate queue
+#define LS_GEMM_SAMPLE_TILES 4       // sample pass: tiles per workgroup (<= QCAP/16)
+#define LS_GEMM_MAX_SPLITS 64        // corpus slices (tau kernel reads <= 8192 sample scores)
 
 __host__ __device__ __forceinline__ u32 ls_ord(float f) {
     f = f + 0.0f;  // folds -0.0 into +0.0
@@ -107,6 +115,18 @@ int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const floa
 // from S itself) -> out_scores[k], out_indices[k]. Either its own launch, or carried by the
 // NEXT query's scan launch as one extra workgroup (ls_launch_scan's `fin` argument).
 int ls_launch_finalize(const ls_fin_params& p, hipStream_t s);
+// batched MFMA path (ls_gemm.hip)
+int ls_launch_prep_f16(const float* d_q, void* d_qh, int64_t nq, int64_t nq_pad, const ls_geom& g,
+                       bool normalize, hipStream_t s);
+int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, const void* d_qh,
+                          int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
+                          int64_t rows_per_split, int tile_stride, u64* d_queues, u32* d_counts,
+                          int cap, u32* d_overflow, hipStream_t s);
+int ls_launch_tau(const u64* d_queues, const u32* d_counts, int cap, int nsplits, int64_t nq,
+                  int64_t nq_pad, int k, float* d_tau, hipStream_t s);
+int ls_launch_batch_select(const u64* d_queues, const u32* d_counts, int cap, int nsplits,
+                           int64_t nq, int64_t nq_pad, int k, int64_t base, u32* d_overflow,
+                           float* d_out_scores, int64_t* d_out_indices, hipStream_t s);
 // merge of per-shard lists
 int ls_launch_merge(const float* d_scores_in, const int64_t* d_indices_in, int64_t stride_s_bytes,
                     int64_t stride_i_bytes, int32_t n_lists, int64_t nq, int32_t k,

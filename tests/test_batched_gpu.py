@@ -1,0 +1,110 @@
+"""Parity of the batched MFMA path (fp16 index, nq > 16) against the CPU oracle. Needs an MI355X.
+
+fp16 semantics (include/leansearch.h, LS_DTYPE_F16): corpus and queries are rounded to fp16,
+products are exact, accumulation is fp32 -> the oracle runs on the same rounded operands."""
+
+import numpy as np
+import pytest
+
+from lean_explore_amd.index import FlatIPIndex
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def check_batched(c, q, k, normalize=False, base=0, ix=None):
+    own = ix is None
+    if own:
+        ix = FlatIPIndex.from_array(c, dtype="f16", base=base)
+    D, I = ix.search(q, k, normalize=normalize)
+    qn = oracle.c_normalize_l2(q) if normalize else q
+    Dr, Ir = oracle.c_search(c, qn, k, f16=True, base=base)
+    _, _, S = oracle.np_search(c, qn, k, f16=True)
+    # normalise-then-round-to-fp16 is discontinuous: a 1-ulp difference in the fp32 normalised
+    # query can flip an fp16 rounding (2^-11 relative on that element), moving a score by ~1e-6.
+    # With the fused normalise flag, near-ties are therefore excused up to the score tolerance.
+    rep = oracle.compare_topk(D, I, Dr, Ir, S, score_tol=1e-5, base=base,
+                              tie_eps=1e-5 if normalize else 2e-6)
+    assert rep["recall"] == 1.0, rep
+    if own:
+        ix.close()
+    return rep
+
+
+def test_batched_matches_scan_path_and_oracle():
+    c = H.gauss(1234, 60_000, 384)
+    q = H.gauss(5678, 200, 384)
+    ix = FlatIPIndex.from_array(c, dtype="f16")
+    rep = check_batched(c, q, 100, ix=ix)
+    Db, Ib = ix.search(q, 100)
+    ix.debug_option(4, 0)  # same index through the per-query scan path
+    Ds, Is = ix.search(q, 100)
+    # the two paths sum in different orders: identical up to near-ties (see compare_topk)
+    _, _, S = oracle.np_search(c, q, 100, f16=True)
+    rep2 = oracle.compare_topk(Db, Ib, Ds, Is, S, score_tol=2e-6)
+    assert rep2["index_mismatches"] <= 4, rep2
+    print("batched", rep, "fallbacks", ix.debug_counter(8))
+    ix.close()
+
+
+def test_config3_full_size():
+    """BASELINE config 3: N=200k, d=384 fp16, nq=1024, k=100."""
+    c = H.gauss(1234, 200_000, 384)
+    q = H.gauss(5678, 1024, 384)
+    ix = FlatIPIndex.from_array(c, dtype="f16")
+    rep = check_batched(c, q, 100, ix=ix)
+    assert ix.debug_counter(8) == 0, "random data must not need the fallback"
+    print("config3", rep)
+    ix.close()
+
+
+def test_batched_integer_corpus_bit_exact():
+    c = H.int_corpus(7, 100_000, 384)
+    q = H.int_corpus(8, 160, 384)
+    ix = FlatIPIndex.from_array(c, dtype="f16")
+    D, I = ix.search(q, 64)
+    Dr, Ir = oracle.c_search(c, q, 64, f16=True)
+    assert np.array_equal(D, Dr) and np.array_equal(I, Ir)
+    print("int corpus fallbacks (ties overflow the queues):", ix.debug_counter(8))
+    ix.close()
+
+
+@pytest.mark.parametrize("nq,k,d", [(17, 1, 384), (130, 50, 256), (300, 128, 512), (129, 10, 100)])
+def test_batched_shapes(nq, k, d):
+    c = H.gauss(11, 40_000, d)
+    q = H.gauss(12, nq, d)
+    check_batched(c, q, k, normalize=True, base=5_000_000)
+    check_batched(c, oracle.c_normalize_l2(q), k, normalize=False)
+
+
+def test_batched_cluster_overflows_queues_and_is_repaired():
+    """300 near-duplicates of query 0 hidden between sampled tiles: tau is too low for them, the
+    private queues overflow, the query is repaired by the exact scan path."""
+    c = H.gauss(21, 200_000, 384)
+    q = H.gauss(22, 64, 384)
+    rng = np.random.default_rng(5)
+    lo = 3125 * 7 + 40 * 32  # inside slice 7, between its sampled tiles (0, 25, 50, 75)
+    for r in range(lo, lo + 300):
+        v = q[0] + 0.05 * rng.standard_normal(384).astype(np.float32)
+        c[r] = v / np.linalg.norm(v)
+    ix = FlatIPIndex.from_array(c, dtype="f16")
+    rep = check_batched(c, q, 100, ix=ix)
+    assert ix.debug_counter(8) >= 1
+    print("cluster", rep, "fallbacks", ix.debug_counter(8))
+    ix.close()
+
+
+def test_batched_device_api_async_check():
+    import torch
+
+    c = H.gauss(31, 80_000, 384)
+    q = H.gauss(32, 256, 384)
+    ix = FlatIPIndex.from_array(c, dtype="f16")
+    tq = torch.from_numpy(q).cuda()
+    s, i = ix.search_device(tq, 100, asynchronous=True)
+    ix.check()
+    Dr, Ir = oracle.c_search(c, q, 100, f16=True)
+    _, _, S = oracle.np_search(c, q, 100, f16=True)
+    oracle.compare_topk(s.cpu().numpy(), i.cpu().numpy(), Dr, Ir, S)
+    ix.close()

@@ -69,6 +69,7 @@ struct ls_index {
     } bc;
     uint64_t n_batched_fallback = 0;  // queries repaired by the scan path (host counter)
     int32_t opt_gemm = 1;             // allow the batched MFMA path
+    int32_t opt_spec_tau = 1;         // speculative (verified) sample threshold
 
     bool has_pending = false;          // a query whose finalize has not been launched yet
     ls_fin_params pending{};
@@ -440,7 +441,7 @@ static int batched_repair(ls_index* ix) {
     ls_index::batched_call& bc = ix->bc;
     if (!bc.active) return LS_OK;
     bc.active = false;
-    const int64_t nq_pad = (bc.nq + 127) / 128 * 128;
+    const int64_t nq_pad = (bc.nq + LS_GEMM_QT - 1) / LS_GEMM_QT * LS_GEMM_QT;
     LS_HIP(hipMemcpyAsync(ix->h_overflow, ix->d_overflow, sizeof(u32) * (size_t)nq_pad,
                           hipMemcpyDeviceToHost, bc.stream));
     LS_HIP(hipStreamSynchronize(bc.stream));
@@ -466,10 +467,10 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         if (rc != LS_OK) return rc;
     }
     const ls_geom& g = ix->g;
-    const int64_t nq_pad = (nq + 127) / 128 * 128;
-    const int nqt = (int)(nq_pad / 128);
-    // corpus slices: about two workgroups per CU in total, a multiple of the 8 XCDs
-    int nsplits = (2 * ix->n_cu / nqt) / 8 * 8;
+    const int64_t nq_pad = (nq + LS_GEMM_QT - 1) / LS_GEMM_QT * LS_GEMM_QT;
+    const int nqt = (int)(nq_pad / LS_GEMM_QT);
+    // corpus slices: one 8-wave workgroup per CU in total, a multiple of the 8 XCDs
+    int nsplits = (ix->n_cu / nqt) / 8 * 8;
     nsplits = std::max(8, std::min(nsplits, LS_GEMM_MAX_SPLITS));
     int64_t rps = (ix->n + nsplits - 1) / nsplits;
     rps = (rps + LS_GEMM_TM - 1) / LS_GEMM_TM * LS_GEMM_TM;
@@ -506,7 +507,28 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     rc = ls_launch_gemm_filter(ix->d_corpus, ix->n, g, ix->d_qh, nq, nq_pad, nullptr, nsplits, rps,
                                sample_stride, ix->d_queues, ix->d_counts, cap, ix->d_overflow, s);
     if (rc != LS_OK) return rc;
-    rc = ls_launch_tau(ix->d_queues, ix->d_counts, cap, nsplits, nq, nq_pad, k, ix->d_tau, s);
+    // Speculative threshold. The k-th best SAMPLE score is a certified lower bound of the final
+    // k-th best but passes ~k*N/M0 rows per query. The j-th best sample score (j < k) passes only
+    // ~j*N/M0 rows; it is not certified, so the select kernel verifies that at least k rows
+    // passed and flags the query for the exact scan path otherwise. j is the smallest rank whose
+    // expected pass count exceeds k by 4.5 standard deviations (relative sd of an order
+    // statistic ~ 1/sqrt(j)): a flag is a ~1e-5 event per query on exchangeable rows.
+    int jrank = k;
+    if (ix->opt_spec_tau) {
+        const int visited = (tiles_per_split + sample_stride - 1) / sample_stride;
+        const double m0 = (double)nsplits * visited * LS_GEMM_TM;
+        const double r = (double)ix->n / std::max(1.0, m0);
+        for (int j = 1; j <= k; ++j) {
+            if ((double)j * r * (1.0 - 4.5 / __builtin_sqrt((double)j)) >= (double)k) {
+                jrank = j;
+                break;
+            }
+        }
+    }
+    static const bool abl_nopass = getenv("LS_GEMM_ABL_NOPASS") != nullptr;  // timing ablation only
+    rc = ls_launch_tau(ix->d_queues, ix->d_counts, cap, nsplits, nq, nq_pad, jrank, ix->d_tau, s);
+    if (abl_nopass)  // every tau = FLT_MAX: the epilogue never appends (results are garbage)
+        LS_HIP(hipMemsetD32Async((hipDeviceptr_t)ix->d_tau, 0x7f7fffff, (size_t)nq_pad, s));
     if (rc != LS_OK) return rc;
     LS_HIP(hipMemsetAsync(ix->d_overflow, 0, sizeof(u32) * (size_t)nq_pad, s));
     // full pass
@@ -518,6 +540,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         LS_HIP(hipEventRecord(pe[1], s));
         ix->prof_n++;
     }
+    if (abl_nopass) return LS_OK;
     rc = ls_launch_batch_select(ix->d_queues, ix->d_counts, cap, nsplits, nq, nq_pad, k, ix->base,
                                 ix->d_overflow, d_out_s, d_out_i, s);
     if (rc != LS_OK) return rc;
@@ -736,6 +759,10 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
     std::lock_guard<std::mutex> lk(ix->mu);
     if (which == 0) {  // force k' (0 = automatic)
         ix->opt_kprime = value;
+        return LS_OK;
+    }
+    if (which == 5) {  // speculative sample threshold on the batched path (default on)
+        ix->opt_spec_tau = value != 0;
         return LS_OK;
     }
     if (which == 4) {  // allow the batched MFMA path (default on)

@@ -26,8 +26,10 @@ typedef unsigned int u32;
 #define LS_FINAL_THREADS 1024
 #define LS_FINAL_CAP 8192            // keys the finalize workgroup sorts in LDS (64 KiB)
 #define LS_SCAN_MAX_NQ 16            // nq <= this: per-query HBM-bound scan path
-#define LS_GEMM_THREADS 256          // batched path: 4 waves x 32 queries per workgroup
+#define LS_GEMM_THREADS 512          // batched path: 8 waves x 32 queries per workgroup
+#define LS_GEMM_QT 256               // queries per workgroup
 #define LS_GEMM_TM 32                // corpus rows per LDS tile (one MFMA row block)
+#define LS_GEMM_APF 6                 // A fragments in flight ahead of the MFMA
 #define LS_GEMM_MAX_K 128            // batched path handles k <= this (larger k: scan path)
 #define LS_GEMM_MAX_CHUNKS 64        // ... and stored rows <= 1 KiB (d <= 512 fp16)
 #define LS_GEMM_MIN_ROWS 32768       // ... and shards at least this big

@@ -6,12 +6,13 @@
 // Why fused: the score matrix is nq*N fp32 = 819 MB for config 3; writing and re-reading it
 // would cost more HBM time than the whole MFMA budget, so scores never leave registers.
 //
-// ls_gemm_filter_kernel — one workgroup = 4 waves = 128 queries x one corpus slice
+// ls_gemm_filter_kernel — one workgroup = 8 waves = 256 queries x one corpus slice
 //   - B operand (queries): each wave keeps its 32 queries' fp16 fragments in VGPRs for the
 //     whole slice (KSTEPS x 4 registers), so B costs no LDS or HBM traffic in the loop.
-//   - A operand (corpus): tiles of 32 rows stream HBM -> LDS with global_load_lds (16 B/lane,
-//     double buffered) and are shared by the 4 waves. LDS rows are XOR-swizzled on the SOURCE
-//     address (chunk ^ (row & 15)) so the ds_read_b128 fragment reads are bank-conflict free.
+//   - A operand (corpus): tiles of 32 rows stream HBM/L2 -> registers -> LDS, two tiles in
+//     flight in registers while a third is consumed from LDS (a 1-tile look-ahead measured
+//     latency-bound), and are shared by the 8 waves. LDS rows are XOR-swizzled
+//     (chunk ^ (row & 15)) so the ds_read_b128 fragment reads are bank-conflict free.
 //   - v_mfma_f32_32x32x16_f16: D[row, query] accumulates in fp32; fp16 x fp16 products are exact.
 //   - epilogue: lane (query j, half h) holds 16 row scores of ONE query. A score >= tau[j]
 //     (tau = k-th best of a row sample, a certified lower bound of the final k-th best) is
@@ -76,14 +77,14 @@ __host__ __device__ __forceinline__ int wg_index(int split, int qt, int nqt) {
     return (((split >> 3) * nqt + qt) << 3) | (split & 7);
 }
 
-template <int CHUNKS>
+template <int CHUNKS, bool SAMPLE>
 __global__ __launch_bounds__(LS_GEMM_THREADS, 2) void ls_gemm_filter_kernel(
     const u32x4* __restrict__ corpus, long long n, const u32x4* __restrict__ qh, int nq, int nqt,
     const float* __restrict__ tau, long long rows_per_split, int tile_stride,
     u64* __restrict__ queues, u32* __restrict__ counts, int cap, u32* __restrict__ overflow) {
-    constexpr int KSTEPS = CHUNKS / 2;            // 16 fp16 per MFMA k-step = 2 chunks
-    constexpr int TILE_CHUNKS = LS_GEMM_TM * CHUNKS;  // 16-byte chunks per LDS tile
-    constexpr int LOADS = TILE_CHUNKS / LS_GEMM_THREADS;  // global_load_lds per thread per tile
+    constexpr int KSTEPS = CHUNKS / 2;                    // 16 fp16 per MFMA k-step = 2 chunks
+    constexpr int TILE_CHUNKS = LS_GEMM_TM * CHUNKS;      // 16-byte chunks per LDS tile
+    constexpr int LOADS = TILE_CHUNKS / LS_GEMM_THREADS;  // 16-byte loads per thread per tile
     static_assert(TILE_CHUNKS % LS_GEMM_THREADS == 0, "tile must split evenly over the threads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 tiles
 
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, 2) void ls_gemm_filter_kernel(
     const int ntiles_all = r_begin < r_end ? (int)((r_end - r_begin + LS_GEMM_TM - 1) / LS_GEMM_TM) : 0;
     const int nt = (ntiles_all + tile_stride - 1) / tile_stride;  // tiles this launch visits
 
-    // B fragments: query j = qt*128 + wave*32 + (lane & 31); k-step kk -> chunk 2kk + (lane >> 5)
-    const int qj = qt * 128 + wave * 32 + (lane & 31);
+    // B fragments: query j = qt*QT + wave*32 + (lane & 31); k-step kk -> chunk 2kk + (lane >> 5)
+    const int qj = qt * LS_GEMM_QT + wave * 32 + (lane & 31);
     half8 bq[KSTEPS];
     {
         const u32x4* qrow = qh + (long long)qj * CHUNKS + (lane >> 5);
@@ -110,60 +111,113 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, 2) void ls_gemm_filter_kernel(
     const bool qvalid = qj < nq;
     const float tauv = tau ? tau[qj] : -FLT_MAX;
 
-    // private queue of this lane: entry e at queues[(b*256 + tid)*cap + e] (contiguous per lane,
-    // so the select kernels read a queue as one coalesced run)
+    // private queue of this lane: entry e at queues[(b*THREADS + tid)*cap + e] (contiguous per
+    // lane, so the select kernels read a queue as one coalesced run)
     u64* myq = queues + ((long long)blockIdx.x * LS_GEMM_THREADS + tid) * cap;
     int cnt = 0;
 
-    // stage tile `ti` (index into this split's tiles) into LDS buffer `buf`
-    auto stage = [&](int ti, int buf) {
+    // Corpus tiles travel HBM/L2 -> registers -> LDS. Two tiles are in flight in registers
+    // (ra, rb) while a third is being consumed from LDS: the loads are ordinary global loads, so
+    // hipcc counts them (vmcnt(N), not 0) next to the epilogue's queue stores.
+    // Thread t fills LDS chunks Lc = j*THREADS + t of the tile: row r = Lc / CHUNKS, slot
+    // sl = Lc % CHUNKS holds source chunk sl ^ (r & 15) (XOR swizzle: conflict-free ds_read_b128).
+    auto load_tile = [&](int ti, u32x4 (&rg)[LOADS]) {
         const long long row0 = r_begin + (long long)ti * LS_GEMM_TM;
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) {
-            const int Lc = (wave * LOADS + j) * 64 + lane;  // LDS chunk this lane fills
+            const int Lc = j * LS_GEMM_THREADS + tid;
             const int r = Lc / CHUNKS, sl = Lc % CHUNKS;
-            const int c = sl ^ (r & 15);                    // source chunk (swizzle on the source)
             long long row = row0 + r;
             row = row < n ? row : n - 1;
-            const u32x4* src = corpus + row * CHUNKS + c;
-            unsigned char* dst = smem + (size_t)buf * TILE_CHUNKS * 16 + (size_t)(wave * LOADS + j) * 1024;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+            rg[j] = corpus[row * CHUNKS + (sl ^ (r & 15))];
         }
     };
-
-    if (nt > 0) stage(0, 0);
-    __syncthreads();  // (the compiler drains the LDS-DMA before the barrier)
+    auto write_tile = [&](int buf, const u32x4 (&rg)[LOADS]) {
+        unsigned char* base = smem + (size_t)buf * TILE_CHUNKS * 16;
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j)
+            *reinterpret_cast<u32x4*>(base + (size_t)(j * LS_GEMM_THREADS + tid) * 16) = rg[j];
+    };
 
     const int ar = lane & 31;  // A fragment: row ar of the tile, chunk 2kk + (lane >> 5)
-    for (int i = 0; i < nt; ++i) {
-        const int buf = i & 1;
-        if (i + 1 < nt) stage((i + 1) * tile_stride, buf ^ 1);
+    auto compute_tile = [&](int i, int buf) {
         const unsigned char* tb = smem + (size_t)buf * TILE_CHUNKS * 16 + (size_t)ar * CHUNKS * 16;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        // A fragments run LS_GEMM_APF k-steps ahead of the MFMA that consumes them
+        u32x4 af[LS_GEMM_APF];
+#pragma unroll
+        for (int kk = 0; kk < LS_GEMM_APF && kk < KSTEPS; ++kk)
+            af[kk] = *reinterpret_cast<const u32x4*>(tb + (((2 * kk + (lane >> 5)) ^ (ar & 15)) * 16));
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
-            const int c = (2 * kk + (lane >> 5)) ^ (ar & 15);
-            const u32x4 av = *reinterpret_cast<const u32x4*>(tb + c * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, av), bq[kk], acc,
-                                                         0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                __builtin_bit_cast(half8, af[kk % LS_GEMM_APF]), bq[kk], acc, 0, 0, 0);
+            if (kk + LS_GEMM_APF < KSTEPS)
+                af[kk % LS_GEMM_APF] = *reinterpret_cast<const u32x4*>(
+                    tb + (((2 * (kk + LS_GEMM_APF) + (lane >> 5)) ^ (ar & 15)) * 16));
+        }
+        // pin the schedule hipcc would otherwise collapse to read->wait->mfma:
+        // APF LDS reads up front, then one MFMA per LDS read (masks: 0x100 DS read, 0x008 MFMA)
+        __builtin_amdgcn_sched_group_barrier(0x100, LS_GEMM_APF, 0);
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (kk + LS_GEMM_APF < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         // epilogue: acc[r] = <corpus row, query qj>, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
         const long long row0 = r_begin + (long long)(i * tile_stride) * LS_GEMM_TM + 4 * (lane >> 5);
+        if (SAMPLE) {
+            // sample pass: every score is kept (0 = no entry): 16 keys = one 128-byte line per
+            // lane and tile, written as 8 x 16-byte stores
+            u64 kk2[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float s = acc[r];
-            if (s >= tauv) {
+            for (int r = 0; r < 16; ++r) {
                 const long long row = row0 + (r & 3) + 8 * (r >> 2);
-                const u64 key = ls_make_key(s, (u32)row);
-                if (qvalid && row < r_end && key != 0ull) {
-                    if (cnt < cap) myq[cnt] = key;
-                    ++cnt;
+                kk2[r] = (qvalid && row < r_end) ? ls_make_key(acc[r], (u32)row) : 0ull;
+            }
+            if (cnt + 16 <= cap) {
+                ulonglong2* dst = reinterpret_cast<ulonglong2*>(myq + cnt);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) dst[r] = make_ulonglong2(kk2[2 * r], kk2[2 * r + 1]);
+            }
+            cnt += 16;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float s = acc[r];
+                if (s >= tauv) {
+                    const long long row = row0 + (r & 3) + 8 * (r >> 2);
+                    const u64 key = ls_make_key(s, (u32)row);
+                    if (qvalid && row < r_end && key != 0ull) {
+                        if (cnt < cap) myq[cnt] = key;
+                        ++cnt;
+                    }
                 }
             }
         }
-        __syncthreads();  // next tile landed (DMA drained before the barrier) / this one consumed
+    };
+
+    u32x4 ra[LOADS], rb[LOADS];
+    if (nt > 0) load_tile(0, ra);
+    if (nt > 1) load_tile(tile_stride, rb);
+    if (nt > 0) write_tile(0, ra);
+    if (nt > 2) load_tile(2 * tile_stride, ra);
+    __syncthreads();
+    // invariant at the top of iteration i: LDS[i&1] = tile i; tile i+1 in flight in rb (i even)
+    // or ra (i odd); tile i+2 in flight in the other set
+    for (int i = 0; i < nt; i += 2) {
+        compute_tile(i, 0);
+        if (i + 1 < nt) write_tile(1, rb);
+        if (i + 3 < nt) load_tile((i + 3) * tile_stride, rb);
+        __syncthreads();
+        if (i + 1 < nt) {
+            compute_tile(i + 1, 1);
+            if (i + 2 < nt) write_tile(0, ra);
+            if (i + 4 < nt) load_tile((i + 4) * tile_stride, ra);
+            __syncthreads();
+        }
     }
     counts[(long long)blockIdx.x * LS_GEMM_THREADS + tid] = (u32)(cnt < cap ? cnt : cap);
     if (cnt > cap) overflow[qj] = 1u;
@@ -173,15 +227,21 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
                           int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
                           int64_t rows_per_split, int tile_stride, u64* d_queues, u32* d_counts,
                           int cap, u32* d_overflow, hipStream_t s) {
-    const int nqt = (int)(nq_pad / 128);
+    const int nqt = (int)(nq_pad / LS_GEMM_QT);
     const dim3 grid((unsigned)(nsplits * nqt)), block(LS_GEMM_THREADS);
     const size_t smem = (size_t)2 * LS_GEMM_TM * g.chunks * 16;
 #define LS_GEMM_CASE(C)                                                                          \
     if (g.chunks == C) {                                                                         \
-        hipLaunchKernelGGL((ls_gemm_filter_kernel<C>), grid, block, smem, s,                      \
-                           (const u32x4*)d_corpus, (long long)n, (const u32x4*)d_qh, (int)nq, nqt, \
-                           d_tau, (long long)rows_per_split, tile_stride, d_queues, d_counts, cap, \
-                           d_overflow);                                                          \
+        if (d_tau)                                                                               \
+            hipLaunchKernelGGL((ls_gemm_filter_kernel<C, false>), grid, block, smem, s,           \
+                               (const u32x4*)d_corpus, (long long)n, (const u32x4*)d_qh, (int)nq,  \
+                               nqt, d_tau, (long long)rows_per_split, tile_stride, d_queues,      \
+                               d_counts, cap, d_overflow);                                       \
+        else                                                                                     \
+            hipLaunchKernelGGL((ls_gemm_filter_kernel<C, true>), grid, block, smem, s,            \
+                               (const u32x4*)d_corpus, (long long)n, (const u32x4*)d_qh, (int)nq,  \
+                               nqt, d_tau, (long long)rows_per_split, tile_stride, d_queues,      \
+                               d_counts, cap, d_overflow);                                       \
         LS_HIP(hipGetLastError());                                                               \
         return LS_OK;                                                                            \
     }
@@ -206,22 +266,26 @@ __global__ __launch_bounds__(256) void ls_tau_kernel(const u64* __restrict__ que
         if (tid == 0) tau[q] = FLT_MAX;  // padded query: nothing passes
         return;
     }
-    const int qt = q / 128, w = (q % 128) / 32, l = q % 32;
+    const int qt = q / LS_GEMM_QT, w = (q % LS_GEMM_QT) / 32, l = q % 32;
     // entry list of this query: (split, half, e) -> flattened index space nsplits * 2 * cap
     const int total = nsplits * 2 * cap;
+    // all loads are independent and issued together: first the queue lengths, then the entries
+    u32 qc[LS_TAU_PER_THREAD];
+    u64 ent[LS_TAU_PER_THREAD];
     u32 hi[LS_TAU_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < LS_TAU_PER_THREAD; ++j) {
         const int idx = tid + j * 256;
-        u32 v = 0;
-        if (idx < total) {
-            const int e = idx % cap, sh = idx / cap, half = sh & 1, split = sh >> 1;
-            const int b = wg_index(split, qt, nqt);
-            const int t = w * 64 + half * 32 + l;
-            if ((u32)e < counts[(long long)b * LS_GEMM_THREADS + t])
-                v = (u32)(queues[((long long)b * LS_GEMM_THREADS + t) * cap + e] >> 32);
-        }
-        hi[j] = v;  // 0 = no entry (ord() of a valid score is never 0: that is -NaN territory)
+        const int sh = (idx < total ? idx : 0) / cap, half = sh & 1, split = sh >> 1;
+        const int b = wg_index(split, qt, nqt);
+        const int t = w * 64 + half * 32 + l;
+        qc[j] = counts[(long long)b * LS_GEMM_THREADS + t];
+        ent[j] = queues[((long long)b * LS_GEMM_THREADS + t) * cap + (idx < total ? idx % cap : 0)];
+    }
+#pragma unroll
+    for (int j = 0; j < LS_TAU_PER_THREAD; ++j) {
+        const int idx = tid + j * 256;
+        hi[j] = (idx < total && (u32)(idx % cap) < qc[j]) ? (u32)(ent[j] >> 32) : 0u;
     }
     for (int i = tid; i < 4 * 256; i += 256) hist[i] = 0;
     __syncthreads();
@@ -253,7 +317,7 @@ int ls_launch_tau(const u64* d_queues, const u32* d_counts, int cap, int nsplits
         return LS_ERR_INVALID_ARG;
     }
     hipLaunchKernelGGL(ls_tau_kernel, dim3((unsigned)nq_pad), dim3(256), 0, s, d_queues, d_counts,
-                       cap, nsplits, (int)(nq_pad / 128), (int)nq, k, d_tau);
+                       cap, nsplits, (int)(nq_pad / LS_GEMM_QT), (int)nq, k, d_tau);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
@@ -271,19 +335,33 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
     __shared__ u32 misc[64];
     __shared__ u32 nkeys;
     const int q = blockIdx.x, tid = threadIdx.x;
-    const int qt = q / 128, w = (q % 128) / 32, l = q % 32;
+    const int qt = q / LS_GEMM_QT, w = (q % LS_GEMM_QT) / 32, l = q % 32;
     if (tid == 0) nkeys = 0;
     __syncthreads();
     // walk the query's 2*nsplits queues in the flattened (queue, entry) index space: a wave
-    // reads one queue's 64 slots as one coalesced run and appends the live ones to LDS
+    // reads one queue's slots as one coalesced run. Loads are unconditional and issued in
+    // batches of 8 so that the gather costs a few memory latencies, not one per queue.
     const int total = nsplits * 2 * cap;
-    for (int idx = tid; idx < total; idx += 256) {
-        const int e = idx % cap, sh = idx / cap, half = sh & 1, split = sh >> 1;
-        const int b = wg_index(split, qt, nqt);
-        const int t = w * 64 + half * 32 + l;
-        if ((u32)e < counts[(long long)b * LS_GEMM_THREADS + t]) {
-            const u32 pos = atomicAdd(&nkeys, 1u);
-            if (pos < LS_BSEL_KEYS) keys[pos] = queues[((long long)b * LS_GEMM_THREADS + t) * cap + e];
+    for (int i0 = 0; i0 < total; i0 += 256 * 8) {
+        u32 qc[8];
+        u64 ent[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = i0 + j * 256 + tid;
+            const int ii = idx < total ? idx : 0;
+            const int e = ii % cap, sh = ii / cap, half = sh & 1, split = sh >> 1;
+            const int b = wg_index(split, qt, nqt);
+            const int t = w * 64 + half * 32 + l;
+            qc[j] = counts[(long long)b * LS_GEMM_THREADS + t];
+            ent[j] = queues[((long long)b * LS_GEMM_THREADS + t) * cap + e];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = i0 + j * 256 + tid;
+            if (idx < total && (u32)(idx % cap) < qc[j]) {
+                const u32 pos = atomicAdd(&nkeys, 1u);
+                if (pos < LS_BSEL_KEYS) keys[pos] = ent[j];
+            }
         }
     }
     __syncthreads();
@@ -313,7 +391,7 @@ int ls_launch_batch_select(const u64* d_queues, const u32* d_counts, int cap, in
         return LS_ERR_INVALID_ARG;
     }
     hipLaunchKernelGGL(ls_batch_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, d_queues,
-                       d_counts, cap, nsplits, (int)(nq_pad / 128), k, (long long)base, d_overflow,
+                       d_counts, cap, nsplits, (int)(nq_pad / LS_GEMM_QT), k, (long long)base, d_overflow,
                        d_out_scores, (long long*)d_out_indices);
     LS_HIP(hipGetLastError());
     return LS_OK;

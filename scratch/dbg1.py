@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.')
+import sys; sys.path.insert(0,'/root/repo')
 import numpy as np
 from lean_explore_amd.index import FlatIPIndex
 from tests import helpers as H

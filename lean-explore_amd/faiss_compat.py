@@ -1,0 +1,168 @@
+"""The slice of the `faiss` module surface that LeanExplore's local backend uses
+(reference src/lean_explore/search/engine.py:156-159,240-250), served by the HIP library:
+
+    import lean_explore_amd.faiss_compat as faiss
+    index = faiss.read_index(path); faiss.normalize_L2(x); D, I = index.search(x, k)
+
+Index files. `write_index` / `read_index` speak FAISS's own container for flat inner-product
+indexes (fourcc ``IxFI``) and `read_index` also accepts the IVF-flat container the reference ships
+(fourcc ``IwFl``, reference src/lean_explore/extract/index.py:103-104,173): the inverted lists are
+scattered back to add order and searched exactly (what IVF approximates). The byte layout is
+restated from upstream faiss's index_write.cpp; no faiss-written file exists in this image, so it
+is checked by writer/reader round trips only — UNVERIFIED against real faiss files.
+"""
+
+from __future__ import annotations
+
+import struct
+from pathlib import Path
+
+import numpy as np
+
+from .index import FlatIPIndex, normalize_L2  # noqa: F401  (re-exported)
+
+METRIC_INNER_PRODUCT = 0
+METRIC_L2 = 1
+
+
+class IndexFlatIP(FlatIPIndex):
+    """faiss.IndexFlatIP(d) (reference extract/index.py:103)."""
+
+    def __init__(self, d: int, dtype="f32", device: int = 0):
+        super().__init__(d, dtype=dtype, device=device)
+
+
+# ------------------------------------------------------------------ container format helpers
+def _fourcc(s: str) -> int:
+    return struct.unpack("<I", s.encode("ascii"))[0]
+
+
+def _write_header(f, d: int, ntotal: int, metric: int) -> None:
+    # write_index_header: d (int32), ntotal (int64), two dummy int64 (1 << 20), is_trained (u8),
+    # metric_type (int32)
+    f.write(struct.pack("<iqqqBi", d, ntotal, 1 << 20, 1 << 20, 1, metric))
+
+
+def _read_header(f) -> tuple[int, int, int]:
+    d, ntotal, _, _, _, metric = struct.unpack("<iqqqBi", f.read(4 + 8 + 8 + 8 + 1 + 4))
+    if metric > 1:
+        f.read(4)  # metric_arg
+    return d, ntotal, metric
+
+
+def _read_vector(f, dtype, what: str) -> np.ndarray:
+    (count,) = struct.unpack("<Q", f.read(8))
+    itemsize = np.dtype(dtype).itemsize
+    raw = f.read(count * itemsize)
+    if len(raw) != count * itemsize:
+        raise ValueError(f"truncated index file while reading {what}")
+    return np.frombuffer(raw, dtype=dtype, count=count)
+
+
+def _read_flat_payload(f) -> tuple[int, np.ndarray]:
+    d, ntotal, _ = _read_header(f)
+    xb = _read_vector(f, "<f4", "flat storage")  # count is in floats (xb / codes/4)
+    if xb.size != d * ntotal:
+        raise ValueError("flat index: storage size does not match d * ntotal")
+    return d, xb.reshape(ntotal, d).astype(np.float32, copy=True)
+
+
+def write_index(index: FlatIPIndex, path: str | Path) -> None:
+    """faiss.write_index for a flat inner-product index (container ``IxFI``)."""
+    corpus = np.ascontiguousarray(index.host_corpus(), dtype="<f4")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", _fourcc("IxFI")))
+        _write_header(f, index.d, corpus.shape[0], METRIC_INNER_PRODUCT)
+        f.write(struct.pack("<Q", corpus.size))
+        f.write(corpus.tobytes())
+
+
+def read_index(path: str | Path, dtype="f32", device: int = 0) -> FlatIPIndex:
+    """faiss.read_index (reference search/engine.py:159) -> exact HIP index."""
+    path = Path(path)
+    with open(path, "rb") as f:
+        (cc,) = struct.unpack("<I", f.read(4))
+        if cc == _fourcc("IxFI"):
+            d, corpus = _read_flat_payload(f)
+        elif cc == _fourcc("IwFl"):
+            d, corpus = _read_ivf_flat(f)
+        else:
+            tag = struct.pack("<I", cc).decode("ascii", "replace")
+            raise ValueError(f"{path}: unsupported index container {tag!r} "
+                             "(expected IxFI flat-IP or IwFl IVF-flat)")
+    index = FlatIPIndex(d, dtype=dtype, device=device)
+    if corpus.shape[0]:
+        index.add(corpus)
+    return index
+
+
+def _read_ivf_flat(f) -> tuple[int, np.ndarray]:
+    """IndexIVFFlat: ivf header, nested quantizer, direct map, ArrayInvertedLists (``ilar``)."""
+    d, ntotal, metric = _read_header(f)
+    if metric != METRIC_INNER_PRODUCT:
+        raise ValueError("IVF index is not an inner-product index")
+    nlist, _nprobe = struct.unpack("<QQ", f.read(16))
+    (qcc,) = struct.unpack("<I", f.read(4))  # nested coarse quantizer: read and discard
+    if qcc not in (_fourcc("IxFI"), _fourcc("IxF2")):
+        raise ValueError("IVF index: unsupported coarse quantizer container")
+    _read_flat_payload(f)
+    (dm_type,) = struct.unpack("<b", f.read(1))  # direct map
+    _read_vector(f, "<i8", "direct map")
+    if dm_type == 2:
+        raise ValueError("IVF index: hashtable direct maps are not supported")
+    (lcc,) = struct.unpack("<I", f.read(4))
+    if lcc != _fourcc("ilar"):
+        raise ValueError("IVF index: unsupported inverted-list container")
+    nl, code_size = struct.unpack("<QQ", f.read(16))
+    if nl != nlist or code_size != 4 * d:
+        raise ValueError("IVF index: inverted lists do not match the header")
+    (list_type,) = struct.unpack("<I", f.read(4))
+    sizes = np.zeros(nlist, dtype=np.int64)
+    raw = _read_vector(f, "<u8", "list sizes")
+    if list_type == _fourcc("full"):
+        sizes[:] = raw
+    elif list_type == _fourcc("sprs"):
+        sizes[raw[0::2].astype(np.int64)] = raw[1::2]
+    else:
+        raise ValueError("IVF index: unknown list-size encoding")
+    corpus = np.zeros((ntotal, d), dtype=np.float32)
+    seen = np.zeros(ntotal, dtype=bool)
+    for n in sizes:
+        n = int(n)
+        if n == 0:
+            continue
+        codes = np.frombuffer(f.read(n * code_size), dtype="<f4").reshape(n, d)
+        ids = np.frombuffer(f.read(n * 8), dtype="<i8")
+        corpus[ids] = codes  # ids are the add-order row numbers (index.add without ids)
+        seen[ids] = True
+    if not seen.all():
+        raise ValueError("IVF index: inverted lists do not cover every row")
+    return d, corpus
+
+
+def write_ivf_flat_for_tests(path, corpus: np.ndarray, assign: np.ndarray, nlist: int) -> None:
+    """Write an ``IwFl`` file with the given row -> list assignment (test helper: exercises the
+    reader on the layout the reference ships; not a trained IVF)."""
+    corpus = np.ascontiguousarray(corpus, dtype="<f4")
+    n, d = corpus.shape
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", _fourcc("IwFl")))
+        _write_header(f, d, n, METRIC_INNER_PRODUCT)
+        f.write(struct.pack("<QQ", nlist, 1))
+        f.write(struct.pack("<I", _fourcc("IxFI")))           # quantizer: nlist zero centroids
+        _write_header(f, d, nlist, METRIC_INNER_PRODUCT)
+        f.write(struct.pack("<Q", nlist * d))
+        f.write(np.zeros(nlist * d, "<f4").tobytes())
+        f.write(struct.pack("<b", 0))                         # no direct map
+        f.write(struct.pack("<Q", 0))
+        f.write(struct.pack("<I", _fourcc("ilar")))
+        f.write(struct.pack("<QQ", nlist, 4 * d))
+        f.write(struct.pack("<I", _fourcc("full")))
+        sizes = np.bincount(assign, minlength=nlist).astype("<u8")
+        f.write(struct.pack("<Q", nlist))
+        f.write(sizes.tobytes())
+        for li in range(nlist):
+            ids = np.nonzero(assign == li)[0].astype("<i8")
+            if ids.size:
+                f.write(corpus[ids].tobytes())
+                f.write(ids.tobytes())

@@ -46,6 +46,8 @@ def normalize_L2(x: np.ndarray, device: int = 0) -> None:
 class FlatIPIndex:
     """Exact inner-product index resident in one GPU's HBM."""
 
+    supports_fused_normalize = True  # search(..., normalize=True) fuses faiss.normalize_L2
+
     def __init__(self, d: int, dtype: Any = "f32", device: int = 0, base: int = 0):
         if d <= 0:
             raise ValueError("d must be positive")

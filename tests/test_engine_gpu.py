@@ -1,0 +1,55 @@
+"""Service.search() end to end on the MI355X: index file on disk -> read_index -> HIP search ->
+row/id mapping -> fusion, against the same engine driven by the CPU oracle."""
+
+import numpy as np
+import pytest
+
+from lean_explore_amd import faiss_compat, loader
+from lean_explore_amd import search as S
+from tests import helpers as H
+from tests.test_glue_cpu import FakeEmbed, OracleIndex, _make_db, run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("container", ["flat", "ivf"])
+def test_service_search_drop_in(tmp_path, container):
+    import json
+
+    n, d = 3000, 1024
+    corpus = H.gauss(17, n, d)
+    rows = []
+    for i in range(n):
+        deps = json.dumps([f"Mathlib.decl{(i * 7 + 1) % n}"]) if i % 4 == 0 else None
+        rows.append((5000 + i, f"Mathlib.decl{i}" if i % 50 else f"Mathlib.S{i}.mk", "Mathlib.Mod",
+                     "doc", f"theorem t{i}", f"http://x/{i}", deps, f"statement {i}",
+                     loader.embedding_to_blob(corpus[i].tolist())))
+    db = tmp_path / "lean_explore.db"
+    _make_db(db, rows)
+    ids, loaded = loader.load_corpus_from_sqlite(db)
+    assert np.array_equal(loaded, corpus)
+    loader.save_ids_map(tmp_path / "informalization_faiss_ids_map.json", ids)
+    index_path = tmp_path / "informalization_faiss.index"
+    if container == "flat":
+        ix = faiss_compat.IndexFlatIP(d)
+        ix.add(loaded)
+        faiss_compat.write_index(ix, index_path)
+    else:  # the container the reference ships (IVF-flat), searched exactly
+        assign = np.random.default_rng(3).integers(0, 256, size=n)
+        faiss_compat.write_ivf_flat_for_tests(index_path, loaded, assign, 256)
+
+    qvec = corpus[123] * 3.0 + 0.01 * H.gauss(5, 1, d)[0]
+    hip = S.SearchEngine(base_path=tmp_path, embedding_client=FakeEmbed(qvec))
+    ref = S.SearchEngine(db_path=db, embedding_client=FakeEmbed(qvec), index=OracleIndex(loaded),
+                         ids_map=ids)
+    sem_hip = run(hip._retrieve_semantic_candidates("q", 1000))
+    sem_ref = run(ref._retrieve_semantic_candidates("q", 1000))
+    assert list(sem_hip) == list(sem_ref)                       # same ids in the same rank order
+    assert list(sem_hip)[0] == 5123
+    assert np.allclose(list(sem_hip.values()), list(sem_ref.values()), atol=1e-5)
+
+    r_hip = run(S.Service(engine=hip).search("q", limit=20, rerank_top=0))
+    r_ref = run(S.Service(engine=ref).search("q", limit=20, rerank_top=0))
+    assert [r.id for r in r_hip.results] == [r.id for r in r_ref.results]
+    assert r_hip.count == len(r_hip.results) > 0
+    assert all(not r.name.endswith(".mk") for r in r_hip.results)

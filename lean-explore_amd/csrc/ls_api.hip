@@ -15,6 +15,8 @@
 #include <vector>
 
 #define LS_NSETS 2
+#define LS_BC_SLOTS 16
+#define LS_CORPUS_PAD_ROWS 128
 #define LS_PROF_MAX 4096
 
 static thread_local char g_err[512] = "";
@@ -56,9 +58,11 @@ struct ls_index {
     u32* d_counts = nullptr;   size_t counts_cap = 0;
     float* d_tau = nullptr;    size_t tau_cap = 0;
     u32* d_overflow = nullptr; size_t overflow_cap = 0;
+    u32* d_sample_top = nullptr; size_t sample_top_cap = 0;  // 4 best sample scores per lane
     u32* h_overflow = nullptr; size_t h_overflow_cap = 0;  // pinned
-    struct batched_call {      // last batched call, kept so ls_check can repair flagged queries
-        bool active = false;
+    // async batched calls not yet checked: each keeps its own flag slice of d_overflow so that
+    // several batches can be in flight before one ls_check repairs whatever was flagged
+    struct batched_call {
         const float* d_q = nullptr;
         int64_t nq = 0;
         int32_t k = 0;
@@ -66,7 +70,10 @@ struct ls_index {
         float* d_out_s = nullptr;
         int64_t* d_out_i = nullptr;
         hipStream_t stream = nullptr;
-    } bc;
+        int32_t slot = 0;
+    };
+    std::vector<batched_call> bc_pending;
+    int64_t bc_slot_stride = 0;  // u32 per flag slot
     uint64_t n_batched_fallback = 0;  // queries repaired by the scan path (host counter)
     int32_t opt_gemm = 1;             // allow the batched MFMA path
     int32_t opt_spec_tau = 1;         // speculative (verified) sample threshold
@@ -175,7 +182,12 @@ static int create_common(ls_index** out, int64_t n, int32_t d, int32_t dtype, in
 
 static int alloc_index_buffers(ls_index* ix) {
     const size_t row_bytes = (size_t)ix->g.chunks * 16;
-    if (ix->n > 0) LS_HIP(hipMalloc(&ix->d_corpus, (size_t)ix->n * row_bytes));
+    // the batched path reads whole 64-row tiles: keep LS_CORPUS_PAD_ROWS zero rows past n
+    if (ix->n > 0) {
+        LS_HIP(hipMalloc(&ix->d_corpus, (size_t)(ix->n + LS_CORPUS_PAD_ROWS) * row_bytes));
+        LS_HIP(hipMemset((char*)ix->d_corpus + (size_t)ix->n * row_bytes, 0,
+                         (size_t)LS_CORPUS_PAD_ROWS * row_bytes));
+    }
     LS_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
     ix->max_blocks = ls_scan_blocks(ix->n > 0 ? ix->n : 1, ix->g, ix->n_cu);
     for (auto& st : ix->sets) {
@@ -214,6 +226,7 @@ void ls_destroy(ls_index* ix) {
     (void)hipFree(ix->d_counts);
     (void)hipFree(ix->d_tau);
     (void)hipFree(ix->d_overflow);
+    (void)hipFree(ix->d_sample_top);
     if (ix->h_overflow) (void)hipHostFree(ix->h_overflow);
     if (ix->h_q) (void)hipHostFree(ix->h_q);
     if (ix->h_out_s) (void)hipHostFree(ix->h_out_s);
@@ -438,22 +451,30 @@ static bool batched_eligible(const ls_index* ix, int64_t nq, int32_t k) {
 // Re-run the queries of the last batched call whose candidate queues overflowed (or were short)
 // through the exact per-query scan path. Synchronises the stream.
 static int batched_repair(ls_index* ix) {
-    ls_index::batched_call& bc = ix->bc;
-    if (!bc.active) return LS_OK;
-    bc.active = false;
-    const int64_t nq_pad = (bc.nq + LS_GEMM_QT - 1) / LS_GEMM_QT * LS_GEMM_QT;
-    LS_HIP(hipMemcpyAsync(ix->h_overflow, ix->d_overflow, sizeof(u32) * (size_t)nq_pad,
-                          hipMemcpyDeviceToHost, bc.stream));
-    LS_HIP(hipStreamSynchronize(bc.stream));
-    for (int64_t q = 0; q < bc.nq; ++q) {
-        if (!ix->h_overflow[q]) continue;
-        ix->n_batched_fallback++;
-        int rc = scan_search_on_stream(ix, bc.d_q + q * ix->g.d, 1, bc.k,
-                                       bc.flags & LS_FLAG_NORMALIZE, bc.d_out_s + q * bc.k,
-                                       bc.d_out_i + q * bc.k, bc.stream);
-        if (rc != LS_OK) return rc;
+    if (ix->bc_pending.empty()) return LS_OK;
+    std::vector<ls_index::batched_call> pend;
+    pend.swap(ix->bc_pending);
+    hipStream_t s = pend.back().stream;
+    for (const auto& bc : pend)  // all slots are read after the youngest call has drained
+        if (bc.stream != s) LS_HIP(hipStreamSynchronize(bc.stream));
+    LS_HIP(hipMemcpyAsync(ix->h_overflow, ix->d_overflow,
+                          sizeof(u32) * (size_t)(ix->bc_slot_stride * LS_BC_SLOTS),
+                          hipMemcpyDeviceToHost, s));
+    LS_HIP(hipStreamSynchronize(s));
+    bool any = false;
+    for (const auto& bc : pend) {
+        const u32* fl = ix->h_overflow + (size_t)bc.slot * ix->bc_slot_stride;
+        for (int64_t q = 0; q < bc.nq; ++q) {
+            if (!fl[q]) continue;
+            ix->n_batched_fallback++;
+            any = true;
+            int rc = scan_search_on_stream(ix, bc.d_q + q * ix->g.d, 1, bc.k,
+                                           bc.flags & LS_FLAG_NORMALIZE, bc.d_out_s + q * bc.k,
+                                           bc.d_out_i + q * bc.k, s);
+            if (rc != LS_OK) return rc;
+        }
     }
-    LS_HIP(hipStreamSynchronize(bc.stream));
+    if (any) LS_HIP(hipStreamSynchronize(s));
     return LS_OK;
 }
 
@@ -462,8 +483,10 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
                                     hipStream_t s) {
     int rc = flush_pending(ix);
     if (rc != LS_OK) return rc;
-    if (ix->bc.active) {  // an earlier async batched call has not been checked yet
-        rc = batched_repair(ix);
+    const int64_t nq_pad0 = (nq + LS_GEMM_QT - 1) / LS_GEMM_QT * LS_GEMM_QT;
+    if ((int)ix->bc_pending.size() >= LS_BC_SLOTS ||
+        (!ix->bc_pending.empty() && nq_pad0 > ix->bc_slot_stride)) {
+        rc = batched_repair(ix);  // flag slots exhausted (or too small): check what is pending
         if (rc != LS_OK) return rc;
     }
     const ls_geom& g = ix->g;
@@ -487,8 +510,17 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     if ((rc = grow(&ix->d_queues, &ix->queues_cap, nwg * LS_GEMM_THREADS * cap)) != LS_OK) return rc;
     if ((rc = grow(&ix->d_counts, &ix->counts_cap, nwg * LS_GEMM_THREADS)) != LS_OK) return rc;
     if ((rc = grow(&ix->d_tau, &ix->tau_cap, (size_t)nq_pad)) != LS_OK) return rc;
-    if ((rc = grow(&ix->d_overflow, &ix->overflow_cap, (size_t)nq_pad)) != LS_OK) return rc;
-    if ((rc = grow_pinned(&ix->h_overflow, &ix->h_overflow_cap, (size_t)nq_pad)) != LS_OK) return rc;
+    if (ix->bc_pending.empty() && nq_pad > ix->bc_slot_stride) ix->bc_slot_stride = nq_pad;
+    if ((rc = grow(&ix->d_overflow, &ix->overflow_cap,
+                   (size_t)ix->bc_slot_stride * LS_BC_SLOTS)) != LS_OK)
+        return rc;
+    const int slot = (int)ix->bc_pending.size();
+    u32* d_flags = ix->d_overflow + (size_t)slot * ix->bc_slot_stride;
+    if ((rc = grow(&ix->d_sample_top, &ix->sample_top_cap, nwg * LS_GEMM_THREADS * 4)) != LS_OK)
+        return rc;
+    if ((rc = grow_pinned(&ix->h_overflow, &ix->h_overflow_cap,
+                          (size_t)ix->bc_slot_stride * LS_BC_SLOTS)) != LS_OK)
+        return rc;
 
     const bool prof = ix->profiling && ix->prof_n < LS_PROF_MAX;
     hipEvent_t* pe = nullptr;
@@ -500,12 +532,13 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         }
         pe = &ix->prof_ev[2 * ix->prof_n];
     }
-    LS_HIP(hipMemsetAsync(ix->d_overflow, 0, sizeof(u32) * (size_t)nq_pad, s));
-    rc = ls_launch_prep_f16(d_q, ix->d_qh, nq, nq_pad, g, (flags & LS_FLAG_NORMALIZE) != 0, s);
+    rc = ls_launch_prep_f16(d_q, ix->d_qh, nq, nq_pad, g, (flags & LS_FLAG_NORMALIZE) != 0,
+                            d_flags, s);
     if (rc != LS_OK) return rc;
     // sample pass: tau[q] = k-th best score over ~LS_GEMM_SAMPLE_TILES tiles of every slice
     rc = ls_launch_gemm_filter(ix->d_corpus, ix->n, g, ix->d_qh, nq, nq_pad, nullptr, nsplits, rps,
-                               sample_stride, ix->d_queues, ix->d_counts, cap, ix->d_overflow, s);
+                               sample_stride, ix->d_queues, ix->d_counts, cap, d_flags,
+                               ix->d_sample_top, s);
     if (rc != LS_OK) return rc;
     // Speculative threshold. The k-th best SAMPLE score is a certified lower bound of the final
     // k-th best but passes ~k*N/M0 rows per query. The j-th best sample score (j < k) passes only
@@ -526,15 +559,15 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         }
     }
     static const bool abl_nopass = getenv("LS_GEMM_ABL_NOPASS") != nullptr;  // timing ablation only
-    rc = ls_launch_tau(ix->d_queues, ix->d_counts, cap, nsplits, nq, nq_pad, jrank, ix->d_tau, s);
+    rc = ls_launch_tau(ix->d_sample_top, nsplits, nq, nq_pad, jrank, ix->d_tau, s);
     if (abl_nopass)  // every tau = FLT_MAX: the epilogue never appends (results are garbage)
         LS_HIP(hipMemsetD32Async((hipDeviceptr_t)ix->d_tau, 0x7f7fffff, (size_t)nq_pad, s));
     if (rc != LS_OK) return rc;
-    LS_HIP(hipMemsetAsync(ix->d_overflow, 0, sizeof(u32) * (size_t)nq_pad, s));
     // full pass
     if (prof) LS_HIP(hipEventRecord(pe[0], s));
     rc = ls_launch_gemm_filter(ix->d_corpus, ix->n, g, ix->d_qh, nq, nq_pad, ix->d_tau, nsplits,
-                               rps, 1, ix->d_queues, ix->d_counts, cap, ix->d_overflow, s);
+                               rps, 1, ix->d_queues, ix->d_counts, cap, d_flags,
+                               ix->d_sample_top, s);
     if (rc != LS_OK) return rc;
     if (prof) {
         LS_HIP(hipEventRecord(pe[1], s));
@@ -542,16 +575,18 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     }
     if (abl_nopass) return LS_OK;
     rc = ls_launch_batch_select(ix->d_queues, ix->d_counts, cap, nsplits, nq, nq_pad, k, ix->base,
-                                ix->d_overflow, d_out_s, d_out_i, s);
+                                d_flags, d_out_s, d_out_i, s);
     if (rc != LS_OK) return rc;
-    ix->bc.active = true;
-    ix->bc.d_q = d_q;
-    ix->bc.nq = nq;
-    ix->bc.k = k;
-    ix->bc.flags = flags;
-    ix->bc.d_out_s = d_out_s;
-    ix->bc.d_out_i = d_out_i;
-    ix->bc.stream = s;
+    ls_index::batched_call bc;
+    bc.d_q = d_q;
+    bc.nq = nq;
+    bc.k = k;
+    bc.flags = flags;
+    bc.d_out_s = d_out_s;
+    bc.d_out_i = d_out_i;
+    bc.stream = s;
+    bc.slot = slot;
+    ix->bc_pending.push_back(bc);
     if (!(flags & (LS_FLAG_ASYNC | LS_FLAG_PIPELINE))) return batched_repair(ix);
     return LS_OK;
 }

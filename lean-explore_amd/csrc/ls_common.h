@@ -28,13 +28,13 @@ typedef unsigned int u32;
 #define LS_SCAN_MAX_NQ 16            // nq <= this: per-query HBM-bound scan path
 #define LS_GEMM_THREADS 512          // batched path: 8 waves x 32 queries per workgroup
 #define LS_GEMM_QT 256               // queries per workgroup
-#define LS_GEMM_TM 32                // corpus rows per LDS tile (one MFMA row block)
-#define LS_GEMM_APF 6                 // A fragments in flight ahead of the MFMA
+#define LS_GEMM_TM 64                // corpus rows per LDS tile (two MFMA row blocks)
+#define LS_GEMM_APF 3                 // A fragments (per row block) in flight ahead of the MFMA
 #define LS_GEMM_MAX_K 128            // batched path handles k <= this (larger k: scan path)
 #define LS_GEMM_MAX_CHUNKS 64        // ... and stored rows <= 1 KiB (d <= 512 fp16)
 #define LS_GEMM_MIN_ROWS 32768       // ... and shards at least this big
 #define LS_GEMM_QCAP 64              // entries per private candidate queue
-#define LS_GEMM_SAMPLE_TILES 4       // sample pass: tiles per workgroup (<= QCAP/16)
+#define LS_GEMM_SAMPLE_TILES 2       // sample pass: 64-row tiles per workgroup
 #define LS_GEMM_MAX_SPLITS 64        // corpus slices (tau kernel reads <= 8192 sample scores)
 
 __host__ __device__ __forceinline__ u32 ls_ord(float f) {
@@ -119,13 +119,13 @@ int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const floa
 int ls_launch_finalize(const ls_fin_params& p, hipStream_t s);
 // batched MFMA path (ls_gemm.hip)
 int ls_launch_prep_f16(const float* d_q, void* d_qh, int64_t nq, int64_t nq_pad, const ls_geom& g,
-                       bool normalize, hipStream_t s);
+                       bool normalize, u32* d_overflow, hipStream_t s);
 int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, const void* d_qh,
                           int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
                           int64_t rows_per_split, int tile_stride, u64* d_queues, u32* d_counts,
-                          int cap, u32* d_overflow, hipStream_t s);
-int ls_launch_tau(const u64* d_queues, const u32* d_counts, int cap, int nsplits, int64_t nq,
-                  int64_t nq_pad, int k, float* d_tau, hipStream_t s);
+                          int cap, u32* d_overflow, u32* d_sample_top, hipStream_t s);
+int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_pad, int j_rank,
+                  float* d_tau, hipStream_t s);
 int ls_launch_batch_select(const u64* d_queues, const u32* d_counts, int cap, int nsplits,
                            int64_t nq, int64_t nq_pad, int k, int64_t base, u32* d_overflow,
                            float* d_out_scores, int64_t* d_out_indices, hipStream_t s);

@@ -9,10 +9,12 @@
 // ls_gemm_filter_kernel — one workgroup = 8 waves = 256 queries x one corpus slice
 //   - B operand (queries): each wave keeps its 32 queries' fp16 fragments in VGPRs for the
 //     whole slice (KSTEPS x 4 registers), so B costs no LDS or HBM traffic in the loop.
-//   - A operand (corpus): tiles of 32 rows stream HBM/L2 -> registers -> LDS, two tiles in
-//     flight in registers while a third is consumed from LDS (a 1-tile look-ahead measured
-//     latency-bound), and are shared by the 8 waves. LDS rows are XOR-swizzled
-//     (chunk ^ (row & 15)) so the ds_read_b128 fragment reads are bank-conflict free.
+//   - A operand (corpus): tiles of 64 rows stream HBM/L2 -> LDS by DMA (global_load_lds,
+//     double buffered) and are shared by the 8 waves. LDS rows are XOR-swizzled on the SOURCE
+//     address (chunk ^ (row & 15)) so the ds_read_b128 fragment reads are bank-conflict free.
+//   - the two 32-row blocks of a tile run in lock step on two accumulators (independent MFMA
+//     chains) while the previous tile's two accumulators are filtered one element per MFMA, in
+//     the shadow of the matrix pipe (a microbenchmark of this pattern: scratch/ub/mfma_ub.hip).
 //   - v_mfma_f32_32x32x16_f16: D[row, query] accumulates in fp32; fp16 x fp16 products are exact.
 //   - epilogue: lane (query j, half h) holds 16 row scores of ONE query. A score >= tau[j]
 //     (tau = k-th best of a row sample, a certified lower bound of the final k-th best) is
@@ -35,9 +37,11 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // ---- queries -> fp16 [nq_pad, d_pad], normalised if asked, zero padded ---------------------------
 __global__ __launch_bounds__(256) void ls_prep_f16_kernel(const float* __restrict__ qin,
                                                           _Float16* __restrict__ qout, int nq,
-                                                          int d, int d_pad, int normalize) {
+                                                          int d, int d_pad, int normalize,
+                                                          u32* __restrict__ overflow) {
     __shared__ float red[4];
     const int qi = blockIdx.x;
+    if (threadIdx.x == 0) overflow[qi] = 0u;  // per-query repair flag, cleared for this batch
     _Float16* dst = qout + (long long)qi * d_pad;
     if (qi >= nq) {
         for (int j = threadIdx.x; j < d_pad; j += 256) dst[j] = (_Float16)0.0f;
@@ -59,9 +63,9 @@ __global__ __launch_bounds__(256) void ls_prep_f16_kernel(const float* __restric
 }
 
 int ls_launch_prep_f16(const float* d_q, void* d_qh, int64_t nq, int64_t nq_pad, const ls_geom& g,
-                       bool normalize, hipStream_t s) {
+                       bool normalize, u32* d_overflow, hipStream_t s) {
     hipLaunchKernelGGL(ls_prep_f16_kernel, dim3((unsigned)nq_pad), dim3(256), 0, s, d_q,
-                       (_Float16*)d_qh, (int)nq, g.d, g.d_pad, normalize ? 1 : 0);
+                       (_Float16*)d_qh, (int)nq, g.d, g.d_pad, normalize ? 1 : 0, d_overflow);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
@@ -77,18 +81,39 @@ __host__ __device__ __forceinline__ int wg_index(int split, int qt, int nqt) {
     return (((split >> 3) * nqt + qt) << 3) | (split & 7);
 }
 
+// top-4 of a lane's sample scores, descending (branch-free insert)
+__device__ __forceinline__ void top4_insert(u32 (&t)[4], u32 v) {
+    u32 a = v > t[3] ? v : t[3];
+    u32 hi = a > t[2] ? a : t[2], lo = a > t[2] ? t[2] : a;
+    t[3] = lo;
+    a = hi;
+    hi = a > t[1] ? a : t[1];
+    lo = a > t[1] ? t[1] : a;
+    t[2] = lo;
+    a = hi;
+    hi = a > t[0] ? a : t[0];
+    lo = a > t[0] ? t[0] : a;
+    t[1] = lo;
+    t[0] = hi;
+}
+
 template <int CHUNKS, bool SAMPLE>
 __global__ __launch_bounds__(LS_GEMM_THREADS, 2) void ls_gemm_filter_kernel(
     const u32x4* __restrict__ corpus, long long n, const u32x4* __restrict__ qh, int nq, int nqt,
     const float* __restrict__ tau, long long rows_per_split, int tile_stride,
-    u64* __restrict__ queues, u32* __restrict__ counts, int cap, u32* __restrict__ overflow) {
+    u64* __restrict__ queues, u32* __restrict__ counts, int cap, u32* __restrict__ overflow,
+    u32* __restrict__ sample_top) {
     constexpr int KSTEPS = CHUNKS / 2;                    // 16 fp16 per MFMA k-step = 2 chunks
+    constexpr int ROW_BYTES = CHUNKS * 16;
     constexpr int TILE_CHUNKS = LS_GEMM_TM * CHUNKS;      // 16-byte chunks per LDS tile
+    constexpr int TILE_BYTES = TILE_CHUNKS * 16;
     constexpr int LOADS = TILE_CHUNKS / LS_GEMM_THREADS;  // 16-byte loads per thread per tile
+    constexpr int NRB = LS_GEMM_TM / 32;                  // MFMA row blocks per tile
     static_assert(TILE_CHUNKS % LS_GEMM_THREADS == 0, "tile must split evenly over the threads");
+    static_assert(NRB == 2, "the block pipeline below alternates two accumulators");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 tiles
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     int split, qt;
     wg_coords((int)blockIdx.x, nqt, &split, &qt);
     const long long r_begin = (long long)split * rows_per_split;
@@ -97,11 +122,11 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, 2) void ls_gemm_filter_kernel(
     const int ntiles_all = r_begin < r_end ? (int)((r_end - r_begin + LS_GEMM_TM - 1) / LS_GEMM_TM) : 0;
     const int nt = (ntiles_all + tile_stride - 1) / tile_stride;  // tiles this launch visits
 
-    // B fragments: query j = qt*QT + wave*32 + (lane & 31); k-step kk -> chunk 2kk + (lane >> 5)
+    // B fragments: query j = qt*QT + wave*32 + (lane & 31); k-step kk -> chunk 2kk + half
     const int qj = qt * LS_GEMM_QT + wave * 32 + (lane & 31);
     half8 bq[KSTEPS];
     {
-        const u32x4* qrow = qh + (long long)qj * CHUNKS + (lane >> 5);
+        const u32x4* qrow = qh + (long long)qj * CHUNKS + half;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             const u32x4 v = qrow[2 * kk];
@@ -109,124 +134,143 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, 2) void ls_gemm_filter_kernel(
         }
     }
     const bool qvalid = qj < nq;
-    const float tauv = tau ? tau[qj] : -FLT_MAX;
+    const float tauv = SAMPLE ? 0.0f : tau[qj];
 
-    // private queue of this lane: entry e at queues[(b*THREADS + tid)*cap + e] (contiguous per
-    // lane, so the select kernels read a queue as one coalesced run)
     u64* myq = queues + ((long long)blockIdx.x * LS_GEMM_THREADS + tid) * cap;
     int cnt = 0;
+    u32 top[4] = {0u, 0u, 0u, 0u};
 
-    // Corpus tiles travel HBM/L2 -> registers -> LDS. Two tiles are in flight in registers
-    // (ra, rb) while a third is being consumed from LDS: the loads are ordinary global loads, so
-    // hipcc counts them (vmcnt(N), not 0) next to the epilogue's queue stores.
-    // Thread t fills LDS chunks Lc = j*THREADS + t of the tile: row r = Lc / CHUNKS, slot
-    // sl = Lc % CHUNKS holds source chunk sl ^ (r & 15) (XOR swizzle: conflict-free ds_read_b128).
-    auto load_tile = [&](int ti, u32x4 (&rg)[LOADS]) {
-        const long long row0 = r_begin + (long long)ti * LS_GEMM_TM;
+    // ---- corpus tiles: HBM/L2 -> LDS by DMA (global_load_lds, 16 B per lane), double buffered --
+    // Wave w, load j fills the 64 consecutive LDS chunks starting at (w*LOADS + j)*64: chunk Lc
+    // is tile row r = Lc / CHUNKS, slot sl = Lc % CHUNKS and receives SOURCE chunk sl ^ (r & 15)
+    // (the swizzle is applied to the source address: the DMA destination is lane-linear). The
+    // per-thread source offsets are loop invariant; the HBM copy is padded with zero rows past n
+    // (ls_api.hip), so no clamping is needed. A 64-row tile takes ~3 us to consume, longer than
+    // the DMA's flight time, so one tile of look-ahead suffices.
+    int goff[LOADS];
+#pragma unroll
+    for (int j = 0; j < LOADS; ++j) {
+        const int Lc = (wave * LOADS + j) * 64 + lane;
+        const int r = Lc / CHUNKS, sl = Lc % CHUNKS;
+        goff[j] = r * CHUNKS + (sl ^ (r & 15));
+    }
+    auto stage = [&](int ti, int buf) {
+        const u32x4* base = corpus + (r_begin + (long long)ti * LS_GEMM_TM) * CHUNKS;
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) {
-            const int Lc = j * LS_GEMM_THREADS + tid;
-            const int r = Lc / CHUNKS, sl = Lc % CHUNKS;
-            long long row = row0 + r;
-            row = row < n ? row : n - 1;
-            rg[j] = corpus[row * CHUNKS + (sl ^ (r & 15))];
+            unsigned char* dst = smem + buf * TILE_BYTES + (wave * LOADS + j) * 1024;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + goff[j]), (lds_ptr_t)dst, 16, 0, 0);
         }
-    };
-    auto write_tile = [&](int buf, const u32x4 (&rg)[LOADS]) {
-        unsigned char* base = smem + (size_t)buf * TILE_CHUNKS * 16;
-#pragma unroll
-        for (int j = 0; j < LOADS; ++j)
-            *reinterpret_cast<u32x4*>(base + (size_t)(j * LS_GEMM_THREADS + tid) * 16) = rg[j];
     };
 
-    const int ar = lane & 31;  // A fragment: row ar of the tile, chunk 2kk + (lane >> 5)
-    auto compute_tile = [&](int i, int buf) {
-        const unsigned char* tb = smem + (size_t)buf * TILE_CHUNKS * 16 + (size_t)ar * CHUNKS * 16;
-        f32x16 acc;
+    // A fragment of k-step kk, row block rb: row ar = lane & 31, chunk (2kk + half) ^ (ar & 15).
+    // (2kk + half) & 15 takes 8 values per lane: 8 precomputed byte offsets + immediates.
+    const int ar = lane & 31;
+    int lo8[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        // A fragments run LS_GEMM_APF k-steps ahead of the MFMA that consumes them
-        u32x4 af[LS_GEMM_APF];
-#pragma unroll
-        for (int kk = 0; kk < LS_GEMM_APF && kk < KSTEPS; ++kk)
-            af[kk] = *reinterpret_cast<const u32x4*>(tb + (((2 * kk + (lane >> 5)) ^ (ar & 15)) * 16));
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                __builtin_bit_cast(half8, af[kk % LS_GEMM_APF]), bq[kk], acc, 0, 0, 0);
-            if (kk + LS_GEMM_APF < KSTEPS)
-                af[kk % LS_GEMM_APF] = *reinterpret_cast<const u32x4*>(
-                    tb + (((2 * (kk + LS_GEMM_APF) + (lane >> 5)) ^ (ar & 15)) * 16));
-        }
-        // pin the schedule hipcc would otherwise collapse to read->wait->mfma:
-        // APF LDS reads up front, then one MFMA per LDS read (masks: 0x100 DS read, 0x008 MFMA)
-        __builtin_amdgcn_sched_group_barrier(0x100, LS_GEMM_APF, 0);
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (kk + LS_GEMM_APF < KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        // epilogue: acc[r] = <corpus row, query qj>, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        const long long row0 = r_begin + (long long)(i * tile_stride) * LS_GEMM_TM + 4 * (lane >> 5);
+    for (int m = 0; m < 8; ++m) lo8[m] = ar * ROW_BYTES + (((2 * m + half) ^ (ar & 15)) * 16);
+    auto a_frag = [&](int buf, int rb, int kk) -> half8 {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + lo8[kk & 7] + buf * TILE_BYTES +
+                                                        rb * 32 * ROW_BYTES + (kk >> 3) * 256);
+        return __builtin_bit_cast(half8, v);
+    };
+
+    // ---- one element of a finished 32x32 block ------------------------------------------------------
+    // element r: row = row0 + (r&3) + 8*(r>>2) (row0 already includes 4*half)
+    auto check = [&](const f32x16& acc, int r, long long row0) {
+        const float s = acc[r];
+        const long long row = row0 + (r & 3) + 8 * (r >> 2);
         if (SAMPLE) {
-            // sample pass: every score is kept (0 = no entry): 16 keys = one 128-byte line per
-            // lane and tile, written as 8 x 16-byte stores
-            u64 kk2[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long row = row0 + (r & 3) + 8 * (r >> 2);
-                kk2[r] = (qvalid && row < r_end) ? ls_make_key(acc[r], (u32)row) : 0ull;
-            }
-            if (cnt + 16 <= cap) {
-                ulonglong2* dst = reinterpret_cast<ulonglong2*>(myq + cnt);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) dst[r] = make_ulonglong2(kk2[2 * r], kk2[2 * r + 1]);
-            }
-            cnt += 16;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float s = acc[r];
-                if (s >= tauv) {
-                    const long long row = row0 + (r & 3) + 8 * (r >> 2);
-                    const u64 key = ls_make_key(s, (u32)row);
-                    if (qvalid && row < r_end && key != 0ull) {
-                        if (cnt < cap) myq[cnt] = key;
-                        ++cnt;
-                    }
-                }
+            const u64 key = (qvalid && row < r_end) ? ls_make_key(s, 0u) : 0ull;
+            top4_insert(top, (u32)(key >> 32));
+        } else if (s >= tauv) {
+            const u64 key = ls_make_key(s, (u32)row);
+            if (qvalid && row < r_end && key != 0ull) {
+                if (cnt < cap) myq[cnt] = key;
+                ++cnt;
             }
         }
     };
 
-    u32x4 ra[LOADS], rb[LOADS];
-    if (nt > 0) load_tile(0, ra);
-    if (nt > 1) load_tile(tile_stride, rb);
-    if (nt > 0) write_tile(0, ra);
-    if (nt > 2) load_tile(2 * tile_stride, ra);
-    __syncthreads();
-    // invariant at the top of iteration i: LDS[i&1] = tile i; tile i+1 in flight in rb (i even)
-    // or ra (i odd); tile i+2 in flight in the other set
+    // One tile = two row blocks computed in lock step on two accumulators (independent chains:
+    // consecutive MFMAs never wait on each other), with the PREVIOUS tile's two accumulators
+    // checked one element per MFMA in the shadow of the matrix pipe.
+    auto run_tile = [&](f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1, bool have_prev,
+                        long long prev_row0, int buf) {
+        half8 a0[LS_GEMM_APF], a1[LS_GEMM_APF];
+#pragma unroll
+        for (int kk = 0; kk < LS_GEMM_APF && kk < KSTEPS; ++kk) {
+            a0[kk] = a_frag(buf, 0, kk);
+            a1[kk] = a_frag(buf, 1, kk);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            if (kk == 0) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[0], bq[0], z, 0, 0, 0);
+            } else {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[kk % LS_GEMM_APF], bq[kk], c0, 0, 0, 0);
+            }
+            if (kk + LS_GEMM_APF < KSTEPS) a0[kk % LS_GEMM_APF] = a_frag(buf, 0, kk + LS_GEMM_APF);
+            if (kk < 16 && have_prev) check(p0, kk, prev_row0);
+            if (kk == 0) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[0], bq[0], z, 0, 0, 0);
+            } else {
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[kk % LS_GEMM_APF], bq[kk], c1, 0, 0, 0);
+            }
+            if (kk + LS_GEMM_APF < KSTEPS) a1[kk % LS_GEMM_APF] = a_frag(buf, 1, kk + LS_GEMM_APF);
+            if (kk < 16 && have_prev) check(p1, kk, prev_row0 + 32);
+        }
+        if (KSTEPS < 16 && have_prev) {
+#pragma unroll
+            for (int r = KSTEPS; r < 16; ++r) {
+                check(p0, r, prev_row0);
+                check(p1, r, prev_row0 + 32);
+            }
+        }
+    };
+
+    f32x16 accA0, accA1, accB0, accB1;  // (A*, B*) alternate between consecutive tiles
+    auto tile_row0 = [&](int i) { return r_begin + (long long)(i * tile_stride) * LS_GEMM_TM + 4 * half; };
+    if (nt > 0) stage(0, 0);
+    __syncthreads();  // the compiler drains the DMA (vmcnt(0)) before the barrier
     for (int i = 0; i < nt; i += 2) {
-        compute_tile(i, 0);
-        if (i + 1 < nt) write_tile(1, rb);
-        if (i + 3 < nt) load_tile((i + 3) * tile_stride, rb);
+        if (i + 1 < nt) stage((i + 1) * tile_stride, 1);
+        run_tile(accA0, accA1, accB0, accB1, i > 0, tile_row0(i - 1), 0);
         __syncthreads();
         if (i + 1 < nt) {
-            compute_tile(i + 1, 1);
-            if (i + 2 < nt) write_tile(0, ra);
-            if (i + 4 < nt) load_tile((i + 4) * tile_stride, ra);
+            if (i + 2 < nt) stage((i + 2) * tile_stride, 0);
+            run_tile(accB0, accB1, accA0, accA1, true, tile_row0(i), 1);
             __syncthreads();
         }
     }
-    counts[(long long)blockIdx.x * LS_GEMM_THREADS + tid] = (u32)(cnt < cap ? cnt : cap);
-    if (cnt > cap) overflow[qj] = 1u;
+    if (nt > 0) {  // the last tile still has to be checked
+        const long long row0 = tile_row0(nt - 1);
+        const bool last_in_b = ((nt - 1) & 1) != 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            check(last_in_b ? accB0 : accA0, r, row0);
+            check(last_in_b ? accB1 : accA1, r, row0 + 32);
+        }
+    }
+    if (SAMPLE) {
+        uint4 t4 = make_uint4(top[0], top[1], top[2], top[3]);
+        reinterpret_cast<uint4*>(sample_top)[(long long)blockIdx.x * LS_GEMM_THREADS + tid] = t4;
+    } else {
+        counts[(long long)blockIdx.x * LS_GEMM_THREADS + tid] = (u32)(cnt < cap ? cnt : cap);
+        if (cnt > cap) overflow[qj] = 1u;
+    }
 }
 
 int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, const void* d_qh,
                           int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
                           int64_t rows_per_split, int tile_stride, u64* d_queues, u32* d_counts,
-                          int cap, u32* d_overflow, hipStream_t s) {
+                          int cap, u32* d_overflow, u32* d_sample_top, hipStream_t s) {
     const int nqt = (int)(nq_pad / LS_GEMM_QT);
     const dim3 grid((unsigned)(nsplits * nqt)), block(LS_GEMM_THREADS);
     const size_t smem = (size_t)2 * LS_GEMM_TM * g.chunks * 16;
@@ -236,12 +280,12 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
             hipLaunchKernelGGL((ls_gemm_filter_kernel<C, false>), grid, block, smem, s,           \
                                (const u32x4*)d_corpus, (long long)n, (const u32x4*)d_qh, (int)nq,  \
                                nqt, d_tau, (long long)rows_per_split, tile_stride, d_queues,      \
-                               d_counts, cap, d_overflow);                                       \
+                               d_counts, cap, d_overflow, d_sample_top);                         \
         else                                                                                     \
             hipLaunchKernelGGL((ls_gemm_filter_kernel<C, true>), grid, block, smem, s,            \
                                (const u32x4*)d_corpus, (long long)n, (const u32x4*)d_qh, (int)nq,  \
                                nqt, d_tau, (long long)rows_per_split, tile_stride, d_queues,      \
-                               d_counts, cap, d_overflow);                                       \
+                               d_counts, cap, d_overflow, d_sample_top);                         \
         LS_HIP(hipGetLastError());                                                               \
         return LS_OK;                                                                            \
     }
@@ -251,13 +295,15 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
     return LS_ERR_INVALID_ARG;
 }
 
-// ---- tau: k-th best sample score of each query ----------------------------------------------------
-// One workgroup per query; the query's queue entries (<= LS_TAU_PER_THREAD per thread) stay in
-// registers; 4 radix passes over the score half. tau = -FLT_MAX when the sample holds < k scores.
-#define LS_TAU_PER_THREAD 32
-__global__ __launch_bounds__(256) void ls_tau_kernel(const u64* __restrict__ queues,
-                                                     const u32* __restrict__ counts, int cap,
-                                                     int nsplits, int nqt, int nq, int k,
+#define LS_TAU_PER_THREAD 2
+// ---- tau: j-th best sample score of each query --------------------------------------------------
+// The sample pass left, for every (workgroup, lane), the 4 best sample scores that lane saw
+// (ord() of the score, 0 = none). A query owns 2 lanes in each of its nsplits workgroups:
+// <= 2*nsplits*4 values, <= 2 per thread. 4 radix passes find the j-th largest.
+// Keeping only 4 per lane can only LOWER the result (if one lane held more than 4 of the best
+// j), i.e. let more rows through: tau is a speculative, verified threshold either way.
+__global__ __launch_bounds__(256) void ls_tau_kernel(const u32* __restrict__ sample_top, int nsplits,
+                                                     int nqt, int nq, int j_rank,
                                                      float* __restrict__ tau) {
     __shared__ u32 hist[4 * 256];
     __shared__ u32 misc[4 * 8];
@@ -267,39 +313,32 @@ __global__ __launch_bounds__(256) void ls_tau_kernel(const u64* __restrict__ que
         return;
     }
     const int qt = q / LS_GEMM_QT, w = (q % LS_GEMM_QT) / 32, l = q % 32;
-    // entry list of this query: (split, half, e) -> flattened index space nsplits * 2 * cap
-    const int total = nsplits * 2 * cap;
-    // all loads are independent and issued together: first the queue lengths, then the entries
-    u32 qc[LS_TAU_PER_THREAD];
-    u64 ent[LS_TAU_PER_THREAD];
-    u32 hi[LS_TAU_PER_THREAD];
+    const int total = nsplits * 2 * 4;  // values of this query
+    u32 v[LS_TAU_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < LS_TAU_PER_THREAD; ++j) {
         const int idx = tid + j * 256;
-        const int sh = (idx < total ? idx : 0) / cap, half = sh & 1, split = sh >> 1;
-        const int b = wg_index(split, qt, nqt);
-        const int t = w * 64 + half * 32 + l;
-        qc[j] = counts[(long long)b * LS_GEMM_THREADS + t];
-        ent[j] = queues[((long long)b * LS_GEMM_THREADS + t) * cap + (idx < total ? idx % cap : 0)];
-    }
-#pragma unroll
-    for (int j = 0; j < LS_TAU_PER_THREAD; ++j) {
-        const int idx = tid + j * 256;
-        hi[j] = (idx < total && (u32)(idx % cap) < qc[j]) ? (u32)(ent[j] >> 32) : 0u;
+        u32 x = 0;
+        if (idx < total) {
+            const int e = idx & 3, sh = idx >> 2, hf = sh & 1, split = sh >> 1;
+            const int b = wg_index(split, qt, nqt);
+            x = sample_top[((long long)b * LS_GEMM_THREADS + w * 64 + hf * 32 + l) * 4 + e];
+        }
+        v[j] = x;
     }
     for (int i = tid; i < 4 * 256; i += 256) hist[i] = 0;
     __syncthreads();
-    u32 pref = 0, pmask = 0, krem = (u32)k;
+    u32 pref = 0, pmask = 0, krem = (u32)j_rank;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
 #pragma unroll
         for (int j = 0; j < LS_TAU_PER_THREAD; ++j)
-            wave_hist_add(hist + pass * 256, (hi[j] >> shift) & 255u,
-                          hi[j] != 0u && (hi[j] & pmask) == pref, lane);
+            wave_hist_add(hist + pass * 256, (v[j] >> shift) & 255u,
+                          v[j] != 0u && (v[j] & pmask) == pref, lane);
         __syncthreads();
         find_bin(hist + pass * 256, krem, misc + pass * 8, tid);
         __syncthreads();
-        if (pass == 0 && misc[3] < (u32)k) {  // fewer than k sample scores: no usable bound
+        if (pass == 0 && misc[3] < (u32)j_rank) {  // fewer than j sample scores: no bound
             if (tid == 0) tau[q] = -FLT_MAX;
             return;
         }
@@ -310,20 +349,20 @@ __global__ __launch_bounds__(256) void ls_tau_kernel(const u64* __restrict__ que
     if (tid == 0) tau[q] = ls_unord(pref);
 }
 
-int ls_launch_tau(const u64* d_queues, const u32* d_counts, int cap, int nsplits, int64_t nq,
-                  int64_t nq_pad, int k, float* d_tau, hipStream_t s) {
-    if ((long long)nsplits * 2 * cap > 256LL * LS_TAU_PER_THREAD) {
+int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_pad, int j_rank,
+                  float* d_tau, hipStream_t s) {
+    if ((long long)nsplits * 2 * 4 > 256LL * LS_TAU_PER_THREAD) {
         ls_set_error("batched path: sample too large for the tau kernel");
         return LS_ERR_INVALID_ARG;
     }
-    hipLaunchKernelGGL(ls_tau_kernel, dim3((unsigned)nq_pad), dim3(256), 0, s, d_queues, d_counts,
-                       cap, nsplits, (int)(nq_pad / LS_GEMM_QT), (int)nq, k, d_tau);
+    hipLaunchKernelGGL(ls_tau_kernel, dim3((unsigned)nq_pad), dim3(256), 0, s, d_sample_top,
+                       nsplits, (int)(nq_pad / LS_GEMM_QT), (int)nq, j_rank, d_tau);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
 
 // ---- exact top-k of each query's queues --------------------------------------------------------------
-#define LS_BSEL_KEYS 6144
+#define LS_BSEL_KEYS 2048
 __global__ __launch_bounds__(256) void ls_batch_select_kernel(
     const u64* __restrict__ queues, const u32* __restrict__ counts, int cap, int nsplits, int nqt,
     int k, long long base, u32* __restrict__ overflow, float* __restrict__ out_scores,
@@ -338,31 +377,34 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
     const int qt = q / LS_GEMM_QT, w = (q % LS_GEMM_QT) / 32, l = q % 32;
     if (tid == 0) nkeys = 0;
     __syncthreads();
-    // walk the query's 2*nsplits queues in the flattened (queue, entry) index space: a wave
-    // reads one queue's slots as one coalesced run. Loads are unconditional and issued in
-    // batches of 8 so that the gather costs a few memory latencies, not one per queue.
-    const int total = nsplits * 2 * cap;
-    for (int i0 = 0; i0 < total; i0 += 256 * 8) {
-        u32 qc[8];
-        u64 ent[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = i0 + j * 256 + tid;
-            const int ii = idx < total ? idx : 0;
-            const int e = ii % cap, sh = ii / cap, half = sh & 1, split = sh >> 1;
-            const int b = wg_index(split, qt, nqt);
-            const int t = w * 64 + half * 32 + l;
-            qc[j] = counts[(long long)b * LS_GEMM_THREADS + t];
-            ent[j] = queues[((long long)b * LS_GEMM_THREADS + t) * cap + e];
+    // gather: thread t < 2*nsplits owns one of the query's queues: one load for its length, a
+    // block-wide prefix for its slot range in LDS, then its (few) live entries
+    __shared__ u32 wsum[8];
+    const int nqueues = nsplits * 2;
+    u32 c = 0;
+    const u64* qptr = nullptr;
+    if (tid < nqueues) {
+        const int half = tid & 1, split = tid >> 1;
+        const int b = wg_index(split, qt, nqt);
+        const int t = w * 64 + half * 32 + l;
+        c = counts[(long long)b * LS_GEMM_THREADS + t];
+        qptr = queues + ((long long)b * LS_GEMM_THREADS + t) * cap;
+    }
+    {   // exclusive prefix sum of c over the 256 threads
+        const int lane = tid & 63, wv = tid >> 6;
+        u32 inc = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t2 = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t2;
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = i0 + j * 256 + tid;
-            if (idx < total && (u32)(idx % cap) < qc[j]) {
-                const u32 pos = atomicAdd(&nkeys, 1u);
-                if (pos < LS_BSEL_KEYS) keys[pos] = ent[j];
-            }
-        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        u32 off = 0;
+        for (int i = 0; i < wv; ++i) off += wsum[i];
+        if (tid == 0) nkeys = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        const u32 start = off + inc - c;
+        for (u32 e = 0; e < c; ++e)
+            if (start + e < LS_BSEL_KEYS) keys[start + e] = qptr[e];
     }
     __syncthreads();
     const int cnt = (int)nkeys;

@@ -1,0 +1,152 @@
+// Microbenchmark: cost per v_mfma_f32_32x32x16_f16 for different issue patterns (gfx950).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cstdlib>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define MF(a,b,c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a,b,c,0,0,0)
+
+template <int PAT>
+__global__ __launch_bounds__(512, 2) void k(const u32x4* g, float* out, int iters, float tau) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[32768];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 2048; i += 512) ((u32x4*)lds)[i] = g[i];
+    __syncthreads();
+    half8 b[8];
+    for (int i = 0; i < 8; ++i) b[i] = __builtin_bit_cast(half8, g[tid + i * 512]);
+    f32x16 A = {0}, B = {0}, C = {0}, D = {0};
+    const unsigned char* p = lds + lane * 16;
+    int cnt = 0;
+    for (int it = 0; it < iters; ++it) {
+        if (PAT == 0) {  // one accumulator, pure chain, operands preloaded
+            half8 a = __builtin_bit_cast(half8, *(const u32x4*)(p));
+#pragma unroll
+            for (int kk = 0; kk < 24; ++kk) A = MF(a, b[kk & 7], A);
+        } else if (PAT == 1) {  // one accumulator, ds_read between
+            half8 a = __builtin_bit_cast(half8, *(const u32x4*)(p));
+#pragma unroll
+            for (int kk = 0; kk < 24; ++kk) {
+                half8 an = __builtin_bit_cast(half8, *(const u32x4*)(p + ((kk + 1) & 15) * 1024));
+                A = MF(a, b[kk & 7], A);
+                a = an;
+            }
+        } else if (PAT == 2) {  // two accumulators alternating, pure
+            half8 a = __builtin_bit_cast(half8, *(const u32x4*)(p));
+#pragma unroll
+            for (int kk = 0; kk < 12; ++kk) { A = MF(a, b[kk & 7], A); B = MF(a, b[(kk + 1) & 7], B); }
+        } else if (PAT == 3) {  // two accumulators, one ds_read per MFMA
+            half8 a0 = __builtin_bit_cast(half8, *(const u32x4*)(p));
+            half8 a1 = __builtin_bit_cast(half8, *(const u32x4*)(p + 1024));
+#pragma unroll
+            for (int kk = 0; kk < 12; ++kk) {
+                half8 n0 = __builtin_bit_cast(half8, *(const u32x4*)(p + ((2 * kk + 2) & 15) * 1024));
+                A = MF(a0, b[kk & 7], A);
+                half8 n1 = __builtin_bit_cast(half8, *(const u32x4*)(p + ((2 * kk + 3) & 15) * 1024));
+                B = MF(a1, b[kk & 7], B);
+                a0 = n0; a1 = n1;
+            }
+        } else if (PAT == 4) {  // four accumulators, one ds_read per MFMA
+            half8 a0 = __builtin_bit_cast(half8, *(const u32x4*)(p));
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) {
+                half8 n0 = __builtin_bit_cast(half8, *(const u32x4*)(p + ((4 * kk + 1) & 15) * 1024));
+                A = MF(a0, b[kk & 7], A);
+                half8 n1 = __builtin_bit_cast(half8, *(const u32x4*)(p + ((4 * kk + 2) & 15) * 1024));
+                B = MF(n0, b[kk & 7], B);
+                half8 n2 = __builtin_bit_cast(half8, *(const u32x4*)(p + ((4 * kk + 3) & 15) * 1024));
+                C = MF(n1, b[kk & 7], C);
+                half8 n3 = __builtin_bit_cast(half8, *(const u32x4*)(p + ((4 * kk + 4) & 15) * 1024));
+                D = MF(n2, b[kk & 7], D);
+                a0 = n3;
+            }
+        } else if (PAT == 5) {  // two accumulators, ds_read + compare/branch (epilogue-like) per MFMA
+            half8 a0 = __builtin_bit_cast(half8, *(const u32x4*)(p));
+            half8 a1 = __builtin_bit_cast(half8, *(const u32x4*)(p + 1024));
+#pragma unroll
+            for (int kk = 0; kk < 12; ++kk) {
+                half8 n0 = __builtin_bit_cast(half8, *(const u32x4*)(p + ((2 * kk + 2) & 15) * 1024));
+                A = MF(a0, b[kk & 7], A);
+                if (C[kk] >= tau) { out[cnt & 1023] = C[kk]; ++cnt; }
+                half8 n1 = __builtin_bit_cast(half8, *(const u32x4*)(p + ((2 * kk + 3) & 15) * 1024));
+                B = MF(a1, b[kk & 7], B);
+                if (D[kk] >= tau) { out[cnt & 1023] = D[kk]; ++cnt; }
+                a0 = n0; a1 = n1;
+            }
+            C = A; D = B;
+        } else if (PAT == 6) {  // one accumulator, pure chain of 24, then 24 ds_reads + 16 checks
+            half8 a[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) a[j] = __builtin_bit_cast(half8, *(const u32x4*)(p + j * 1024));
+#pragma unroll
+            for (int kk = 0; kk < 24; ++kk) A = MF(a[kk % 6], b[kk & 7], A);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (A[r] >= tau) { out[cnt & 1023] = A[r]; ++cnt; }
+        }
+        else if (PAT == 7 || PAT == 8 || PAT == 9) {
+            // v3 structure: per block a 24-long chain on one accumulator, A fragments 6 ahead,
+            // one check of the PREVIOUS block's accumulator per k-step
+            f32x16& cur = (it & 1) ? B : A;
+            const f32x16& prev = (it & 1) ? A : B;
+            half8 a[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) a[j] = __builtin_bit_cast(half8, *(const u32x4*)(p + j * 1024));
+#pragma unroll
+            for (int kk = 0; kk < 24; ++kk) {
+                cur = MF(a[kk % 6], b[kk & 7], cur);
+                if (kk + 6 < 24) a[kk % 6] = __builtin_bit_cast(half8, *(const u32x4*)(p + ((kk + 6) & 15) * 1024));
+                if (kk < 16 && PAT != 9) { if (prev[kk] >= tau) { out[cnt & 1023] = prev[kk]; ++cnt; } }
+            }
+            if (PAT == 8 && (it & 1)) {  // staging every 2 blocks: 6 loads, 6 LDS writes, barrier
+                u32x4 r[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) r[j] = g[(it & 63) * 3072 + j * 512 + tid];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) *(u32x4*)(lds + ((j * 512 + tid) & 2047) * 16) = r[j];
+                __syncthreads();
+            }
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += A[i] + B[i] + C[i] + D[i];
+    if (s == 12345.f || cnt == 777) out[tid] = s;
+}
+
+template <int PAT> void run(const u32x4* g, float* o, const char* name) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 2000;
+    k<PAT><<<256, 512>>>(g, o, 10, 1e30f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k<PAT><<<256, 512>>>(g, o, iters, 1e30f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double mf = 24.0 * iters;                       // MFMAs per wave
+    double per_simd = mf * 2;                       // 2 waves per SIMD
+    printf("%-44s %8.1f us   %.1f ns per MFMA per SIMD  (%.0f TFLOP/s)\n", name, ms * 1e3,
+           ms * 1e6 / per_simd, 256.0 * 8 * mf * 32768 / (ms * 1e-3) / 1e12);
+}
+int main() {
+    u32x4* g; float* o;
+    hipMalloc(&g, 8 << 20); hipMalloc(&o, 1 << 20);
+    std::vector<unsigned short> h(4 << 20);
+    unsigned x = 12345;
+    for (auto& v : h) {  // random fp16 in roughly [-0.1, 0.1] (sign + small exponent + mantissa)
+        x = x * 1664525u + 1013904223u;
+        v = (unsigned short)(((x >> 16) & 0x8000) | (0x2800 + ((x >> 8) & 0x07ff)));
+    }
+    if (getenv("UB_CONST")) for (auto& v : h) v = 0x3c00;
+    hipMemcpy(g, h.data(), 8 << 20, hipMemcpyHostToDevice);
+    run<0>(g, o, "P0 1 acc, pure dependent chain");
+    run<1>(g, o, "P1 1 acc, ds_read between");
+    run<2>(g, o, "P2 2 acc alternating, pure");
+    run<3>(g, o, "P3 2 acc, ds_read per MFMA");
+    run<4>(g, o, "P4 4 acc, ds_read per MFMA");
+    run<5>(g, o, "P5 2 acc, ds_read + cmp/branch per MFMA");
+    run<6>(g, o, "P6 1 acc pure chain(6 frags), then 16 checks");
+    run<9>(g, o, "P9 v3 chain + 6-ahead ds_reads, no checks");
+    run<7>(g, o, "P7 v3 chain + ds_reads + interleaved prev checks");
+    run<8>(g, o, "P8 P7 + staging (6 ld, 6 ds_write, barrier)/2 blk");
+    return 0;
+}

@@ -129,9 +129,10 @@ def main():
     index = ShardedFlatIPIndex(local, n)
     tq = torch.from_numpy(queries).to(dev)
 
-    # nq <= 16 is the per-query HBM-bound scan path: consecutive steps are pipelined on the
-    # index's two internal lanes (LS_FLAG_PIPELINE), exactly how a server keeps two single
-    # queries in flight; results are validated by local.check() at the end of the region.
+    # nq <= 16 is the per-query HBM-bound scan path: consecutive steps are pipelined
+    # (LS_FLAG_PIPELINE: launch i = scan of step i + one workgroup finalising step i-1, all on
+    # one stream); the last finalize is flushed and everything validated by local.check() inside
+    # the timed region.
     pipelined = world == 1 and nq <= 16
     out_ring = [(torch.empty((nq, k), dtype=torch.float32, device=dev),
                  torch.empty((nq, k), dtype=torch.int64, device=dev)) for _ in range(4)]
@@ -244,9 +245,11 @@ def main():
             "data": "synthetic (standard-normal rows, L2-normalised; corpus seed 1234, query seed 5678)",
             "config": {"workload": f"{args.workload}: N={n} d={d} {dtype} nq={nq} k={k}",
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
-                       "launches_per_step": 1,
+                       "launches_per_step": (1 if pipelined else
+                                             (5 if nq > 16 and dtype == "f16" else 2 * nq)
+                                             + (2 if world > 1 else 0)),
                        "note": "each launch = scan(step i) + one workgroup finalising step i-1"
-                       if pipelined else ("prep, sample pass, tau, MFMA pass, select per batch"
+                       if pipelined else ("prep, sample pass, tau, MFMA pass + select per batch"
                                           if nq > 16 and dtype == "f16" else
                                           "scan + select launches per query")},
             "effective_gbs": round(algorithmic_bytes(n_local, d, elem, nq, k) * args.steps / dt / 1e9, 1),

@@ -75,8 +75,12 @@ class ShardedFlatIPIndex:
 
     # ------------------------------------------------------------------ HIP defaults
     def _hip_local_search(self, q, k, normalize, out_scores=None, out_indices=None):
+        # The per-query scan path is exact in stream order, so it can stay asynchronous. The
+        # batched MFMA path may flag queries for repair (ls_check): the local result must be
+        # final BEFORE it is exchanged, so larger batches run synchronously (sync + repair).
+        asynchronous = q.shape[0] <= 16 or self.local.storage_dtype != "f16"
         return self.local.search_device(q, k, out_scores, out_indices, normalize=normalize,
-                                        asynchronous=True)
+                                        asynchronous=asynchronous)
 
     def _hip_merge(self, all_scores, all_rows, k, list_stride_bytes=None):
         import torch

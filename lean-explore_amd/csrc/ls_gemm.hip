@@ -14,7 +14,7 @@
 //     address (chunk ^ (row & 15)) so the ds_read_b128 fragment reads are bank-conflict free.
 //   - the two 32-row blocks of a tile run in lock step on two accumulators (independent MFMA
 //     chains) while the previous tile's two accumulators are filtered one element per MFMA, in
-//     the shadow of the matrix pipe (a microbenchmark of this pattern: scratch/ub/mfma_ub.hip).
+//     the shadow of the matrix pipe (a microbenchmark of this pattern: tools/mfma_ub.hip).
 //   - v_mfma_f32_32x32x16_f16: D[row, query] accumulates in fp32; fp16 x fp16 products are exact.
 //   - epilogue: lane (query j, half h) holds 16 row scores of ONE query. A score >= tau[j]
 //     (tau = k-th best of a row sample, a certified lower bound of the final k-th best) is

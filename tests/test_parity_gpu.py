@@ -328,3 +328,68 @@ def test_pipelined_calls_piggyback_finalize():
     _, _, S = oracle.np_search(c, qs[5:6], 20)
     oracle.compare_topk(d2, i2, Dr, Ir, S)
     ix.close()
+
+
+def test_concurrent_searches_on_one_handle():
+    """SURVEY §8(b) threading: ls_search is safe to call concurrently on one handle."""
+    import threading
+
+    c = H.gauss(51, 40_000, 384)
+    qs = H.gauss(52, 32, 384)
+    ix = FlatIPIndex.from_array(c)
+    want = [oracle.c_search(c, qs[i:i + 1], 25) for i in range(32)]
+    got = [None] * 32
+    errs = []
+
+    def worker(lo, hi):
+        try:
+            for i in range(lo, hi):
+                got[i] = ix.search(qs[i:i + 1], 25)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    threads = [threading.Thread(target=worker, args=(j * 8, j * 8 + 8)) for j in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs
+    _, _, S = oracle.np_search(c, qs, 25)
+    for i in range(32):
+        oracle.compare_topk(got[i][0], got[i][1], want[i][0], want[i][1], S[i:i + 1])
+    ix.close()
+
+
+def test_error_codes_and_messages():
+    import ctypes
+
+    lib = native.load()
+    h = ctypes.c_void_p()
+    x = np.zeros((4, 8), np.float32)
+    assert lib.ls_create(ctypes.byref(h), x.ctypes.data, 4, 8, 7, 0) == native.LS_ERR_INVALID_ARG
+    assert b"unsupported" in lib.ls_last_error()
+    assert lib.ls_create(ctypes.byref(h), x.ctypes.data, 4, 8, 0, 99) == native.LS_ERR_NO_DEVICE
+    assert lib.ls_create(ctypes.byref(h), None, 4, 8, 0, 0) == native.LS_ERR_INVALID_ARG
+    assert lib.ls_create(ctypes.byref(h), x.ctypes.data, 4, 5000, 0, 0) == native.LS_ERR_INVALID_ARG
+    assert lib.ls_create(ctypes.byref(h), x.ctypes.data, 4, 8, 0, 0) == native.LS_OK
+    D = np.zeros((1, 2), np.float32)
+    I = np.zeros((1, 2), np.int64)
+    assert lib.ls_search(h, x.ctypes.data, 1, 0, 0, D.ctypes.data, I.ctypes.data) == native.LS_ERR_INVALID_ARG
+    assert lib.ls_search(h, x.ctypes.data, 1, 2, 64, D.ctypes.data, I.ctypes.data) == native.LS_ERR_INVALID_ARG
+    assert lib.ls_search(h, None, 1, 2, 0, D.ctypes.data, I.ctypes.data) == native.LS_ERR_INVALID_ARG
+    assert lib.ls_search(h, x.ctypes.data, 1, 2, 0, D.ctypes.data, I.ctypes.data) == native.LS_OK
+    assert lib.ls_ntotal(h) == 4 and lib.ls_dim(h) == 8 and lib.ls_dtype(h) == 0
+    assert lib.ls_set_base(h, -1) == native.LS_ERR_INVALID_ARG
+    lib.ls_destroy(h)
+    lib.ls_destroy(None)  # harmless
+    with pytest.raises(ValueError):
+        FlatIPIndex.from_array(np.zeros((3, 4), np.float32)).search(np.zeros((1, 5), np.float32), 1)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_multi_query_ordered_batch_uses_piggyback(dtype):
+    """nq in 2..16 stays on the scan path: launch i carries the finalize of query i-1."""
+    c = H.gauss(61, 70_000, 768)
+    q = H.gauss(62, 16, 768)
+    for nq in (2, 3, 16):
+        check(c, q[:nq], 100, dtype=dtype)

@@ -483,23 +483,30 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
                                     hipStream_t s) {
     int rc = flush_pending(ix);
     if (rc != LS_OK) return rc;
-    const int64_t nq_pad0 = (nq + LS_GEMM_QT - 1) / LS_GEMM_QT * LS_GEMM_QT;
+    const int QG = ls_gemm_qg(ix->g);
+    const int QT = 128 * QG;              // queries per workgroup
+    const int TM = ls_gemm_tile_rows(ix->g);
+    const int64_t nq_pad0 = (nq + QT - 1) / QT * QT;
     if ((int)ix->bc_pending.size() >= LS_BC_SLOTS ||
         (!ix->bc_pending.empty() && nq_pad0 > ix->bc_slot_stride)) {
         rc = batched_repair(ix);  // flag slots exhausted (or too small): check what is pending
         if (rc != LS_OK) return rc;
     }
     const ls_geom& g = ix->g;
-    const int64_t nq_pad = (nq + LS_GEMM_QT - 1) / LS_GEMM_QT * LS_GEMM_QT;
-    const int nqt = (int)(nq_pad / LS_GEMM_QT);
+    const int64_t nq_pad = nq_pad0;
+    const int nqt = (int)(nq_pad / QT);
     // corpus slices: one 8-wave workgroup per CU in total, a multiple of the 8 XCDs
     int nsplits = (ix->n_cu / nqt) / 8 * 8;
     nsplits = std::max(8, std::min(nsplits, LS_GEMM_MAX_SPLITS));
     int64_t rps = (ix->n + nsplits - 1) / nsplits;
-    rps = (rps + LS_GEMM_TM - 1) / LS_GEMM_TM * LS_GEMM_TM;
-    const int tiles_per_split = (int)(rps / LS_GEMM_TM);
-    const int sample_stride = std::max(1, (tiles_per_split + LS_GEMM_SAMPLE_TILES - 1) /
-                                              LS_GEMM_SAMPLE_TILES);
+    rps = (rps + TM - 1) / TM * TM;
+    const int tiles_per_split = (int)(rps / TM);
+    // the sample is a fixed FRACTION of the corpus (~1/24 of every slice, at least
+    // LS_GEMM_SAMPLE_ROWS rows): the expected number of rows passing tau, ~j*N/M0, then does
+    // not grow with N
+    const int sample_tiles = std::max(std::max(1, LS_GEMM_SAMPLE_ROWS / TM),
+                                      (tiles_per_split + 23) / 24);
+    const int sample_stride = std::max(1, (tiles_per_split + sample_tiles - 1) / sample_tiles);
     const int cap = LS_GEMM_QCAP;
     const size_t nwg = (size_t)nsplits * nqt;
 
@@ -507,8 +514,9 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     c = ix->qh_cap;
     if ((rc = grow((unsigned char**)&ix->d_qh, &c, (size_t)nq_pad * g.d_pad * 2)) != LS_OK) return rc;
     ix->qh_cap = c;
-    if ((rc = grow(&ix->d_queues, &ix->queues_cap, nwg * LS_GEMM_THREADS * cap)) != LS_OK) return rc;
-    if ((rc = grow(&ix->d_counts, &ix->counts_cap, nwg * LS_GEMM_THREADS)) != LS_OK) return rc;
+    if ((rc = grow(&ix->d_queues, &ix->queues_cap, nwg * LS_GEMM_THREADS * QG * cap)) != LS_OK)
+        return rc;
+    if ((rc = grow(&ix->d_counts, &ix->counts_cap, nwg * LS_GEMM_THREADS * QG)) != LS_OK) return rc;
     if ((rc = grow(&ix->d_tau, &ix->tau_cap, (size_t)nq_pad)) != LS_OK) return rc;
     if (ix->bc_pending.empty() && nq_pad > ix->bc_slot_stride) ix->bc_slot_stride = nq_pad;
     if ((rc = grow(&ix->d_overflow, &ix->overflow_cap,
@@ -516,7 +524,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         return rc;
     const int slot = (int)ix->bc_pending.size();
     u32* d_flags = ix->d_overflow + (size_t)slot * ix->bc_slot_stride;
-    if ((rc = grow(&ix->d_sample_top, &ix->sample_top_cap, nwg * LS_GEMM_THREADS * 4)) != LS_OK)
+    if ((rc = grow(&ix->d_sample_top, &ix->sample_top_cap, nwg * LS_GEMM_THREADS * QG * 4)) != LS_OK)
         return rc;
     if ((rc = grow_pinned(&ix->h_overflow, &ix->h_overflow_cap,
                           (size_t)ix->bc_slot_stride * LS_BC_SLOTS)) != LS_OK)
@@ -535,7 +543,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     rc = ls_launch_prep_f16(d_q, ix->d_qh, nq, nq_pad, g, (flags & LS_FLAG_NORMALIZE) != 0,
                             d_flags, s);
     if (rc != LS_OK) return rc;
-    // sample pass: tau[q] = k-th best score over ~LS_GEMM_SAMPLE_TILES tiles of every slice
+    // sample pass: LS_GEMM_SAMPLE_ROWS rows of every slice, spread over the slice
     rc = ls_launch_gemm_filter(ix->d_corpus, ix->n, g, ix->d_qh, nq, nq_pad, nullptr, nsplits, rps,
                                sample_stride, ix->d_queues, ix->d_counts, cap, d_flags,
                                ix->d_sample_top, s);
@@ -549,7 +557,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     int jrank = k;
     if (ix->opt_spec_tau) {
         const int visited = (tiles_per_split + sample_stride - 1) / sample_stride;
-        const double m0 = (double)nsplits * visited * LS_GEMM_TM;
+        const double m0 = (double)nsplits * visited * TM;
         const double r = (double)ix->n / std::max(1.0, m0);
         for (int j = 1; j <= k; ++j) {
             if ((double)j * r * (1.0 - 4.5 / __builtin_sqrt((double)j)) >= (double)k) {
@@ -559,7 +567,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         }
     }
     static const bool abl_nopass = getenv("LS_GEMM_ABL_NOPASS") != nullptr;  // timing ablation only
-    rc = ls_launch_tau(ix->d_sample_top, nsplits, nq, nq_pad, jrank, ix->d_tau, s);
+    rc = ls_launch_tau(ix->d_sample_top, nsplits, nq, nq_pad, g, jrank, ix->d_tau, s);
     if (abl_nopass)  // every tau = FLT_MAX: the epilogue never appends (results are garbage)
         LS_HIP(hipMemsetD32Async((hipDeviceptr_t)ix->d_tau, 0x7f7fffff, (size_t)nq_pad, s));
     if (rc != LS_OK) return rc;
@@ -574,7 +582,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         ix->prof_n++;
     }
     if (abl_nopass) return LS_OK;
-    rc = ls_launch_batch_select(ix->d_queues, ix->d_counts, cap, nsplits, nq, nq_pad, k, ix->base,
+    rc = ls_launch_batch_select(ix->d_queues, ix->d_counts, cap, nsplits, nq, nq_pad, g, k, ix->base,
                                 d_flags, d_out_s, d_out_i, s);
     if (rc != LS_OK) return rc;
     ls_index::batched_call bc;

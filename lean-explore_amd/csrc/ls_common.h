@@ -26,16 +26,13 @@ typedef unsigned int u32;
 #define LS_FINAL_THREADS 1024
 #define LS_FINAL_CAP 8192            // keys the finalize workgroup sorts in LDS (64 KiB)
 #define LS_SCAN_MAX_NQ 16            // nq <= this: per-query HBM-bound scan path
-#define LS_GEMM_THREADS 512          // batched path: 8 waves x 32 queries per workgroup
-#define LS_GEMM_QT 256               // queries per workgroup
-#define LS_GEMM_TM 64                // corpus rows per LDS tile (two MFMA row blocks)
-#define LS_GEMM_APF 3                 // A fragments (per row block) in flight ahead of the MFMA
+#define LS_GEMM_THREADS 512          // batched path: 8 waves per workgroup
 #define LS_GEMM_MAX_K 128            // batched path handles k <= this (larger k: scan path)
-#define LS_GEMM_MAX_CHUNKS 64        // ... and stored rows <= 1 KiB (d <= 512 fp16)
+#define LS_GEMM_MAX_CHUNKS 128       // ... and stored rows <= 2 KiB (d <= 1024 fp16)
 #define LS_GEMM_MIN_ROWS 32768       // ... and shards at least this big
-#define LS_GEMM_QCAP 64              // entries per private candidate queue
-#define LS_GEMM_SAMPLE_TILES 2       // sample pass: 64-row tiles per workgroup
-#define LS_GEMM_MAX_SPLITS 64        // corpus slices (tau kernel reads <= 8192 sample scores)
+#define LS_GEMM_QCAP 32              // entries per private candidate queue
+#define LS_GEMM_SAMPLE_ROWS 128      // sample pass: rows per workgroup
+#define LS_GEMM_MAX_SPLITS 64        // corpus slices (the select kernel walks 4 queues per slice)
 
 __host__ __device__ __forceinline__ u32 ls_ord(float f) {
     f = f + 0.0f;  // folds -0.0 into +0.0
@@ -124,11 +121,14 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
                           int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
                           int64_t rows_per_split, int tile_stride, u64* d_queues, u32* d_counts,
                           int cap, u32* d_overflow, u32* d_sample_top, hipStream_t s);
-int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_pad, int j_rank,
-                  float* d_tau, hipStream_t s);
+int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_pad, const ls_geom& g,
+                  int j_rank, float* d_tau, hipStream_t s);
+int ls_gemm_qg(const ls_geom& g);         // query groups of 16 per wave (2, or 1 for long rows)
+int ls_gemm_tile_rows(const ls_geom& g);  // corpus rows per LDS tile (64, or 32 for long rows)
 int ls_launch_batch_select(const u64* d_queues, const u32* d_counts, int cap, int nsplits,
-                           int64_t nq, int64_t nq_pad, int k, int64_t base, u32* d_overflow,
-                           float* d_out_scores, int64_t* d_out_indices, hipStream_t s);
+                           int64_t nq, int64_t nq_pad, const ls_geom& g, int k, int64_t base,
+                           u32* d_overflow, float* d_out_scores, int64_t* d_out_indices,
+                           hipStream_t s);
 // merge of per-shard lists
 int ls_launch_merge(const float* d_scores_in, const int64_t* d_indices_in, int64_t stride_s_bytes,
                     int64_t stride_i_bytes, int32_t n_lists, int64_t nq, int32_t k,

@@ -239,7 +239,10 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-static constexpr int scan_unroll(int V) { return (V >= 3) ? 4 : 8; }  // >= 8 loads in flight
+#ifndef LS_UNROLL_V3
+#define LS_UNROLL_V3 4
+#endif
+static constexpr int scan_unroll(int V) { return (V >= 3) ? LS_UNROLL_V3 : 8; }  // >= 8 loads in flight
 
 int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu) {
     static int bpc = -1;

@@ -70,7 +70,8 @@ def test_batched_integer_corpus_bit_exact():
     ix.close()
 
 
-@pytest.mark.parametrize("nq,k,d", [(17, 1, 384), (130, 50, 256), (300, 128, 512), (129, 10, 100)])
+@pytest.mark.parametrize("nq,k,d", [(17, 1, 384), (130, 50, 256), (300, 128, 512), (129, 10, 100),
+                                    (256, 100, 768), (140, 64, 1024), (40, 20, 600)])
 def test_batched_shapes(nq, k, d):
     c = H.gauss(11, 40_000, d)
     q = H.gauss(12, nq, d)
@@ -108,3 +109,39 @@ def test_batched_device_api_async_check():
     _, _, S = oracle.np_search(c, q, 100, f16=True)
     oracle.compare_topk(s.cpu().numpy(), i.cpu().numpy(), Dr, Ir, S)
     ix.close()
+
+
+def test_config4_shape_reduced():
+    """BASELINE config 4's per-GPU shape, reduced in N: d=768 fp16, nq=256, k=100, sharded
+    3 ways on one GPU with global row offsets, merged with the HIP merge kernel."""
+    import torch
+
+    from lean_explore_amd import native
+
+    n, d, nq, k = 150_000, 768, 256, 100
+    c = H.gauss(1234, n, d)
+    q = H.gauss(5678, nq, d)
+    Dref, Iref = oracle.c_search(c, q, k, f16=True)
+    _, _, S = oracle.np_search(c, q, k, f16=True)
+    dev = torch.device("cuda:0")
+    tq = torch.from_numpy(q).to(dev)
+    outs_s, outs_i = [], []
+    for r in range(3):
+        lo, hi = r * 50_000, (r + 1) * 50_000
+        ix = FlatIPIndex.from_array(c[lo:hi], dtype="f16", base=lo)
+        s_, i_ = ix.search_device(tq, k)  # synchronous: repaired before the exchange
+        outs_s.append(s_)
+        outs_i.append(i_)
+        assert ix.debug_counter(8) == 0
+        ix.close()
+    So = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    Io = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    S_in = torch.stack(outs_s).contiguous()  # keep alive until the kernel has run
+    I_in = torch.stack(outs_i).contiguous()
+    native.check(native.load().ls_merge_topk(S_in.data_ptr(), I_in.data_ptr(), 3, nq, k,
+                                             So.data_ptr(), Io.data_ptr(), 0,
+                                             torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    rep = oracle.compare_topk(So.cpu().numpy(), Io.cpu().numpy(), Dref, Iref, S)
+    assert rep["recall"] == 1.0
+    print("config4-reduced", rep)

@@ -78,9 +78,12 @@ struct ls_index {
     int32_t opt_gemm = 1;             // allow the batched MFMA path
     int32_t opt_spec_tau = 1;         // speculative (verified) sample threshold
 
-    bool has_pending = false;          // a query whose finalize has not been launched yet
-    ls_fin_params pending{};
+    int n_pending = 0;                 // queries whose finalize has not been launched yet
+    ls_fin_batch pending{};
     hipStream_t pending_stream = nullptr;
+    float* d_qpad = nullptr; size_t qpad_cap = 0;  // padded query group (ragged last group)
+    long long s_stride = 0;            // floats between the score vectors of one generation
+    int32_t opt_multi_query = 1;       // several queries per corpus pass (groups of 8 / 4)
     int32_t max_blocks = 0;
     float* d_out_s = nullptr;  int64_t* d_out_i = nullptr;  size_t out_cap = 0;  // nq*k
     u32* d_counters = nullptr;                        // [0] finalize slow-path count
@@ -190,10 +193,12 @@ static int alloc_index_buffers(ls_index* ix) {
     }
     LS_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
     ix->max_blocks = ls_scan_blocks(ix->n > 0 ? ix->n : 1, ix->g, ix->n_cu);
-    for (auto& st : ix->sets) {
-        LS_HIP(hipMalloc((void**)&st.d_S, sizeof(float) * (size_t)(ix->n > 0 ? ix->n : 1)));
-        LS_HIP(hipMalloc((void**)&st.d_cand, sizeof(u64) * (size_t)ix->max_blocks * LS_KP_MAX));
-        LS_HIP(hipMalloc((void**)&st.d_bound, sizeof(u64) * (size_t)ix->max_blocks));
+    ix->s_stride = ((ix->n > 0 ? ix->n : 1) + 63) / 64 * 64;
+    for (auto& st : ix->sets) {  // room for LS_SCAN_NQ_MAX queries per generation
+        LS_HIP(hipMalloc((void**)&st.d_S, sizeof(float) * (size_t)ix->s_stride * LS_SCAN_NQ_MAX));
+        LS_HIP(hipMalloc((void**)&st.d_cand,
+                         sizeof(u64) * (size_t)ix->max_blocks * LS_KP_MAX * LS_SCAN_NQ_MAX));
+        LS_HIP(hipMalloc((void**)&st.d_bound, sizeof(u64) * (size_t)ix->max_blocks * LS_SCAN_NQ_MAX));
 
     }
 
@@ -221,6 +226,7 @@ void ls_destroy(ls_index* ix) {
     (void)hipFree(ix->d_out_s);
     (void)hipFree(ix->d_out_i);
     (void)hipFree(ix->d_counters);
+    (void)hipFree(ix->d_qpad);
     (void)hipFree(ix->d_qh);
     (void)hipFree(ix->d_queues);
     (void)hipFree(ix->d_counts);
@@ -351,16 +357,19 @@ static size_t ls_fin_lds_bytes_host(int keys_cap, int keff) {
     return ((size_t)keys_cap + (size_t)rc + 256 + 16) * sizeof(u64) + (8 * 256 + 64) * sizeof(u32);
 }
 
-// Launch the pending finalize on its own (1024 threads, LDS for the full 8192-key capacity).
+// Launch the pending selection jobs on their own (1024 threads each, LDS for the full
+// 8192-key capacity).
 static int flush_pending(ls_index* ix) {
-    if (!ix->has_pending) return LS_OK;
-    ls_fin_params p = ix->pending;
-    p.keys_cap = LS_FINAL_CAP;
-    ix->has_pending = false;
-    return ls_launch_finalize(p, ix->pending_stream);
+    const int np = ix->n_pending;
+    if (np == 0) return LS_OK;
+    ix->n_pending = 0;
+    ls_fin_batch jobs = ix->pending;
+    for (int i = 0; i < np; ++i) jobs.p[i].keys_cap = LS_FINAL_CAP;
+    return ls_launch_finalize(jobs, np, ix->pending_stream);  // one launch, one workgroup per job
 }
 
-// Queue one search on stream `s`. d_q: device fp32 [nq, d]; outputs device [nq, k].
+// Queue one search on stream `s` through the scan path. d_q: device fp32 [nq, d]; outputs
+// device [nq, k].
 static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
                             float* d_out_s, int64_t* d_out_i, hipStream_t s) {
     const ls_geom& g = ix->g;
@@ -369,21 +378,26 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
     const int64_t keff = std::min<int64_t>(k, ix->n);
     const int blocks = ls_scan_blocks(ix->n > 0 ? ix->n : 1, g, ix->n_cu);
     const int kprime = pick_kprime(ix, blocks, (int)std::max<int64_t>(keff, 1));
-    // Everything is queued on the caller's stream, one launch per query:
-    //     launch i = { scan(query i)  +  one extra workgroup: finalize(query i-1) }
+    // Everything is queued on the caller's stream. Queries go out in groups of 8, 4 or 1 that
+    // share one pass over the corpus:
+    //     launch i = { scan(group i)  +  one extra workgroup per query of group i-1: finalize }
     // so the selection step costs neither a launch nor a kernel boundary and hides under the
-    // next scan. Two scratch sets alternate (finalize(i-1) reads set A while scan(i) fills B).
-    // The last query's finalize is "pending": it rides on the next call's first scan
-    // (LS_FLAG_PIPELINE), or is launched on its own right away (ordered modes).
+    // next scan. Two scratch generations alternate (group i-1's finalize reads generation A
+    // while group i's scan fills B). The last group's finalizes are "pending": they ride on the
+    // next call's first scan (LS_FLAG_PIPELINE) or are launched on their own right away.
     const bool pipeline = (flags & LS_FLAG_PIPELINE) != 0;
-    if (ix->has_pending && (ix->pending_stream != s || !ix->opt_overlap)) {
+    if (ix->n_pending && (ix->pending_stream != s || !ix->opt_overlap)) {
         hipStream_t old = ix->pending_stream;
         rc = flush_pending(ix);
         if (rc != LS_OK) return rc;
         // a different stream takes over: do not let its scans race the old stream's finalize
         if (old != s) LS_HIP(hipStreamSynchronize(old));
     }
-    for (int64_t qi = 0; qi < nq; ++qi) {
+    for (int64_t q0 = 0; q0 < nq;) {
+        const int64_t left = nq - q0;
+        // queries per launch: 8 or 4 with the last real query repeated as padding, or 1
+        const int NQ = !ix->opt_multi_query ? 1 : (left >= 5 ? 8 : (left >= 2 ? 4 : 1));
+        const int real = (int)std::min<int64_t>(NQ, left);
         const bool prof = ix->profiling && ix->prof_n < LS_PROF_MAX;
         hipEvent_t* pe = nullptr;
         if (prof) {
@@ -394,49 +408,74 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             }
             pe = &ix->prof_ev[2 * ix->prof_n];
         }
-        const int si = (int)(ix->set_rr++ % LS_NSETS);
-        ls_index::scratch_set& st = ix->sets[si];
-        // the pending job reads the OTHER set (sets alternate), never the one scanned now
-        const ls_fin_params* fin = nullptr;
-        if (ix->has_pending && ix->n <= 0) {  // an empty index launches no scan to ride on
+        const int gen = (int)(ix->set_rr++ % LS_NSETS);
+        ls_index::scratch_set& st = ix->sets[gen];
+        if (ix->n_pending && ix->n <= 0) {  // an empty index launches no scan to ride on
             rc = flush_pending(ix);
             if (rc != LS_OK) return rc;
         }
-        if (ix->has_pending) {
-            const int keff_p = (int)std::min<int64_t>(ix->pending.k, ix->n);
-            if (ls_fin_lds_bytes_host(ix->pending.keys_cap, keff_p) <= LS_PIGGY_LDS_MAX) {
-                fin = &ix->pending;
+        ls_scan_args a{};
+        a.nfin = 0;
+        if (ix->n_pending) {
+            const int keff_p = (int)std::min<int64_t>(ix->pending.p[0].k, ix->n);
+            if (ls_fin_lds_bytes_host(ix->pending.p[0].keys_cap, keff_p) <= LS_PIGGY_LDS_MAX) {
+                a.nfin = ix->n_pending;
+                a.fin = ix->pending;
             } else {
                 rc = flush_pending(ix);
                 if (rc != LS_OK) return rc;
             }
         }
+        // padded query slots re-read the last real query (their results are never finalised)
+        const float* qsrc = d_q + q0 * g.d;
+        if (real < NQ) {
+            rc = grow(&ix->d_qpad, &ix->qpad_cap, (size_t)LS_SCAN_NQ_MAX * g.d);
+            if (rc != LS_OK) return rc;
+            for (int i = 0; i < NQ; ++i)
+                LS_HIP(hipMemcpyAsync(ix->d_qpad + (size_t)i * g.d,
+                                      d_q + (q0 + std::min(i, real - 1)) * g.d,
+                                      sizeof(float) * g.d, hipMemcpyDeviceToDevice, s));
+            qsrc = ix->d_qpad;
+        }
+        a.d_q = qsrc;
+        a.nq = NQ;
+        a.normalize = normalize;
+        a.reverse = ix->opt_alternate && (ix->sweep_count++ & 1);
+        a.d_S = st.d_S;
+        a.s_stride = ix->s_stride;
+        a.d_cand = st.d_cand;
+        a.c_stride = (long long)ix->max_blocks * LS_KP_MAX;
+        a.d_bound = st.d_bound;
+        a.b_stride = ix->max_blocks;
+        a.blocks = blocks;
+        a.kprime = kprime;
         if (prof) LS_HIP(hipEventRecord(pe[0], s));
-        const bool reverse = ix->opt_alternate && (ix->sweep_count++ & 1);
-        rc = ls_launch_scan(ix->d_corpus, ix->n, g, d_q + qi * g.d, normalize, reverse, st.d_S,
-                            st.d_cand, st.d_bound, blocks, kprime, fin, s);
+        rc = ls_launch_scan(ix->d_corpus, ix->n, g, a, s);
         if (rc != LS_OK) return rc;
         if (prof) {
             LS_HIP(hipEventRecord(pe[1], s));
             ix->prof_n++;
         }
-        ix->has_pending = true;
+        ix->n_pending = real;
         ix->pending_stream = s;
-        ls_fin_params& p = ix->pending;
-        p.S = st.d_S;
-        p.n = ix->n;
-        p.cand = st.d_cand;
-        p.bound = st.d_bound;
-        p.blocks = blocks;
-        p.kprime = kprime;
-        p.k = k;
-        p.keys_cap = std::max(256, blocks * kprime);
-        p.force_slow = ix->opt_force_slow;
-        p.base = ix->base;
-        p.out_scores = d_out_s + qi * k;
-        p.out_indices = (long long*)(d_out_i + qi * k);
-        p.counters = ix->d_counters;
-        ix->last_set = si;
+        for (int i = 0; i < real; ++i) {
+            ls_fin_params& p = ix->pending.p[i];
+            p.S = st.d_S + (size_t)i * a.s_stride;
+            p.n = ix->n;
+            p.cand = st.d_cand + (size_t)i * a.c_stride;
+            p.bound = st.d_bound + (size_t)i * a.b_stride;
+            p.blocks = blocks;
+            p.kprime = kprime;
+            p.k = k;
+            p.keys_cap = std::max(256, blocks * kprime);
+            p.force_slow = ix->opt_force_slow;
+            p.base = ix->base;
+            p.out_scores = d_out_s + (q0 + i) * k;
+            p.out_indices = (long long*)(d_out_i + (q0 + i) * k);
+            p.counters = ix->d_counters;
+        }
+        ix->last_set = gen;
+        q0 += real;
     }
     if (!pipeline || !ix->opt_overlap) return flush_pending(ix);
     return LS_OK;
@@ -484,7 +523,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     int rc = flush_pending(ix);
     if (rc != LS_OK) return rc;
     const int QG = ls_gemm_qg(ix->g);
-    const int QT = 128 * QG;              // queries per workgroup
+    const int QT = LS_GEMM_WAVES * 16 * QG;  // queries per workgroup
     const int TM = ls_gemm_tile_rows(ix->g);
     const int64_t nq_pad0 = (nq + QT - 1) / QT * QT;
     if ((int)ix->bc_pending.size() >= LS_BC_SLOTS ||
@@ -496,7 +535,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     const int64_t nq_pad = nq_pad0;
     const int nqt = (int)(nq_pad / QT);
     // corpus slices: one 8-wave workgroup per CU in total, a multiple of the 8 XCDs
-    int nsplits = (ix->n_cu / nqt) / 8 * 8;
+    int nsplits = (LS_GEMM_WG_PER_CU * ix->n_cu / nqt) / 8 * 8;
     nsplits = std::max(8, std::min(nsplits, LS_GEMM_MAX_SPLITS));
     int64_t rps = (ix->n + nsplits - 1) / nsplits;
     rps = (rps + TM - 1) / TM * TM;
@@ -802,6 +841,10 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
     std::lock_guard<std::mutex> lk(ix->mu);
     if (which == 0) {  // force k' (0 = automatic)
         ix->opt_kprime = value;
+        return LS_OK;
+    }
+    if (which == 6) {  // several queries per corpus pass on the scan path (default on)
+        ix->opt_multi_query = value != 0;
         return LS_OK;
     }
     if (which == 5) {  // speculative sample threshold on the batched path (default on)

@@ -26,7 +26,15 @@ typedef unsigned int u32;
 #define LS_FINAL_THREADS 1024
 #define LS_FINAL_CAP 8192            // keys the finalize workgroup sorts in LDS (64 KiB)
 #define LS_SCAN_MAX_NQ 16            // nq <= this: per-query HBM-bound scan path
+#ifndef LS_GEMM_THREADS
 #define LS_GEMM_THREADS 512          // batched path: 8 waves per workgroup
+#endif
+#define LS_GEMM_WAVES (LS_GEMM_THREADS / 64)
+#define LS_GEMM_WAVES_PER_SIMD 2     // register budget: 2 waves per SIMD
+#ifndef LS_GEMM_TM_SHORT
+#define LS_GEMM_TM_SHORT 64          // corpus rows per LDS tile for stored rows <= 1 KiB
+#endif
+#define LS_GEMM_WG_PER_CU (8 / LS_GEMM_WAVES)
 #define LS_GEMM_MAX_K 128            // batched path handles k <= this (larger k: scan path)
 #define LS_GEMM_MAX_CHUNKS 128       // ... and stored rows <= 2 KiB (d <= 1024 fp16)
 #define LS_GEMM_MIN_ROWS 32768       // ... and shards at least this big
@@ -92,6 +100,10 @@ struct ls_fin_params {
     long long* out_indices;  // [k]
     u32* counters;         // [0] left the fast path, [1] took the general path
 };
+#define LS_SCAN_NQ_MAX 8
+struct ls_fin_batch {
+    ls_fin_params p[LS_SCAN_NQ_MAX];
+};
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
 // prep: q_out[nq, d_pad] = pad(round(normalise(q_in[nq, d]))), fp32
@@ -103,17 +115,31 @@ int ls_launch_convert(const float* d_src, void* d_dst, int64_t n, const ls_geom&
 // scan: scores S[n] for one RAW query (d floats; normalisation / fp16 rounding fused in)
 // + per-workgroup best kprime keys and bound
 int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu);
-// `fin` (may be null): the PREVIOUS query's selection job, executed by one extra workgroup of
-// this launch so that it costs neither a launch nor a kernel boundary.
-int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const float* d_q,
-                   bool normalize, bool reverse, float* d_S, u64* d_cand, u64* d_bound,
-                   int32_t blocks, int32_t kprime, const ls_fin_params* fin, hipStream_t s);
+// One scan launch: `nq` (1, 4 or 8) queries share one pass over the corpus; the launch may carry
+// up to LS_SCAN_NQ_MAX selection jobs of the PREVIOUS launch, each executed by one extra
+// workgroup, so that selection costs neither a launch nor a kernel boundary.
+struct ls_scan_args {
+    const float* d_q;      // nq raw queries, d floats apart (normalisation / fp16 rounding fused in)
+    int nq;                // 1, 4 or 8
+    bool normalize, reverse;
+    float* d_S;            // score vectors, s_stride floats apart
+    long long s_stride;
+    u64* d_cand;           // blocks*kprime keys per query, c_stride keys apart
+    long long c_stride;
+    u64* d_bound;          // blocks bounds per query, b_stride apart
+    long long b_stride;
+    int blocks, kprime;
+    int nfin;              // selection jobs riding on this launch
+    ls_fin_batch fin;
+};
+int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const ls_scan_args& a,
+                   hipStream_t s);
 // LDS bytes a piggy-backed finalize may use without lowering the scan's occupancy below 2/CU
 #define LS_PIGGY_LDS_MAX (72 * 1024)
 // finalize: exact top-k from the scan's candidates (or, if they cannot be proven complete,
 // from S itself) -> out_scores[k], out_indices[k]. Either its own launch, or carried by the
 // NEXT query's scan launch as one extra workgroup (ls_launch_scan's `fin` argument).
-int ls_launch_finalize(const ls_fin_params& p, hipStream_t s);
+int ls_launch_finalize(const struct ls_fin_batch& jobs, int njobs, hipStream_t s);
 // batched MFMA path (ls_gemm.hip)
 int ls_launch_prep_f16(const float* d_q, void* d_qh, int64_t nq, int64_t nq_pad, const ls_geom& g,
                        bool normalize, u32* d_overflow, hipStream_t s);

@@ -105,12 +105,12 @@ __device__ __forceinline__ void top4_insert(u32 (&t)[4], u32 v) {
 }
 
 template <int CHUNKS, int QG, bool SAMPLE>
-__global__ __launch_bounds__(LS_GEMM_THREADS, 2) void ls_gemm_filter_kernel(
+__global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_gemm_filter_kernel(
     const u32x4* __restrict__ corpus, long long n, const u32x4* __restrict__ qh, int nq, int nqt,
     const float* __restrict__ tau, long long rows_per_split, int tile_stride,
     u64* __restrict__ queues, u32* __restrict__ counts, int cap, u32* __restrict__ overflow,
     u32* __restrict__ sample_top) {
-    constexpr int TM = CHUNKS <= 64 ? 64 : 32;            // corpus rows per LDS tile
+    constexpr int TM = CHUNKS <= 64 ? LS_GEMM_TM_SHORT : 32;  // corpus rows per LDS tile
     constexpr int NRB = TM / 16;                          // 16-row MFMA blocks per tile
     constexpr int KS = CHUNKS / 4;                        // k-steps: 32 fp16 = 4 chunks each
     constexpr int QPW = 16 * QG;                          // queries per wave
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, 2) void ls_gemm_filter_kernel(
     float tauv[QG];
 #pragma unroll
     for (int g2 = 0; g2 < QG; ++g2) {
-        qj[g2] = (qt * 8 + wave) * QPW + g2 * 16 + li;
+        qj[g2] = (qt * LS_GEMM_WAVES + wave) * QPW + g2 * 16 + li;
         const u32x4* qrow = qh + (long long)qj[g2] * CHUNKS + qd;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
@@ -286,14 +286,14 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, 2) void ls_gemm_filter_kernel(
 }
 
 int ls_gemm_qg(const ls_geom& g) { return g.chunks <= 64 ? 2 : 1; }
-int ls_gemm_tile_rows(const ls_geom& g) { return g.chunks <= 64 ? 64 : 32; }
+int ls_gemm_tile_rows(const ls_geom& g) { return g.chunks <= 64 ? LS_GEMM_TM_SHORT : 32; }
 
 int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, const void* d_qh,
                           int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
                           int64_t rows_per_split, int tile_stride, u64* d_queues, u32* d_counts,
                           int cap, u32* d_overflow, u32* d_sample_top, hipStream_t s) {
     const int QG = ls_gemm_qg(g);
-    const int nqt = (int)(nq_pad / (128 * QG));
+    const int nqt = (int)(nq_pad / (LS_GEMM_WAVES * 16 * QG));
     const dim3 grid((unsigned)(nsplits * nqt)), block(LS_GEMM_THREADS);
     const size_t smem = (size_t)2 * ls_gemm_tile_rows(g) * g.chunks * 16;
 #define LS_GEMM_LAUNCH(C, Q, SMP)                                                                 \
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void ls_tau_kernel(const u32* __restrict__ sam
         if (tid == 0) tau[q] = FLT_MAX;  // padded query: nothing passes
         return;
     }
-    const int QT = 128 * QG, QPW = 16 * QG;
+    const int QT = LS_GEMM_WAVES * 16 * QG, QPW = 16 * QG;
     const int qt = q / QT, w = (q % QT) / QPW, qg = (q % QPW) / 16, li = q % 16;
     const int total = nsplits * 4 * 4;  // values of this query
     u32 v[LS_TAU_PER_THREAD];
@@ -387,7 +387,7 @@ int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_p
         return LS_ERR_INVALID_ARG;
     }
     hipLaunchKernelGGL(ls_tau_kernel, dim3((unsigned)nq_pad), dim3(256), 0, s, d_sample_top,
-                       nsplits, (int)(nq_pad / (128 * QG)), QG, (int)nq, j_rank, d_tau);
+                       nsplits, (int)(nq_pad / (LS_GEMM_WAVES * 16 * QG)), QG, (int)nq, j_rank, d_tau);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
     __shared__ u32 nkeys;
     __shared__ u32 wsum[8];
     const int q = blockIdx.x, tid = threadIdx.x;
-    const int QT = 128 * QG, QPW = 16 * QG;
+    const int QT = LS_GEMM_WAVES * 16 * QG, QPW = 16 * QG;
     const int qt = q / QT, w = (q % QT) / QPW, qg = (q % QPW) / 16, li = q % 16;
     // gather: thread t < 4*nsplits owns one of the query's queues: one load for its length, a
     // block-wide prefix for its slot range in LDS, then its (few) live entries
@@ -463,7 +463,7 @@ int ls_launch_batch_select(const u64* d_queues, const u32* d_counts, int cap, in
         return LS_ERR_INVALID_ARG;
     }
     hipLaunchKernelGGL(ls_batch_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, d_queues,
-                       d_counts, cap, nsplits, (int)(nq_pad / (128 * QG)), QG, k, (long long)base,
+                       d_counts, cap, nsplits, (int)(nq_pad / (LS_GEMM_WAVES * 16 * QG)), QG, k, (long long)base,
                        d_overflow, d_out_scores, (long long*)d_out_indices);
     LS_HIP(hipGetLastError());
     return LS_OK;

@@ -25,6 +25,8 @@
 
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
+
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // one 16-byte chunk
 
@@ -114,11 +116,46 @@ struct QueryRegs<true, V> {
     }
 };
 
+// Sum over the L lanes that share a row, result in every lane of the group. Pure VALU: DPP
+// inside 16-lane rows (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror), then gfx950's
+// v_permlane16_swap / v_permlane32_swap across rows. (ds_bpermute-based shuffles go through the
+// LDS crossbar, which becomes the bottleneck when 8 queries share one corpus pass.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
+    return v + __builtin_bit_cast(float, moved);
+}
 template <int L>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int m = L / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]: + lane ^ 1
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]: + lane ^ 2
+    v = dpp_add<0x141>(v);  // row_half_mirror: + the other quad of each 8
+    v = dpp_add<0x140>(v);  // row_mirror: + the other half of each 16
+    if (L >= 32) {          // rows 0<->1, 2<->3
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    if (L >= 64) {          // lanes 0-31 <-> 32-63
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
     return v;
+}
+
+// value of group (lane % R) delivered to every lane: R scalar reads + a select chain, no LDS
+template <int L>
+__device__ __forceinline__ float pick_group(float s, int lane) {
+    constexpr int R = LS_WAVE / L;
+    float out = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 0));
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+        const float vr =
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), r * L));
+        out = (lane % R) == r ? vr : out;
+    }
+    return out;
 }
 
 __device__ __forceinline__ u64 readlane64(u64 v, int l) {  // l must be wave-uniform
@@ -137,21 +174,22 @@ __device__ __forceinline__ void wave_insert(u64& lst, u64 v, int lane, int kp) {
     }
 }
 
-template <bool F16, int L, int V, int U, int MODE>
+template <bool F16, int L, int V, int U, int NQ>
 __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
     const f32x4* __restrict__ corpus, long long n, int chunks, const float* __restrict__ qraw,
-    int d, int normalize, int reverse, float* __restrict__ S, u64* __restrict__ cand,
-    u64* __restrict__ bound, int kprime, int has_fin, ls_fin_params fin) {
-    // Workgroup 0 of a launch that carries a selection job runs the PREVIOUS query's finalize
-    // (ls_select_dev.h) while every other workgroup scans for the current query: the selection
-    // costs neither a launch nor a kernel boundary, and its ~5 us hide under the ~50 us scan.
+    int d, int normalize, int reverse, float* __restrict__ S, long long s_stride,
+    u64* __restrict__ cand, long long c_stride, u64* __restrict__ bound, long long b_stride,
+    int kprime, int nfin, ls_fin_batch fin) {
+    // The first `nfin` workgroups of a launch run the PREVIOUS launch's selection jobs
+    // (finalize_body, ls_select_dev.h) while every other workgroup scans for the current queries:
+    // selection costs neither a launch nor a kernel boundary and hides under the scan.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-    if (has_fin && blockIdx.x == 0) {
-        finalize_body<LS_SCAN_THREADS>(fin, smem_dyn, threadIdx.x);
+    if ((int)blockIdx.x < nfin) {
+        finalize_body<LS_SCAN_THREADS>(fin.p[blockIdx.x], smem_dyn, threadIdx.x);
         return;
     }
-    const int bid = (int)blockIdx.x - has_fin;
-    const int nblk = (int)gridDim.x - has_fin;
+    const int bid = (int)blockIdx.x - nfin;
+    const int nblk = (int)gridDim.x - nfin;
     constexpr int R = LS_WAVE / L;  // rows per wave load step
     constexpr int TR = U * R;       // rows per tile: one tile = U steps = TR contiguous rows
     static_assert(TR <= LS_WAVE, "a tile's scores must fit one per lane");
@@ -181,60 +219,78 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
         }
     };
     long long t = gw;
-    if (t < NT) issue_loads(t);  // first tile's loads fly while the query is prepared
+    if (t < NT) issue_loads(t);  // first tile's loads fly while the queries are prepared
 
-    // query -> registers, with faiss.normalize_L2 (reference search/engine.py:242) fused in:
-    // x *= 1/sqrt(sum x^2), rows of zero norm untouched
-    QueryRegs<F16, V> qr;
-    {
-        const float ss = group_sum<L>(qr.load(qraw, d, sub, L));
+    // NQ queries -> registers, with faiss.normalize_L2 (reference search/engine.py:242) fused
+    // in: x *= 1/sqrt(sum x^2), rows of zero norm untouched. One pass over the corpus then
+    // serves all NQ queries (the reference sends one query at a time; small batches share the
+    // HBM traffic this way).
+    QueryRegs<F16, V> qr[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        const float ss = group_sum<L>(qr[qi].load(qraw + (long long)qi * d, d, sub, L));
         const float inv = (normalize && ss > 0.0f) ? 1.0f / sqrtf(ss) : 1.0f;
-        qr.scale(inv);
+        qr[qi].scale(inv);
     }
 
-    u64 lst = 0;  // lanes 0..kp-1: this wave's best keys, descending
-    u64 thr = 0;  // key in lane kp-1 (wave-uniform): a row must beat it to matter
+    u64 lst[NQ];  // per query, lanes 0..kp-1: this wave's best keys, descending
+    u64 thr[NQ];  // key in lane kp-1 (wave-uniform): a row must beat it to matter
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        lst[qi] = 0;
+        thr[qi] = 0;
+    }
 
     while (t < NT) {
-        // lane i < TR collects the score of tile row i
-        float sc = 0.0f;
+        // lane i < TR collects the score of tile row i, per query
+        float sc[NQ];
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) sc[qi] = 0.0f;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float s = group_sum<L>(qr.dot(x[u]));         // valid in all L lanes of a group
-            const float sel = __shfl(s, (lane % R) * L, 64);    // lane i <- group (i % R)
-            if (lane / R == u) sc = sel;
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+                const float s = group_sum<L>(qr[qi].dot(x[u]));   // valid in all L lanes of a group
+                const float sel = pick_group<L>(s, lane);         // lane i <- group (i % R)
+                if (lane / R == u) sc[qi] = sel;
+            }
         }
         const long long tt = reverse ? NT - 1 - t : t;
         const long long row = tt * TR + lane;
         t += W;
         if (t < NT) issue_loads(t);  // next tile's loads overlap the selection below
         const bool valid = lane < TR && row < n;
-        if (valid) S[row] = sc;  // TR contiguous floats
-        const u64 key = valid ? ls_make_key(sc, (u32)row) : 0ull;
-        u64 mask = __ballot(key > thr);
-        while (mask) {  // rare once the threshold has warmed up
-            const int j = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const u64 v = readlane64(key, j);
-            wave_insert(lst, v, lane, kp);
-            thr = readlane64(lst, kp - 1);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+            if (valid) S[qi * s_stride + row] = sc[qi];  // TR contiguous floats
+            const u64 key = valid ? ls_make_key(sc[qi], (u32)row) : 0ull;
+            u64 mask = __ballot(key > thr[qi]);
+            while (mask) {  // rare once the threshold has warmed up
+                const int j = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const u64 v = readlane64(key, j);
+                wave_insert(lst[qi], v, lane, kp);
+                thr[qi] = readlane64(lst[qi], kp - 1);
+            }
         }
     }
 
-    // merge the 4 wave lists -> this workgroup's best kprime keys + bound
-    __shared__ u64 sm[LS_SCAN_WAVES * LS_KP_MAX];
-    if (lane < LS_KP_MAX) sm[wave * LS_KP_MAX + lane] = (lane < kp) ? lst : 0ull;
+    // merge the 4 wave lists of every query -> this workgroup's best kprime keys + bound
+    __shared__ u64 sm[NQ][LS_SCAN_WAVES * LS_KP_MAX];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+        if (lane < LS_KP_MAX) sm[qi][wave * LS_KP_MAX + lane] = (lane < kp) ? lst[qi] : 0ull;
     __syncthreads();
-    if (wave == 0) {
-        const u64 mine = sm[lane];  // LS_SCAN_WAVES * LS_KP_MAX == 64 slots
+    for (int qi = wave; qi < NQ; qi += LS_SCAN_WAVES) {  // wave w ranks queries w, w+4, ..
+        const u64 mine = sm[qi][lane];  // LS_SCAN_WAVES * LS_KP_MAX == 64 slots
         int rank = 0;
 #pragma unroll 8
         for (int i = 0; i < LS_SCAN_WAVES * LS_KP_MAX; ++i) {
-            const u64 o = sm[i];
+            const u64 o = sm[qi][i];
             rank += (o > mine) || (o == mine && i < lane);
         }
-        if (rank < kprime) cand[(long long)bid * kprime + rank] = mine;
-        if (rank == kprime) bound[bid] = mine;
+        if (rank < kprime) cand[qi * c_stride + (long long)bid * kprime + rank] = mine;
+        if (rank == kprime) bound[qi * b_stride + bid] = mine;
     }
 }
 
@@ -260,42 +316,49 @@ int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu) {
     return (int)b;
 }
 
-template <bool F16, int L, int V>
-static int launch_lv(const void* corpus, int64_t n, const ls_geom& g, const float* q,
-                     int normalize, int reverse, float* S, u64* cand, u64* bound, int blocks,
-                     int kprime, const ls_fin_params* fin, hipStream_t s) {
+template <bool F16, int L, int V, int NQ>
+static int launch_lvq(const void* corpus, int64_t n, const ls_geom& g, const ls_scan_args& a,
+                      hipStream_t s) {
     constexpr int U = scan_unroll(V);
-    ls_fin_params fp{};
     size_t smem = 0;
-    int has_fin = 0;
-    if (fin) {
-        fp = *fin;
-        has_fin = 1;
+    for (int i = 0; i < a.nfin; ++i) {
+        const ls_fin_params& fp = a.fin.p[i];
         const int keff = (int)((long long)fp.k < fp.n ? fp.k : fp.n);
-        smem = ls_fin_lds_bytes(fp.keys_cap, keff);
+        smem = std::max(smem, ls_fin_lds_bytes(fp.keys_cap, keff));
     }
-    auto kern = ls_scan_kernel<F16, L, V, U, 0>;
+    auto kern = ls_scan_kernel<F16, L, V, U, NQ>;
     static bool attr_set = false;
     if (!attr_set) {
         LS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LS_PIGGY_LDS_MAX));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks + has_fin), dim3(LS_SCAN_THREADS), smem, s,
-                       (const f32x4*)corpus, (long long)n, g.chunks, q, g.d, normalize, reverse, S,
-                       cand, bound, kprime, has_fin, fp);
+    hipLaunchKernelGGL(kern, dim3(a.blocks + a.nfin), dim3(LS_SCAN_THREADS), smem, s,
+                       (const f32x4*)corpus, (long long)n, g.chunks, a.d_q, g.d,
+                       a.normalize ? 1 : 0, a.reverse ? 1 : 0, a.d_S, (long long)a.s_stride,
+                       a.d_cand, (long long)a.c_stride, a.d_bound, (long long)a.b_stride, a.kprime,
+                       a.nfin, a.fin);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
 
+template <bool F16, int L, int V>
+static int launch_lv(const void* corpus, int64_t n, const ls_geom& g, const ls_scan_args& a,
+                     hipStream_t s) {
+    switch (a.nq) {
+        case 1: return launch_lvq<F16, L, V, 1>(corpus, n, g, a, s);
+        case 4: return launch_lvq<F16, L, V, 4>(corpus, n, g, a, s);
+        case 8: return launch_lvq<F16, L, V, 8>(corpus, n, g, a, s);
+    }
+    ls_set_error("ls_launch_scan: unsupported queries per launch %d", a.nq);
+    return LS_ERR_INVALID_ARG;
+}
+
 template <bool F16>
-static int launch_dt(const void* corpus, int64_t n, const ls_geom& g, const float* q,
-                     int normalize, int reverse, float* S, u64* cand, u64* bound, int blocks,
-                     int kprime, const ls_fin_params* fin, hipStream_t s) {
-#define LS_CASE(LL, VV)                                                                    \
-    if (g.L == LL && g.V == VV)                                                            \
-        return launch_lv<F16, LL, VV>(corpus, n, g, q, normalize, reverse, S, cand, bound, blocks,      \
-                                      kprime, fin, s);
+static int launch_dt(const void* corpus, int64_t n, const ls_geom& g, const ls_scan_args& a,
+                     hipStream_t s) {
+#define LS_CASE(LL, VV) \
+    if (g.L == LL && g.V == VV) return launch_lv<F16, LL, VV>(corpus, n, g, a, s);
     LS_CASE(16, 1) LS_CASE(16, 2) LS_CASE(16, 3) LS_CASE(16, 4)
     LS_CASE(32, 3) LS_CASE(32, 4)
     LS_CASE(64, 3) LS_CASE(64, 4)
@@ -304,18 +367,12 @@ static int launch_dt(const void* corpus, int64_t n, const ls_geom& g, const floa
     return LS_ERR_INVALID_ARG;
 }
 
-int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const float* d_q,
-                   bool normalize, bool reverse, float* d_S, u64* d_cand, u64* d_bound,
-                   int32_t blocks, int32_t kprime, const ls_fin_params* fin, hipStream_t s) {
+int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const ls_scan_args& a,
+                   hipStream_t s) {
     if (n <= 0) return LS_OK;
-    if (kprime < 1 || kprime + 1 > LS_KP_MAX) {
-        ls_set_error("ls_launch_scan: kprime %d out of range", kprime);
+    if (a.kprime < 1 || a.kprime + 1 > LS_KP_MAX) {
+        ls_set_error("ls_launch_scan: kprime %d out of range", a.kprime);
         return LS_ERR_INVALID_ARG;
     }
-    const int nz = normalize ? 1 : 0;
-    return g.elem == 2
-               ? launch_dt<true>(d_corpus, n, g, d_q, nz, reverse ? 1 : 0, d_S, d_cand, d_bound,
-                                 blocks, kprime, fin, s)
-               : launch_dt<false>(d_corpus, n, g, d_q, nz, reverse ? 1 : 0, d_S, d_cand, d_bound,
-                                  blocks, kprime, fin, s);
+    return g.elem == 2 ? launch_dt<true>(d_corpus, n, g, a, s) : launch_dt<false>(d_corpus, n, g, a, s);
 }

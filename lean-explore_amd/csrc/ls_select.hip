@@ -2,22 +2,29 @@
 // merge. The device code lives in ls_select_dev.h.
 #include "ls_select_dev.h"
 
-// ---- stand-alone finalize: one workgroup of 1024 threads, dynamic LDS ---------------------------
-__global__ __launch_bounds__(LS_FINAL_THREADS) void ls_finalize_kernel(ls_fin_params p) {
+#include <algorithm>
+
+// ---- stand-alone finalize: one workgroup of 1024 threads per job, dynamic LDS ---------------------
+__global__ __launch_bounds__(LS_FINAL_THREADS) void ls_finalize_kernel(ls_fin_batch jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_fin[];
-    finalize_body<LS_FINAL_THREADS>(p, smem_fin, threadIdx.x);
+    finalize_body<LS_FINAL_THREADS>(jobs.p[blockIdx.x], smem_fin, threadIdx.x);
 }
 
-int ls_launch_finalize(const ls_fin_params& p, hipStream_t s) {
+int ls_launch_finalize(const ls_fin_batch& jobs, int njobs, hipStream_t s) {
+    if (njobs <= 0) return LS_OK;
     static bool attr_set = false;
     if (!attr_set) {
         LS_HIP(hipFuncSetAttribute((const void*)ls_finalize_kernel,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
-    const int keff = (int)((long long)p.k < p.n ? p.k : p.n);
-    const size_t smem = ls_fin_lds_bytes(p.keys_cap, keff);
-    hipLaunchKernelGGL(ls_finalize_kernel, dim3(1), dim3(LS_FINAL_THREADS), smem, s, p);
+    size_t smem = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const ls_fin_params& p = jobs.p[i];
+        const int keff = (int)((long long)p.k < p.n ? p.k : p.n);
+        smem = std::max(smem, ls_fin_lds_bytes(p.keys_cap, keff));
+    }
+    hipLaunchKernelGGL(ls_finalize_kernel, dim3(njobs), dim3(LS_FINAL_THREADS), smem, s, jobs);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }

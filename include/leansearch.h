@@ -136,6 +136,24 @@ int64_t ls_debug_counter(ls_index* index, int32_t which);
 /* Copy the score vector S[0..count) of the most recent per-query scan to host memory. */
 int ls_debug_read_scores(ls_index* index, float* out, int64_t count);
 
+/* ---- lexical (BM25+) name retrieval: SURVEY §8(f) row 3 -----------------------------------------
+ * Stands in for `bm25s.BM25.retrieve([tokens], k)` (reference src/lean_explore/search/engine.py:
+ * 209-214). The index is bm25s's eager-sparse CSC matrix (one column per vocabulary token:
+ * document rows + float32 scores) plus its per-token non-occurrence array (bm25+), i.e. the
+ * arrays bm25s saves as data/indices/indptr.csc.index.npy and nonoccurrence_array.index.npy
+ * (reference src/lean_explore/cli/data_commands.py:42-59). All pointers are host memory. */
+typedef struct ls_bm25 ls_bm25;
+int ls_bm25_create(ls_bm25** out, const int64_t* indptr, const int32_t* indices, const float* data,
+                   const float* nonoccurrence, int64_t n_docs, int64_t n_vocab, int32_t device);
+/* token_ids: the query's token ids in query order (unknown tokens already dropped, duplicates
+ * kept). out_scores float32 [k], out_docs int64 [k], best first under (score desc, doc asc),
+ * padded with (-FLT_MAX, -1) when k > n_docs. Scores are bit-identical to the sequential
+ * float32 accumulation bm25s performs. Synchronous. */
+int ls_bm25_search(ls_bm25* index, const int32_t* token_ids, int32_t n_tokens, int32_t k,
+                   float* out_scores, int64_t* out_docs);
+int64_t ls_bm25_ntotal(const ls_bm25* index);
+void ls_bm25_destroy(ls_bm25* index);
+
 const char* ls_last_error(void); /* thread-local; valid until the next call on this thread */
 const char* ls_version(void);
 int32_t ls_device_count(void);

@@ -158,22 +158,6 @@ __device__ __forceinline__ float pick_group(float s, int lane) {
     return out;
 }
 
-__device__ __forceinline__ u64 readlane64(u64 v, int l) {  // l must be wave-uniform
-    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
-    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
-    return ((u64)hi << 32) | lo;
-}
-
-// Insert key `v` (wave-uniform) into the wave's sorted list (lanes 0..kp-1, descending).
-__device__ __forceinline__ void wave_insert(u64& lst, u64 v, int lane, int kp) {
-    const int cnt = __popcll(__ballot(lst > v));  // lanes >= kp hold 0 and never count
-    if (cnt < kp) {
-        const u64 up = __shfl_up(lst, 1, 64);
-        lst = (lane > cnt) ? up : (lane == cnt ? v : lst);
-        if (lane >= kp) lst = 0;
-    }
-}
-
 template <bool F16, int L, int V, int U, int NQ>
 __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
     const f32x4* __restrict__ corpus, long long n, int chunks, const float* __restrict__ qraw,

@@ -27,6 +27,24 @@
 
 #define LS_RES_CAP 2048  // == LS_MAX_K
 
+// ---- a wave's running best-keys list (used by the scan and the BM25 candidate kernels) -----------
+__device__ __forceinline__ u64 readlane64(u64 v, int l) {  // l must be wave-uniform
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
+// Insert key `v` (wave-uniform) into the wave's sorted list (lanes 0..kp-1, descending).
+__device__ __forceinline__ void wave_insert(u64& lst, u64 v, int lane, int kp) {
+    const int cnt = __popcll(__ballot(lst > v));  // lanes >= kp hold 0 and never count
+    if (cnt < kp) {
+        const u64 up = __shfl_up(lst, 1, 64);
+        lst = (lane > cnt) ? up : (lane == cnt ? v : lst);
+        if (lane >= kp) lst = 0;
+    }
+}
+
+
 // ---- workgroup-wide bitonic sort, descending, m a power of two, keys in LDS ------------------
 // Pair p of a stage is handled by thread p % nthreads. For strides j <= 64 both elements of
 // pair p lie in the 128-element block p >> 6, and all lanes of a wave share p >> 6, so those

@@ -1,0 +1,93 @@
+"""Lexical (BM25+) retrieval, SURVEY §8(f) row 3: numpy oracle vs the textbook formula and the
+product's host builder on CPU; HIP retrieval vs the oracle bit for bit on the GPU."""
+
+import json
+
+import numpy as np
+import pytest
+
+from lean_explore_amd.bm25 import BM25Index, NameRetriever
+from lean_explore_amd.search.tokenization import tokenize_raw, tokenize_spaced
+from oracle import bm25_ref as R
+
+WORDS = ["nat", "add", "comm", "mul", "zero", "succ", "list", "map", "append", "real", "sqrt", "le",
+         "lt", "of", "iff", "continuous", "on", "measure", "theory", "group", "ring", "hom", "ker"]
+
+
+def synth_names(n, seed=0):
+    rng = np.random.default_rng(seed)
+    names = []
+    for i in range(n):
+        parts = [WORDS[j] for j in rng.integers(0, len(WORDS), size=rng.integers(1, 5))]
+        ns = ["Nat", "List", "Real", "MeasureTheory", "Mathlib"][rng.integers(0, 5)]
+        names.append(f"{ns}.{'_'.join(parts)}{i % 97 if i % 3 == 0 else ''}")
+    return names
+
+
+def test_oracle_matches_textbook_bm25_plus():
+    corpus = [tokenize_spaced(n) for n in synth_names(300, 1)]  # repeated tokens: tf > 1 occurs
+    ix = R.build(corpus)
+    for q in (["nat", "add"], ["list", "map", "append", "list"], ["nope"], []):
+        s = R.scores(ix, R.token_ids(ix, q))
+        b = R.brute_force_scores(corpus, q)
+        assert np.allclose(s, b, atol=2e-5), q
+    docs, sc = R.retrieve(ix, ["nat", "add"], 400)
+    assert (docs[300:] == -1).all() and (np.diff(sc[:300]) <= 0).all()
+
+
+def test_host_builder_equals_oracle_and_roundtrips(tmp_path):
+    corpus = [list(dict.fromkeys(tokenize_spaced(n))) for n in synth_names(500, 2)]
+    ref = R.build(corpus)
+    ix = BM25Index().index(corpus)
+    assert ix.vocab == ref["vocab"] and ix.num_docs == 500
+    assert np.array_equal(ix.indptr, ref["indptr"]) and np.array_equal(ix.indices, ref["indices"])
+    assert np.array_equal(ix.data, ref["data"]) and np.array_equal(ix.nonoccurrence, ref["nonocc"])
+    ix.save(tmp_path / "bm25_name_spaced")
+    # the reference's file set (cli/data_commands.py:42-59)
+    assert sorted(p.name for p in (tmp_path / "bm25_name_spaced").iterdir()) == sorted([
+        "data.csc.index.npy", "indices.csc.index.npy", "indptr.csc.index.npy",
+        "nonoccurrence_array.index.npy", "params.index.json", "vocab.index.json"])
+    back = BM25Index.load(tmp_path / "bm25_name_spaced")
+    assert back.vocab == ix.vocab and np.array_equal(back.data, ix.data)
+    assert np.array_equal(back.indptr, ix.indptr) and back.num_docs == 500
+    assert json.loads((tmp_path / "bm25_name_spaced" / "params.index.json").read_text())["method"] == "bm25+"
+
+
+@pytest.mark.gpu
+def test_hip_retrieve_bit_exact_vs_oracle():
+    names = synth_names(200_000, 3)
+    corpus = [list(dict.fromkeys(tokenize_spaced(n))) for n in names]
+    ref = R.build(corpus)
+    ix = BM25Index().index(corpus)
+    for q, k in ((["nat", "add", "comm"], 1000), (["measure", "theory"], 50), (["nope"], 10),
+                 (["list", "list", "map"], 1000), ([], 5), (["ker"], 2048)):
+        docs, sc = ix.retrieve(q, k)
+        dref, sref = R.retrieve(ref, q, k)
+        assert np.array_equal(sc, sref), q      # same float32 accumulation order: bit-identical
+        assert np.array_equal(docs, dref), q    # ties (thousands) broken by ascending document
+    small = BM25Index().index(corpus[:30])
+    docs, sc = small.retrieve(["nat"], 100)     # k > n_docs -> padding
+    dref, sref = R.retrieve(R.build(corpus[:30]), ["nat"], 100)
+    assert np.array_equal(docs, dref) and np.array_equal(sc, sref)
+
+
+@pytest.mark.gpu
+def test_name_retriever_max_merge_and_engine_plug(tmp_path):
+    names = synth_names(5000, 4)
+    ids = [10_000 + i for i in range(len(names))]
+    nr = NameRetriever.from_names(ids, names)
+    nr.save(tmp_path)
+    nr2 = NameRetriever.load(tmp_path)
+    q = names[1234]
+    got = nr(q, 1000)
+    assert got == nr2(q, 1000)
+    # restate engine.py:192-223 with the oracle
+    want: dict[int, float] = {}
+    for toks, corp in ((tokenize_spaced(q), [list(dict.fromkeys(tokenize_spaced(n))) for n in names]),
+                       (tokenize_raw(q), [list(dict.fromkeys(tokenize_raw(n))) for n in names])):
+        docs, sc = R.retrieve(R.build(corp), toks, 1000)
+        for d, s in zip(docs, sc):
+            if d >= 0:
+                want[ids[d]] = max(want.get(ids[d], 0.0), float(s))
+    assert got == want
+    assert max(got, key=got.get) == ids[1234] or got[ids[1234]] == max(got.values())

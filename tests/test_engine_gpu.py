@@ -53,3 +53,32 @@ def test_service_search_drop_in(tmp_path, container):
     assert [r.id for r in r_hip.results] == [r.id for r in r_ref.results]
     assert r_hip.count == len(r_hip.results) > 0
     assert all(not r.name.endswith(".mk") for r in r_hip.results)
+
+
+def test_hybrid_search_with_lexical_retriever(tmp_path):
+    """Both retrievers on the GPU, fused by reciprocal rank as in engine.py:263-300."""
+    import json
+
+    from lean_explore_amd.bm25 import NameRetriever
+
+    n, d = 2000, 384
+    corpus = H.gauss(23, n, d)
+    names = [f"Mathlib.lemma_{i}_add_comm" if i % 2 else f"Mathlib.thm{i}.mul_zero" for i in range(n)]
+    rows = [(7000 + i, names[i], "Mathlib.Mod", None, "src", "link", None, f"text {i}",
+             loader.embedding_to_blob(corpus[i].tolist())) for i in range(n)]
+    db = tmp_path / "lean_explore.db"
+    _make_db(db, rows)
+    ids, loaded = loader.load_corpus_from_sqlite(db)
+    ix = faiss_compat.IndexFlatIP(d)
+    ix.add(loaded)
+    lexical = NameRetriever.from_names(ids, names)
+    eng = S.SearchEngine(db_path=db, embedding_client=FakeEmbed(corpus[400]), index=ix, ids_map=ids,
+                         lexical_retriever=lexical)
+    res = run(eng.search("thm401 mul_zero", limit=10, rerank_top=0))
+    assert res and all(isinstance(r, S.SearchResult) for r in res)
+    sem = run(eng._retrieve_semantic_candidates("q", 1000))
+    lex = eng._retrieve_bm25_candidates("thm401 mul_zero", 1000)
+    fused = dict(S.SearchEngine._compute_rrf_scores(lex, sem))
+    best = max(fused, key=fused.get)
+    assert res[0].id == best or fused[res[0].id] == pytest.approx(fused[best])
+    assert 7400 in sem and len(lex) > 0

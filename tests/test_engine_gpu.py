@@ -82,3 +82,34 @@ def test_hybrid_search_with_lexical_retriever(tmp_path):
     best = max(fused, key=fused.get)
     assert res[0].id == best or fused[res[0].id] == pytest.approx(fused[best])
     assert 7400 in sem and len(lex) > 0
+
+
+def test_rerank_mixing_weights(tmp_path):
+    """engine.py:360-416: 1.0*reranker + 0.4*bm25(informalization) + 0.2*deps (+1.0*fuzzy>=0.7)."""
+    from types import SimpleNamespace
+
+    class FakeReranker:
+        async def rerank(self, query, documents):
+            self.documents = documents
+            return SimpleNamespace(scores=[float(len(d) % 7) for d in documents])
+
+    n, d = 300, 64
+    corpus = H.gauss(29, n, d)
+    rows = [(100 + i, f"Pkg.decl{i}", "Pkg.Mod", None, "src", "link", None,
+             f"the sum of {i} and zero equals {i}" if i % 2 else f"a list of length {i}",
+             loader.embedding_to_blob(corpus[i].tolist())) for i in range(n)]
+    db = tmp_path / "lean_explore.db"
+    _make_db(db, rows)
+    ids, loaded = loader.load_corpus_from_sqlite(db)
+    ix = faiss_compat.IndexFlatIP(d)
+    ix.add(loaded)
+    rr = FakeReranker()
+    eng = S.SearchEngine(db_path=db, embedding_client=FakeEmbed(corpus[10]), index=ix, ids_map=ids,
+                         reranker_client=rr)
+    res = run(eng.search("sum and zero", limit=5, rerank_top=20))
+    assert len(res) == 5 and len(rr.documents) == 20
+    assert rr.documents[0].startswith("Pkg.decl")            # "name: informalization"
+    decls = [SimpleNamespace(name=f"n{i}", informalization=t, dependencies=None)
+             for i, t in enumerate(["sum of zero", "unrelated words", "zero zero sum and"])]
+    b = eng._compute_bm25_on_informalizations("sum and zero", [(d_, 0.0) for d_ in decls])
+    assert b[2] > b[0] > b[1]

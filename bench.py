@@ -111,8 +111,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    rehearse = bool(os.environ.get("LS_BENCH_FORCE_EXCHANGE"))  # 1-GPU rehearsal of the N > 1 step
+    if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from lean_explore_amd import native
@@ -138,12 +142,27 @@ def main():
                  torch.empty((nq, k), dtype=torch.int64, device=dev)) for _ in range(4)]
     step_i = [0]
 
+    # N > 1, small batches: the sharded pipeline (local search of step i carries the finalize of
+    # step i-1; the all-gather of step i-1 runs asynchronously; step i-2 is merged)
+    sharded_pipe = world > 1 and nq <= 16
+    if rehearse:
+        index.force_exchange = True
+        sharded_pipe, pipelined = nq <= 16, False
+
     def step():
         o = out_ring[step_i[0] & 3]
         step_i[0] += 1
         if pipelined:
             return local.search_device(tq, k, o[0], o[1], pipeline=True)
+        if sharded_pipe:
+            return index.search_device_pipelined(tq, k)
         return index.search_device(tq, k)
+
+    def drain():
+        if sharded_pipe:
+            index.flush()
+        else:
+            local.check()
 
     # ---- verification on the very arrays that are timed ------------------------------------
     recall = None
@@ -151,7 +170,7 @@ def main():
         from oracle import oracle
 
         s, i = step()
-        local.check()
+        drain()
         nv = min(nq, 16)
         Dr, Ir = oracle.c_search(corpus, queries[:nv], k, f16=(dtype == "f16"))
         _, _, S = oracle.np_search(corpus, queries[:nv], k, f16=(dtype == "f16"))
@@ -159,7 +178,7 @@ def main():
         recall = rep["recall"]
     elif not args.no_verify:
         step()
-        local.check()
+        drain()
 
     def barrier():
         if world > 1:
@@ -175,7 +194,7 @@ def main():
     for _ in range(args.steps):
         step()
     ev1.record()
-    local.check()  # synchronises the stream
+    drain()  # flushes the pipeline and synchronises
     barrier()
     dt = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
@@ -190,7 +209,7 @@ def main():
     n_prof = min(args.steps, 4096 // max(1, min(nq, 16)))
     for _ in range(n_prof):
         step()
-    local.check()
+    drain()
     barrier()
     scan_ms_avg, total_ms_avg = local.last_kernel_ms()
     local.set_profiling(False)
@@ -245,11 +264,14 @@ def main():
             "data": "synthetic (standard-normal rows, L2-normalised; corpus seed 1234, query seed 5678)",
             "config": {"workload": f"{args.workload}: N={n} d={d} {dtype} nq={nq} k={k}",
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
-                       "launches_per_step": (1 if pipelined else
+                       "exchange": ("pipelined: all-gather of step i-1 overlaps scan of step i"
+                                    if sharded_pipe else ("one all-gather per step" if world > 1
+                                                          else "none")),
+                       "launches_per_step": (1 if pipelined else 2 if sharded_pipe else
                                              (5 if nq > 16 and dtype == "f16" else 2 * nq)
                                              + (2 if world > 1 else 0)),
                        "note": "each launch = scan(step i) + one workgroup finalising step i-1"
-                       if pipelined else ("prep, sample pass, tau, MFMA pass + select per batch"
+                       if (pipelined or sharded_pipe) else ("prep, sample pass, tau, MFMA pass + select per batch"
                                           if nq > 16 and dtype == "f16" else
                                           "scan + select launches per query")},
             "effective_gbs": round(algorithmic_bytes(n_local, d, elem, nq, k) * args.steps / dt / 1e9, 1),
@@ -259,7 +281,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(corpus, queries, k, dtype == "f16")
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or rehearse:
         dist.destroy_process_group()
 
 

@@ -48,6 +48,10 @@ class ShardedFlatIPIndex:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._local_search = local_search or self._hip_local_search
         self._merge = merge or self._hip_merge
+        # testing hook: run the exchange + merge even with a single rank (exercises the RCCL
+        # collective on a one-GPU box)
+        self.force_exchange = False
+        self._pipe = None
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -109,7 +113,7 @@ class ShardedFlatIPIndex:
         import torch
         import torch.distributed as dist
 
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             return self._local_search(q, k, normalize)
         nq = q.shape[0]
         # one packed block per rank: [scores f32 nq*k | pad to 8 B | rows i64 nq*k] -> ONE all-gather
@@ -148,6 +152,100 @@ class ShardedFlatIPIndex:
             out_s.data_ptr(), out_i.data_ptr(), dev,
             torch.cuda.current_stream(gathered.device).cuda_stream))
         return out_s, out_i
+
+    # ------------------------------------------------------------------ pipelined search
+    # Throughput mode for streams of small query batches (the scan path, nq <= 16). Step i:
+    #   1. local HIP search of step i with LS_FLAG_PIPELINE: its launch also finalises step i-1,
+    #      so after it the packed local result of step i-1 is complete (stream order);
+    #   2. the all-gather of step i-1 is started asynchronously (it runs on the backend's own
+    #      stream: the collective's latency hides under the next scans);
+    #   3. the all-gather of step i-2 is waited for and merged.
+    # Results of a step are valid after `flush()`; `depth` ring slots hold the last steps.
+    def search_device_pipelined(self, q, k: int, *, normalize: bool = False, depth: int = 4):
+        import torch
+        import torch.distributed as dist
+
+        nq = q.shape[0]
+        if nq > 16:
+            raise ValueError("pipelined search is for the scan path (nq <= 16)")
+        sbytes = (nq * k * 4 + 7) & ~7
+        block = sbytes + nq * k * 8
+        p = self._pipe
+        if p is None or p["key"] != (nq, k, depth, q.device):
+            if p is not None:
+                self.flush()
+            dev = q.device
+            p = self._pipe = {
+                "key": (nq, k, depth, dev), "i": 0, "sbytes": sbytes, "block": block,
+                "packed": [torch.empty(block, dtype=torch.uint8, device=dev) for _ in range(depth)],
+                "gathered": [torch.empty(self.world * block, dtype=torch.uint8, device=dev)
+                             for _ in range(depth)],
+                "out": [(torch.empty((nq, k), dtype=torch.float32, device=dev),
+                         torch.empty((nq, k), dtype=torch.int64, device=dev)) for _ in range(depth)],
+                "work": [None] * depth, "normalize": normalize,
+            }
+        i, depth = p["i"], len(p["packed"])
+        slot = i % depth
+        packed = p["packed"][slot]
+        s_loc = packed[: nq * k * 4].view(torch.float32).view(nq, k)
+        i_loc = packed[sbytes:].view(torch.int64).view(nq, k)
+        self.local.search_device(q, k, s_loc, i_loc, normalize=normalize, pipeline=True)
+        if i >= 1:
+            self._start_exchange((i - 1) % depth)
+        if i >= 2:
+            self._finish_exchange((i - 2) % depth)
+        p["i"] = i + 1
+        return p["out"][slot]
+
+    def _start_exchange(self, slot: int) -> None:
+        import torch.distributed as dist
+
+        p = self._pipe
+        if self.world == 1 and not self.force_exchange:
+            p["work"][slot] = "local"
+            return
+        p["work"][slot] = dist.all_gather_into_tensor(p["gathered"][slot], p["packed"][slot],
+                                                      group=self.group, async_op=True)
+
+    def _finish_exchange(self, slot: int) -> None:
+        import torch
+
+        from . import native
+
+        p = self._pipe
+        work = p["work"][slot]
+        if work is None:
+            return
+        nq, k = p["key"][0], p["key"][1]
+        out_s, out_i = p["out"][slot]
+        if work == "local":
+            packed = p["packed"][slot]
+            out_s.copy_(packed[: nq * k * 4].view(torch.float32).view(nq, k))
+            out_i.copy_(packed[p["sbytes"]:].view(torch.int64).view(nq, k))
+        else:
+            work.wait()  # the current stream waits for the collective
+            g = p["gathered"][slot]
+            native.check(native.load().ls_merge_topk_strided(
+                g.data_ptr(), g.data_ptr() + p["sbytes"], p["block"], self.world, nq, k,
+                out_s.data_ptr(), out_i.data_ptr(), g.device.index or 0,
+                torch.cuda.current_stream(g.device).cuda_stream))
+        p["work"][slot] = None
+
+    def flush(self) -> None:
+        """Drain the pipeline: the last step's finalize, the outstanding exchanges and merges."""
+        import torch
+
+        p = self._pipe
+        self.local.check()  # launches the pending finalize and synchronises the stream
+        if p is None or p["i"] == 0:
+            return
+        i, depth = p["i"], len(p["packed"])
+        self._start_exchange((i - 1) % depth)
+        if i >= 2:
+            self._finish_exchange((i - 2) % depth)
+        self._finish_exchange((i - 1) % depth)
+        torch.cuda.synchronize()
+        p["i"] = 0
 
     def search(self, x: np.ndarray, k: int, *, normalize: bool = False
                ) -> tuple[np.ndarray, np.ndarray]:

@@ -139,7 +139,7 @@ def main():
     # the timed region.
     pipelined = world == 1 and nq <= 16
     out_ring = [(torch.empty((nq, k), dtype=torch.float32, device=dev),
-                 torch.empty((nq, k), dtype=torch.int64, device=dev)) for _ in range(4)]
+                 torch.empty((nq, k), dtype=torch.int64, device=dev)) for _ in range(16)]
     step_i = [0]
 
     # N > 1, small batches: the sharded pipeline (local search of step i carries the finalize of
@@ -149,11 +149,18 @@ def main():
         index.force_exchange = True
         sharded_pipe, pipelined = nq <= 16, False
 
+    # 1 GPU, large batches (MFMA path): calls are queued asynchronously; the verification flags of
+    # up to 16 outstanding batches are checked (and flagged queries repaired) by local.check()
+    # inside the timed region, instead of one host round trip per batch
+    batched_async = world == 1 and not pipelined and not rehearse
+
     def step():
-        o = out_ring[step_i[0] & 3]
+        o = out_ring[step_i[0] & 15]
         step_i[0] += 1
         if pipelined:
             return local.search_device(tq, k, o[0], o[1], pipeline=True)
+        if batched_async:
+            return local.search_device(tq, k, o[0], o[1], asynchronous=True)
         if sharded_pipe:
             return index.search_device_pipelined(tq, k)
         return index.search_device(tq, k)

@@ -622,6 +622,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     }
     if (abl_nopass) return LS_OK;
     rc = ls_launch_batch_select(ix->d_queues, ix->d_counts, cap, nsplits, nq, nq_pad, g, k, ix->base,
+                                ix->n, rps,
                                 d_flags, d_out_s, d_out_i, s);
     if (rc != LS_OK) return rc;
     ls_index::batched_call bc;

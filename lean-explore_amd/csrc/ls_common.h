@@ -152,7 +152,7 @@ int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_p
 int ls_gemm_qg(const ls_geom& g);         // query groups of 16 per wave (2, or 1 for long rows)
 int ls_gemm_tile_rows(const ls_geom& g);  // corpus rows per LDS tile (64, or 32 for long rows)
 int ls_launch_batch_select(const u64* d_queues, const u32* d_counts, int cap, int nsplits,
-                           int64_t nq, int64_t nq_pad, const ls_geom& g, int k, int64_t base,
+                           int64_t nq, int64_t nq_pad, const ls_geom& g, int k, int64_t base, int64_t n, int64_t rows_per_split,
                            u32* d_overflow, float* d_out_scores, int64_t* d_out_indices,
                            hipStream_t s);
 // merge of per-shard lists

@@ -29,6 +29,10 @@
 // path, so the result is always exact.
 #include "ls_select_dev.h"
 
+#ifndef LS_GEMM_CHECK_NUM
+#define LS_GEMM_CHECK_NUM 1
+#define LS_GEMM_CHECK_DEN 1
+#endif
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -115,7 +119,11 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     constexpr int KS = CHUNKS / 4;                        // k-steps: 32 fp16 = 4 chunks each
     constexpr int QPW = 16 * QG;                          // queries per wave
     constexpr int NV = NRB * QG * 4;                      // filter values per lane per tile
-    constexpr int CPK = (NV + KS - 1) / KS;               // checks interleaved per k-step
+    // The filter's queue appends are global stores, and the tile hand-over barrier drains vmcnt:
+    // a store issued in a tile's last k-steps would hold the barrier for its whole round trip.
+    // So the previous tile is filtered in the FIRST LS_GEMM_CHECK_NUM/DEN of the k-steps only.
+    constexpr int CKS = (KS * LS_GEMM_CHECK_NUM + LS_GEMM_CHECK_DEN - 1) / LS_GEMM_CHECK_DEN;
+    constexpr int CPK = (NV + CKS - 1) / CKS;             // checks interleaved per k-step
     constexpr int ROW_BYTES = CHUNKS * 16;
     constexpr int TILE_CHUNKS = TM * CHUNKS;
     constexpr int TILE_BYTES = TILE_CHUNKS * 16;
@@ -123,7 +131,8 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     static_assert(TILE_CHUNKS % LS_GEMM_THREADS == 0, "tile must split evenly over the threads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 tiles
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar DMA addressing
     const int qd = lane >> 4, li = lane & 15;  // quarter (k-chunk / row group), index in group
     int split, qt;
     wg_coords((int)blockIdx.x, nqt, &split, &qt);
@@ -152,12 +161,13 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     }
 
     // private queues of this lane (one per query group), contiguous per lane
-    u64* myq[QG];
+    // entry = {score bits, row relative to the slice}; the select kernel turns it into a key
+    uint2* myq[QG];
     int cnt[QG];
     u32 top[QG][4];
 #pragma unroll
     for (int g2 = 0; g2 < QG; ++g2) {
-        myq[g2] = queues + queue_id((int)blockIdx.x, tid, g2, QG) * cap;
+        myq[g2] = reinterpret_cast<uint2*>(queues) + queue_id((int)blockIdx.x, tid, g2, QG) * cap;
         cnt[g2] = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) top[g2][e] = 0u;
@@ -197,26 +207,28 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     };
 
     // ---- one element of a finished tile: e -> (row block, query group, register) ------------------
-    auto check = [&](const f32x4v (&acc)[NRB][QG], int e, long long row0) {
+    // The append is the hot slow path (a wave enters it for ~1 check in 5): no key building, no
+    // bounds logic here. Padded queries carry tau = FLT_MAX and never pass; zero-pad rows past n
+    // are dropped by the select kernel; a full queue keeps overwriting its last slot while the
+    // count runs on, which is how the overflow is seen at the end.
+    auto check = [&](const f32x4v (&acc)[NRB][QG], int e, int lrow0) {
         const int rb = e / (QG * 4), g2 = (e / 4) % QG, reg = e % 4;
         const float s = acc[rb][g2][reg];
-        const long long row = row0 + rb * 16 + reg;  // row0 already includes 4*qd
+        const int lrow = lrow0 + rb * 16 + reg;  // lrow0 already includes 4*qd
         if (SAMPLE) {
-            const u64 key = (qvalid[g2] && row < r_end) ? ls_make_key(s, 0u) : 0ull;
+            const u64 key = (qvalid[g2] && r_begin + lrow < r_end) ? ls_make_key(s, 0u) : 0ull;
             top4_insert(top[g2], (u32)(key >> 32));
         } else if (s >= tauv[g2]) {
-            const u64 key = ls_make_key(s, (u32)row);
-            if (qvalid[g2] && row < r_end && key != 0ull) {
-                if (cnt[g2] < cap) myq[g2][cnt[g2]] = key;
-                ++cnt[g2];
-            }
+            const int slot = cnt[g2] < cap ? cnt[g2] : cap - 1;
+            myq[g2][slot] = make_uint2(__float_as_uint(s), (u32)lrow);
+            ++cnt[g2];
         }
     };
 
     // One tile: NRB*QG independent accumulator chains advance together, one k-step at a time;
     // the PREVIOUS tile's accumulators are filtered CPK elements per k-step.
     auto run_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], bool have_prev,
-                        long long prev_row0, int buf) {
+                        int prev_row0, int buf) {
         half8 a[2][NRB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) a[0][rb] = a_frag(buf, rb, 0);
@@ -240,7 +252,20 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                                                                         c, 0, 0, 0);
                 }
             }
+#ifdef LS_GEMM_ABL_NOCHECK  // timing ablation: a branch-free sink instead of the filter
             if (have_prev) {
+#pragma unroll
+                for (int c2 = 0; c2 < CPK; ++c2)
+                    if (kk * CPK + c2 < NV) {
+                        const int e = kk * CPK + c2;
+                        tauv[0] += prev[e / (QG * 4)][(e / 4) % QG][e % 4];
+                    }
+            }
+            if (false)
+#else
+            if (have_prev)
+#endif
+            {
 #pragma unroll
                 for (int c2 = 0; c2 < CPK; ++c2)
                     if (kk * CPK + c2 < NV) check(prev, kk * CPK + c2, prev_row0);
@@ -249,21 +274,28 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     };
 
     f32x4v accA[NRB][QG], accB[NRB][QG];  // alternate between consecutive tiles
-    auto tile_row0 = [&](int i) { return r_begin + (long long)(i * tile_stride) * TM + 4 * qd; };
+    auto tile_row0 = [&](int i) { return (i * tile_stride) * TM + 4 * qd; };  // slice-relative
     if (nt > 0) stage(0, 0);
     __syncthreads();  // the compiler drains the DMA (vmcnt(0)) before the barrier
+#ifdef LS_GEMM_ABL_NOSTAGE  // timing ablation: no tile hand-over (results are garbage)
+#define LS_STAGE(t, b) if (cap < 0) stage(t, b)
+#define LS_TILE_BARRIER() if (cap < 0) __syncthreads()
+#else
+#define LS_STAGE(t, b) stage(t, b)
+#define LS_TILE_BARRIER() __syncthreads()
+#endif
     for (int i = 0; i < nt; i += 2) {
-        if (i + 1 < nt) stage((i + 1) * tile_stride, 1);
+        if (i + 1 < nt) LS_STAGE((i + 1) * tile_stride, 1);
         run_tile(accA, accB, i > 0, tile_row0(i - 1), 0);
-        __syncthreads();
+        LS_TILE_BARRIER();
         if (i + 1 < nt) {
-            if (i + 2 < nt) stage((i + 2) * tile_stride, 0);
+            if (i + 2 < nt) LS_STAGE((i + 2) * tile_stride, 0);
             run_tile(accB, accA, true, tile_row0(i), 1);
-            __syncthreads();
+            LS_TILE_BARRIER();
         }
     }
     if (nt > 0) {  // the last tile still has to be filtered
-        const long long row0 = tile_row0(nt - 1);
+        const int row0 = tile_row0(nt - 1);
         if ((nt - 1) & 1) {
 #pragma unroll
             for (int e = 0; e < NV; ++e) check(accB, e, row0);
@@ -280,6 +312,9 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                 make_uint4(top[g2][0], top[g2][1], top[g2][2], top[g2][3]);
         } else {
             counts[qid] = (u32)(cnt[g2] < cap ? cnt[g2] : cap);
+#ifdef LS_GEMM_ABL_NOCHECK
+            if (tauv[0] == 12345.0f) counts[qid] = 7u;
+#endif
             if (cnt[g2] > cap) overflow[qj[g2]] = 1u;
         }
     }
@@ -396,7 +431,8 @@ int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_p
 #define LS_BSEL_KEYS 2048
 __global__ __launch_bounds__(256) void ls_batch_select_kernel(
     const u64* __restrict__ queues, const u32* __restrict__ counts, int cap, int nsplits, int nqt,
-    int QG, int k, long long base, u32* __restrict__ overflow, float* __restrict__ out_scores,
+    int QG, int k, long long base, long long n, long long rows_per_split,
+    u32* __restrict__ overflow, float* __restrict__ out_scores,
     long long* __restrict__ out_indices) {
     __shared__ u64 keys[LS_BSEL_KEYS];
     __shared__ u64 res[256];
@@ -413,8 +449,10 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
     const int nqueues = nsplits * 4;
     u32 c = 0;
     const u64* qptr = nullptr;
+    long long r_begin = 0;
     if (tid < nqueues) {
         const int quarter = tid & 3, split = tid >> 2;
+        r_begin = (long long)split * rows_per_split;
         const long long qid = queue_id(wg_index(split, qt, nqt), w * 64 + quarter * 16 + li, qg, QG);
         c = counts[qid];
         qptr = queues + qid * cap;
@@ -432,8 +470,22 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
         for (int i = 0; i < wv; ++i) off += wsum[i];
         if (tid == 0) nkeys = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         const u32 start = off + inc - c;
-        for (u32 e = 0; e < c; ++e)
-            if (start + e < LS_BSEL_KEYS) keys[start + e] = qptr[e];
+        // entries are read four at a time (two 16-byte loads in flight per step): a queue holds
+        // ~3 entries on average, so most threads need a single round trip
+        auto put = [&](u32 e, u32 bits, u32 lrow) {
+            if (e < c && start + e < LS_BSEL_KEYS) {
+                const long long row = r_begin + (long long)lrow;
+                keys[start + e] = row < n ? ls_make_key(__uint_as_float(bits), (u32)row) : 0ull;
+            }
+        };
+        for (u32 e0 = 0; e0 < c; e0 += 4) {  // cap is a multiple of 4: the loads stay in the queue
+            const uint4 a = reinterpret_cast<const uint4*>(qptr + e0)[0];
+            const uint4 b = reinterpret_cast<const uint4*>(qptr + e0)[1];
+            put(e0, a.x, a.y);
+            put(e0 + 1, a.z, a.w);
+            put(e0 + 2, b.x, b.y);
+            put(e0 + 3, b.z, b.w);
+        }
     }
     __syncthreads();
     const int cnt = (int)nkeys;
@@ -455,7 +507,7 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
 
 int ls_launch_batch_select(const u64* d_queues, const u32* d_counts, int cap, int nsplits,
                            int64_t nq, int64_t nq_pad, const ls_geom& g, int k, int64_t base,
-                           u32* d_overflow, float* d_out_scores, int64_t* d_out_indices,
+                           int64_t n, int64_t rows_per_split, u32* d_overflow, float* d_out_scores, int64_t* d_out_indices,
                            hipStream_t s) {
     const int QG = ls_gemm_qg(g);
     if (k > LS_GEMM_MAX_K || nsplits * 4 > 256) {
@@ -464,7 +516,7 @@ int ls_launch_batch_select(const u64* d_queues, const u32* d_counts, int cap, in
     }
     hipLaunchKernelGGL(ls_batch_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, d_queues,
                        d_counts, cap, nsplits, (int)(nq_pad / (LS_GEMM_WAVES * 16 * QG)), QG, k, (long long)base,
-                       d_overflow, d_out_scores, (long long*)d_out_indices);
+                       (long long)n, (long long)rows_per_split, d_overflow, d_out_scores, (long long*)d_out_indices);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }

@@ -92,20 +92,20 @@ __host__ __device__ __forceinline__ long long queue_id(int b, int t, int qg, int
     return ((long long)b * LS_GEMM_THREADS + t) * QG + qg;
 }
 
-// top-4 of a lane's sample scores, descending (branch-free insert)
-__device__ __forceinline__ void top4_insert(u32 (&t)[4], u32 v) {
-    u32 a = v > t[3] ? v : t[3];
-    u32 hi = a > t[2] ? a : t[2], lo = a > t[2] ? t[2] : a;
-    t[3] = lo;
-    a = hi;
-    hi = a > t[1] ? a : t[1];
-    lo = a > t[1] ? t[1] : a;
-    t[2] = lo;
-    a = hi;
-    hi = a > t[0] ? a : t[0];
-    lo = a > t[0] ? t[0] : a;
-    t[1] = lo;
-    t[0] = hi;
+// top-4 of a lane's sample scores, descending: branch-free insert on the floats themselves
+// (v_max/v_min pairs); they become ord() keys once, when the kernel stores them
+__device__ __forceinline__ void top4_insert(float (&t)[4], float v) {
+    float a = fmaxf(v, t[3]);
+    t[3] = fminf(a, t[2]);
+    a = fmaxf(a, t[2]);
+    t[2] = fminf(a, t[1]);
+    a = fmaxf(a, t[1]);
+    t[1] = fminf(a, t[0]);
+    t[0] = fmaxf(a, t[0]);
+}
+__device__ __forceinline__ uint4 top4_keys(const float (&t)[4]) {  // 0 = "no sample"
+    return make_uint4(t[0] == -FLT_MAX ? 0u : ls_ord(t[0]), t[1] == -FLT_MAX ? 0u : ls_ord(t[1]),
+                      t[2] == -FLT_MAX ? 0u : ls_ord(t[2]), t[3] == -FLT_MAX ? 0u : ls_ord(t[3]));
 }
 
 template <int CHUNKS, int QG, bool SAMPLE>
@@ -140,38 +140,13 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     long long r_end = r_begin + rows_per_split;
     if (r_end > n) r_end = n;
     const int ntiles_all = r_begin < r_end ? (int)((r_end - r_begin + TM - 1) / TM) : 0;
+#ifdef LS_GEMM_ABL_NOLOOP  // timing ablation: prologue + epilogue only (cap is never negative)
+    const int nt = cap < 0 ? 1 : 0;
+#elif defined(LS_GEMM_ABL_HALF)  // timing ablation: half the tiles
+    const int nt = ((ntiles_all + tile_stride - 1) / tile_stride) / 2;
+#else
     const int nt = (ntiles_all + tile_stride - 1) / tile_stride;  // tiles this launch visits
-
-    // B fragments: group qg holds query qt*8*QPW + wave*QPW + qg*16 + li; k-step kk -> chunk 4kk+qd
-    half8 bq[QG][KS];
-    int qj[QG];
-    bool qvalid[QG];
-    float tauv[QG];
-#pragma unroll
-    for (int g2 = 0; g2 < QG; ++g2) {
-        qj[g2] = (qt * LS_GEMM_WAVES + wave) * QPW + g2 * 16 + li;
-        const u32x4* qrow = qh + (long long)qj[g2] * CHUNKS + qd;
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const u32x4 v = qrow[4 * kk];
-            bq[g2][kk] = __builtin_bit_cast(half8, v);
-        }
-        qvalid[g2] = qj[g2] < nq;
-        tauv[g2] = SAMPLE ? 0.0f : tau[qj[g2]];
-    }
-
-    // private queues of this lane (one per query group), contiguous per lane
-    // entry = {score bits, row relative to the slice}; the select kernel turns it into a key
-    uint2* myq[QG];
-    int cnt[QG];
-    u32 top[QG][4];
-#pragma unroll
-    for (int g2 = 0; g2 < QG; ++g2) {
-        myq[g2] = reinterpret_cast<uint2*>(queues) + queue_id((int)blockIdx.x, tid, g2, QG) * cap;
-        cnt[g2] = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) top[g2][e] = 0u;
-    }
+#endif
 
     // ---- corpus tiles: HBM/L2 -> LDS by DMA (global_load_lds, 16 B per lane), double buffered --
     // Wave w, load j fills the 64 consecutive LDS chunks starting at (w*LOADS + j)*64: chunk Lc
@@ -195,6 +170,51 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
         }
     };
 
+    // The first tile(s) are requested BEFORE the query fragments: the HBM round trip of tile 0
+    // then overlaps the (L2-resident) query loads instead of queueing behind them.
+    constexpr int NB_ALL = (144 * 1024) / TILE_BYTES;  // tiles that fit in the 144 KiB carve-out
+    const bool sample_upfront = SAMPLE && nt > 0 && nt <= NB_ALL && nt <= 3;
+    if (nt > 0) stage(0, 0);
+    if (sample_upfront) {
+        if (nt > 1) stage(tile_stride, 1);
+        if (nt > 2) stage(2 * tile_stride, 2);
+    }
+
+    // B fragments: group qg holds query qt*8*QPW + wave*QPW + qg*16 + li; k-step kk -> chunk 4kk+qd
+    half8 bq[QG][KS];
+    int qj[QG];
+    bool qvalid[QG];
+    float tauv[QG];
+#pragma unroll
+    for (int g2 = 0; g2 < QG; ++g2) {
+        qj[g2] = (qt * LS_GEMM_WAVES + wave) * QPW + g2 * 16 + li;
+        const u32x4* qrow = qh + (long long)qj[g2] * CHUNKS + qd;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+#ifdef LS_GEMM_ABL_NOBQ  // timing ablation: no query-fragment loads
+            const u32x4 v = {(u32)kk, (u32)cap, (u32)nq, (u32)lane};
+#else
+            const u32x4 v = qrow[4 * kk];
+#endif
+            bq[g2][kk] = __builtin_bit_cast(half8, v);
+        }
+        qvalid[g2] = qj[g2] < nq;
+        tauv[g2] = SAMPLE ? 0.0f : tau[qj[g2]];
+    }
+
+    // private queues of this lane (one per query group), contiguous per lane
+    // entry = {score bits, row relative to the slice}; the select kernel turns it into a key
+    uint2* myq[QG];
+    int cnt[QG];
+    float top[QG][4];
+#pragma unroll
+    for (int g2 = 0; g2 < QG; ++g2) {
+        myq[g2] = reinterpret_cast<uint2*>(queues) + queue_id((int)blockIdx.x, tid, g2, QG) * cap;
+        cnt[g2] = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) top[g2][e] = -FLT_MAX;
+    }
+
     // A fragment of k-step kk, row block rb: tile row rb*16 + li, chunk (4kk + qd) ^ li.
     // (4kk + qd) & 15 takes 4 values per lane: 4 precomputed byte offsets + immediates.
     int lo4[4];
@@ -216,8 +236,8 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
         const float s = acc[rb][g2][reg];
         const int lrow = lrow0 + rb * 16 + reg;  // lrow0 already includes 4*qd
         if (SAMPLE) {
-            const u64 key = (qvalid[g2] && r_begin + lrow < r_end) ? ls_make_key(s, 0u) : 0ull;
-            top4_insert(top[g2], (u32)(key >> 32));
+            // NaN never enters (fmaxf/fminf drop it); padded queries and zero-pad rows are masked
+            top4_insert(top[g2], (qvalid[g2] && r_begin + lrow < r_end) ? s : -FLT_MAX);
         } else if (s >= tauv[g2]) {
             const int slot = cnt[g2] < cap ? cnt[g2] : cap - 1;
             myq[g2][slot] = make_uint2(__float_as_uint(s), (u32)lrow);
@@ -275,7 +295,27 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
 
     f32x4v accA[NRB][QG], accB[NRB][QG];  // alternate between consecutive tiles
     auto tile_row0 = [&](int i) { return (i * tile_stride) * TM + 4 * qd; };  // slice-relative
-    if (nt > 0) stage(0, 0);
+    // The sample pass visits only a few tiles, so their DMA latencies would be paid one by one:
+    // when all of them fit in LDS together they are fetched up front and consumed back to back.
+    if (sample_upfront) {
+        __syncthreads();
+        run_tile(accA, accB, false, 0, 0);
+        if (nt > 1) run_tile(accB, accA, true, tile_row0(0), 1);
+        if (nt > 2) run_tile(accA, accB, true, tile_row0(1), 2);
+        const int row0 = tile_row0(nt - 1);
+        if ((nt - 1) & 1) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) check(accB, e, row0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) check(accA, e, row0);
+        }
+#pragma unroll
+        for (int g2 = 0; g2 < QG; ++g2)
+            reinterpret_cast<uint4*>(sample_top)[queue_id((int)blockIdx.x, tid, g2, QG)] =
+                top4_keys(top[g2]);
+        return;
+    }
     __syncthreads();  // the compiler drains the DMA (vmcnt(0)) before the barrier
 #ifdef LS_GEMM_ABL_NOSTAGE  // timing ablation: no tile hand-over (results are garbage)
 #define LS_STAGE(t, b) if (cap < 0) stage(t, b)
@@ -308,8 +348,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     for (int g2 = 0; g2 < QG; ++g2) {
         const long long qid = queue_id((int)blockIdx.x, tid, g2, QG);
         if (SAMPLE) {
-            reinterpret_cast<uint4*>(sample_top)[qid] =
-                make_uint4(top[g2][0], top[g2][1], top[g2][2], top[g2][3]);
+            reinterpret_cast<uint4*>(sample_top)[qid] = top4_keys(top[g2]);
         } else {
             counts[qid] = (u32)(cnt[g2] < cap ? cnt[g2] : cap);
 #ifdef LS_GEMM_ABL_NOCHECK
@@ -330,7 +369,9 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
     const int QG = ls_gemm_qg(g);
     const int nqt = (int)(nq_pad / (LS_GEMM_WAVES * 16 * QG));
     const dim3 grid((unsigned)(nsplits * nqt)), block(LS_GEMM_THREADS);
-    const size_t smem = (size_t)2 * ls_gemm_tile_rows(g) * g.chunks * 16;
+    // two tile buffers; the sample pass takes a third when it fits (all its tiles up front)
+    const size_t tile_bytes = (size_t)ls_gemm_tile_rows(g) * g.chunks * 16;
+    const size_t smem = tile_bytes * ((!d_tau && 3 * tile_bytes <= 144 * 1024) ? 3 : 2);
 #define LS_GEMM_LAUNCH(C, Q, SMP)                                                                 \
     {                                                                                             \
         auto kern = ls_gemm_filter_kernel<C, Q, SMP>;                                             \

@@ -11,6 +11,8 @@ Workloads (BASELINE.json configs):
   c3            N=200k d=384 fp16, nq=1024, k=100   MFMA-bound
   c2p           N=200k d=1024 fp32, nq=1,   k=1000  the reference's real call shape
   c1            N=10k  d=384 fp32, nq=1,    k=50    the reference's CPU-runnable case
+  c4            N=12.5M rows PER GPU (100M at 8 GPUs), d=768 fp16, nq=256, k=100; rows are
+                generated on the device per shard (seed 1234+rank); weak scaling
 
 N > 1: the corpus is row-sharded over the ranks (strong scaling: the same corpus, the same
 queries; every rank ends with the identical merged top-k after one RCCL all-gather).
@@ -38,6 +40,7 @@ WORKLOADS = {
     "c2": (200_000, 384, "f32", 1, 50),
     "c2p": (200_000, 1024, "f32", 1, 1000),
     "c3": (200_000, 384, "f16", 1024, 100),
+    "c4": (12_500_000, 768, "f16", 256, 100),  # rows PER GPU
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA peak
@@ -99,6 +102,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--c4-rows", type=int, default=0, help="rows per GPU for c4 (default 12.5M)")
     args = ap.parse_args()
 
     import torch
@@ -125,13 +129,50 @@ def main():
 
     n, d, dtype, nq, k = WORKLOADS[args.workload]
     elem = 2 if dtype == "f16" else 4
-    corpus = gauss(1234, n, d)
-    queries = gauss(5678, nq, d)
-    lo, hi = shard_bounds(n, world, rank)
-    local = FlatIPIndex.from_array(np.ascontiguousarray(corpus[lo:hi]), dtype=dtype,
-                                   device=local_rank, base=lo)
+    c4 = args.workload == "c4"
+    c4_ref = None
+    if c4:
+        # config 4: every rank generates its own shard in HBM (the 153.6 GB corpus never exists
+        # on the host); queries come from one seed, identical on every rank
+        rows = args.c4_rows or n
+        n, lo, hi = rows * world, rank * rows, (rank + 1) * rows
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1234 + rank)
+        shard = torch.empty((rows, d), dtype=torch.float32, device=dev)
+        for r0 in range(0, rows, 1 << 20):
+            blk = torch.randn((min(1 << 20, rows - r0), d), device=dev, generator=gen)
+            shard[r0:r0 + blk.shape[0]] = blk / blk.norm(dim=1, keepdim=True)
+        gen.manual_seed(5678)
+        tq = torch.randn((nq, d), device=dev, generator=gen)
+        tq /= tq.norm(dim=1, keepdim=True)
+        local = FlatIPIndex.from_device_tensor(shard, dtype=dtype, base=lo)
+        queries = tq.cpu().numpy()
+        corpus = shard[:200_000].cpu().numpy()  # the CPU baseline's bounded sample
+        if not args.no_verify:
+            # torch fp32 reference of the same op on this rank's shard (fp16-rounded operands,
+            # fp32 accumulate), 4 queries, in row blocks: the oracle cannot hold 12.5 M rows
+            nv = 4
+            q16 = tq[:nv].half().float()
+            best_s = torch.full((nv, 0), 0.0, device=dev)
+            best_i = torch.zeros((nv, 0), dtype=torch.int64, device=dev)
+            for r0 in range(0, rows, 1 << 20):
+                sc = q16 @ shard[r0:r0 + (1 << 20)].half().float().T
+                ts, ti = sc.topk(min(k, sc.shape[1]), dim=1)
+                best_s = torch.cat([best_s, ts], 1)
+                best_i = torch.cat([best_i, ti + r0 + lo], 1)
+                ts, sel = best_s.topk(min(k, best_s.shape[1]), dim=1)
+                best_s, best_i = ts, best_i.gather(1, sel)
+            c4_ref = (best_s.cpu().numpy(), best_i.cpu().numpy())
+        del shard
+        torch.cuda.empty_cache()
+    else:
+        corpus = gauss(1234, n, d)
+        queries = gauss(5678, nq, d)
+        lo, hi = shard_bounds(n, world, rank)
+        local = FlatIPIndex.from_array(np.ascontiguousarray(corpus[lo:hi]), dtype=dtype,
+                                       device=local_rank, base=lo)
+        tq = torch.from_numpy(queries).to(dev)
     index = ShardedFlatIPIndex(local, n)
-    tq = torch.from_numpy(queries).to(dev)
 
     # nq <= 16 is the per-query HBM-bound scan path: consecutive steps are pipelined
     # (LS_FLAG_PIPELINE: launch i = scan of step i + one workgroup finalising step i-1, all on
@@ -173,7 +214,19 @@ def main():
 
     # ---- verification on the very arrays that are timed ------------------------------------
     recall = None
-    if not args.no_verify and rank == 0:
+    if not args.no_verify and c4:
+        # this rank's shard result (before the exchange) against the torch reference; the
+        # exchange + merge of an N > 1 run is covered by tests/test_sharded_*.py
+        s, i = local.search_device(tq[:4].contiguous(), k)
+        local.check()
+        rs, ri = c4_ref
+        hit = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(i.cpu().numpy(), ri))
+        recall = hit / float(ri.size)
+        if not np.allclose(s.cpu().numpy(), rs, rtol=0, atol=2e-5):
+            raise SystemExit("c4: scores differ from the torch fp32 reference")
+        step()
+        drain()
+    elif not args.no_verify and rank == 0:
         from oracle import oracle
 
         s, i = step()
@@ -229,7 +282,14 @@ def main():
         roof_src = ("timed region: hipEvent pair around the K back-to-back launches / K "
                     "(kernel boundary included); event-bracketed mean in kernel_ms_bracketed")
     n_local = hi - lo
-    if args.workload == "c3":
+    if c4:  # 256 FLOP/B, just under the ridge (312): HBM-bound; the MFMA fraction rides along
+        ab = algorithmic_bytes(n_local, d, elem, nq, k)
+        ach = ab / (scan_ms_avg * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "mfma_frac": round(2.0 * nq * n_local * d / (scan_ms_avg * 1e-3) / 1e12
+                                   / MFMA_F16_PEAK_TF, 4)}
+    elif args.workload == "c3":
         flops = 2.0 * nq * n_local * d
         ach = flops / (scan_ms_avg * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F16_PEAK_TF,
@@ -239,7 +299,7 @@ def main():
         ach = ab / (scan_ms_avg * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-    roof["kernel"] = "ls_gemm_filter_kernel" if args.workload == "c3" else "ls_scan_kernel"
+    roof["kernel"] = "ls_gemm_filter_kernel" if args.workload in ("c3", "c4") else "ls_scan_kernel"
     roof["kernel_ms"] = round(scan_ms_avg, 5)
     roof["kernel_ms_source"] = roof_src
     roof["kernel_ms_bracketed"] = round(ev_ms, 5)
@@ -265,10 +325,12 @@ def main():
             "ms_per_step": round(dt * 1e3 / args.steps, 5),
             "device_ms_per_step": round(dev_ms / args.steps, 5),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if c4 else "strong",
             "vs_baseline": None,
             "dtype": dtype,
-            "data": "synthetic (standard-normal rows, L2-normalised; corpus seed 1234, query seed 5678)",
+            "data": ("synthetic (standard-normal rows, L2-normalised; generated in HBM per shard, "
+                     "corpus seed 1234+rank, query seed 5678)" if c4 else
+                     "synthetic (standard-normal rows, L2-normalised; corpus seed 1234, query seed 5678)"),
             "config": {"workload": f"{args.workload}: N={n} d={d} {dtype} nq={nq} k={k}",
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
                        "exchange": ("pipelined: all-gather of step i-1 overlaps scan of step i"
@@ -286,7 +348,12 @@ def main():
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(corpus, queries, k, dtype == "f16")
+            cb = cpu_baseline(corpus, queries, k, dtype == "f16")
+            if c4:  # timed on the first 200k rows; a flat scan is linear in the row count
+                cb["value"] = round(cb["value"] * corpus.shape[0] / n, 3)
+                cb["sample"] = (f"first {corpus.shape[0]} of the {n} rows, rate scaled by "
+                                f"{corpus.shape[0]}/{n}; " + cb["sample"])
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1 or rehearse:
         dist.destroy_process_group()

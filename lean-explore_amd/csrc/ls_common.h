@@ -40,7 +40,7 @@ typedef unsigned int u32;
 #define LS_GEMM_MIN_ROWS 32768       // ... and shards at least this big
 #define LS_GEMM_QCAP 32              // entries per private candidate queue
 #define LS_GEMM_SAMPLE_ROWS 128      // sample pass: rows per workgroup
-#define LS_GEMM_MAX_SPLITS 64        // corpus slices (the select kernel walks 4 queues per slice)
+#define LS_GEMM_MAX_SPLITS 128       // corpus slices (the select kernel walks 4 queues per slice)
 
 __host__ __device__ __forceinline__ u32 ls_ord(float f) {
     f = f + 0.0f;  // folds -0.0 into +0.0

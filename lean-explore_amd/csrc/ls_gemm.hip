@@ -406,7 +406,7 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
 // workgroups: 16*nsplits values, <= 4 per thread. 4 radix passes find the j-th largest.
 // Keeping only 4 per lane can only LOWER the result (if one lane held more than 4 of the best
 // j), i.e. let more rows through: tau is a speculative, verified threshold either way.
-#define LS_TAU_PER_THREAD 4
+#define LS_TAU_PER_THREAD 8
 __global__ __launch_bounds__(256) void ls_tau_kernel(const u32* __restrict__ sample_top, int nsplits,
                                                      int nqt, int QG, int nq, int j_rank,
                                                      float* __restrict__ tau) {
@@ -485,22 +485,28 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
     const int q = blockIdx.x, tid = threadIdx.x;
     const int QT = LS_GEMM_WAVES * 16 * QG, QPW = 16 * QG;
     const int qt = q / QT, w = (q % QT) / QPW, qg = (q % QPW) / 16, li = q % 16;
-    // gather: thread t < 4*nsplits owns one of the query's queues: one load for its length, a
-    // block-wide prefix for its slot range in LDS, then its (few) live entries
+    // gather: the query owns 4 queues per slice (<= 512); thread t takes queues t and t + 256:
+    // one load each for their lengths, a block-wide prefix for the slot ranges in LDS, then the
+    // (few) live entries
     const int nqueues = nsplits * 4;
-    u32 c = 0;
-    const u64* qptr = nullptr;
-    long long r_begin = 0;
-    if (tid < nqueues) {
-        const int quarter = tid & 3, split = tid >> 2;
-        r_begin = (long long)split * rows_per_split;
-        const long long qid = queue_id(wg_index(split, qt, nqt), w * 64 + quarter * 16 + li, qg, QG);
-        c = counts[qid];
-        qptr = queues + qid * cap;
+    u32 c[2] = {0, 0};
+    const u64* qptr[2] = {nullptr, nullptr};
+    long long r_begin[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int qi = tid + h * 256;
+        if (qi < nqueues) {
+            const int quarter = qi & 3, split = qi >> 2;
+            r_begin[h] = (long long)split * rows_per_split;
+            const long long qid = queue_id(wg_index(split, qt, nqt), w * 64 + quarter * 16 + li, qg, QG);
+            c[h] = counts[qid];
+            qptr[h] = queues + qid * cap;
+        }
     }
     {
         const int lane = tid & 63, wv = tid >> 6;
-        u32 inc = c;
+        const u32 ct = c[0] + c[1];
+        u32 inc = ct;
         for (int o = 1; o < 64; o <<= 1) {
             const u32 t2 = __shfl_up(inc, o, 64);
             if (lane >= o) inc += t2;
@@ -510,22 +516,28 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
         u32 off = 0;
         for (int i = 0; i < wv; ++i) off += wsum[i];
         if (tid == 0) nkeys = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        const u32 start = off + inc - c;
+        u32 start = off + inc - ct;
         // entries are read four at a time (two 16-byte loads in flight per step): a queue holds
         // ~3 entries on average, so most threads need a single round trip
-        auto put = [&](u32 e, u32 bits, u32 lrow) {
-            if (e < c && start + e < LS_BSEL_KEYS) {
-                const long long row = r_begin + (long long)lrow;
-                keys[start + e] = row < n ? ls_make_key(__uint_as_float(bits), (u32)row) : 0ull;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u32 ch = c[h];
+            const long long rb = r_begin[h];
+            auto put = [&](u32 e, u32 bits, u32 lrow) {
+                if (e < ch && start + e < LS_BSEL_KEYS) {
+                    const long long row = rb + (long long)lrow;
+                    keys[start + e] = row < n ? ls_make_key(__uint_as_float(bits), (u32)row) : 0ull;
+                }
+            };
+            for (u32 e0 = 0; e0 < ch; e0 += 4) {  // cap is a multiple of 4: loads stay in the queue
+                const uint4 a = reinterpret_cast<const uint4*>(qptr[h] + e0)[0];
+                const uint4 b = reinterpret_cast<const uint4*>(qptr[h] + e0)[1];
+                put(e0, a.x, a.y);
+                put(e0 + 1, a.z, a.w);
+                put(e0 + 2, b.x, b.y);
+                put(e0 + 3, b.z, b.w);
             }
-        };
-        for (u32 e0 = 0; e0 < c; e0 += 4) {  // cap is a multiple of 4: the loads stay in the queue
-            const uint4 a = reinterpret_cast<const uint4*>(qptr + e0)[0];
-            const uint4 b = reinterpret_cast<const uint4*>(qptr + e0)[1];
-            put(e0, a.x, a.y);
-            put(e0 + 1, a.z, a.w);
-            put(e0 + 2, b.x, b.y);
-            put(e0 + 3, b.z, b.w);
+            start += ch;
         }
     }
     __syncthreads();
@@ -551,7 +563,7 @@ int ls_launch_batch_select(const u64* d_queues, const u32* d_counts, int cap, in
                            int64_t n, int64_t rows_per_split, u32* d_overflow, float* d_out_scores, int64_t* d_out_indices,
                            hipStream_t s) {
     const int QG = ls_gemm_qg(g);
-    if (k > LS_GEMM_MAX_K || nsplits * 4 > 256) {
+    if (k > LS_GEMM_MAX_K || nsplits * 4 > 512) {
         ls_set_error("batched path: k > %d or too many slices", LS_GEMM_MAX_K);
         return LS_ERR_INVALID_ARG;
     }

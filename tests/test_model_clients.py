@@ -1,0 +1,56 @@
+"""EmbeddingClient / RerankerClient: call surface and invariants of the
+reference clients (reference tests/util/embedding_client_test.py, reranker_client_test.py mock the
+model and check shapes only). Here a tiny random Qwen3 stands in, on CPU."""
+
+import asyncio
+
+import numpy as np
+import pytest
+
+from lean_explore_amd.util import EmbeddingClient, RerankerClient
+from lean_explore_amd.util.synthetic import HashTokenizer, random_qwen3
+
+TINY = dict(vocab_size=512, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+            num_attention_heads=4, num_key_value_heads=2, head_dim=16)
+
+
+def run(coro):
+    return asyncio.new_event_loop().run_until_complete(coro)
+
+
+@pytest.fixture(scope="module")
+def embedder():
+    return EmbeddingClient("tiny-random-qwen3", device="cpu", max_length=32, batch_size=2,
+                           model=random_qwen3(seed=1, **TINY), tokenizer=HashTokenizer(512))
+
+
+def test_embed_shapes_norms_and_prompt(embedder):
+    texts = ["continuous function on a compact set", "prime number", "a b c d e f g"]
+    r = run(embedder.embed(texts))
+    e = np.array(r.embeddings, dtype=np.float32)
+    assert r.texts == texts and r.model == "tiny-random-qwen3" and e.shape == (3, 64)
+    assert np.allclose(np.linalg.norm(e, axis=1), 1.0, atol=1e-5)
+    q = np.array(run(embedder.embed(texts, is_query=True)).embeddings, dtype=np.float32)
+    assert not np.allclose(q, e, atol=1e-3)  # the query prompt changes the encoding
+
+
+def test_embed_is_independent_of_batch_composition(embedder):
+    """Left padding + last-token pooling: a text's vector must not depend on its batch mates."""
+    texts = ["x y z", "one two three four five six seven eight", "p", "q r"]
+    together = embedder.encode(texts)
+    alone = np.concatenate([embedder.encode([t]) for t in texts])
+    assert np.allclose(together, alone, atol=2e-5)
+
+
+def test_reranker_scores_and_batching():
+    tok = HashTokenizer(512)
+    rr = RerankerClient("tiny-random-qwen3", device="cpu", max_length=64, batch_size=2,
+                        model=random_qwen3(causal_lm=True, seed=2, **TINY), tokenizer=tok)
+    docs = ["theorem about groups", "lemma on compactness", "definition of a ring", "x"]
+    r = run(rr.rerank("compact", docs))  # 4 > batch_size: executor batches
+    assert r.query == "compact" and len(r.scores) == 4 and all(0.0 <= s <= 1.0 for s in r.scores)
+    s_sync = rr.rerank_sync("compact", docs).scores  # one batch of 4
+    assert np.allclose(r.scores, s_sync, atol=2e-5)
+    assert run(rr.rerank("compact", [])).scores == []
+    assert rr._format_pair("q", "d") == (
+        "<Instruct>: Find relevant Lean 4 math declarations\n<Query>: q\n<Document>: d")

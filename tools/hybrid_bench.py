@@ -1,0 +1,130 @@
+#!/usr/bin/env python
+"""Config 5 (BASELINE.json configs[4]): the full hybrid pipeline end to end on
+one MI355X --  Service.search(query): embed (PyTorch-ROCm) -> BM25 names + HIP dense top-1000
+-> RRF -> dependency boost -> cross-encoder rerank of the top 50 (PyTorch-ROCm) -> results.
+
+No checkpoints or vocab files can be fetched here: the two models are RANDOM-INITIALISED Qwen3s of
+the production shape (Qwen3-Embedding-0.6B / Qwen3-Reranker-0.6B: 28 layers, hidden 1024), the
+tokenizer hashes whitespace pieces, the corpus is synthetic. The numbers are therefore about
+time, not retrieval quality; the dense/BM25 results themselves are exact (tests/).
+
+    python tools/hybrid_bench.py [--n 200000] [--queries 30] [--layers 28]
+"""
+
+import argparse
+import asyncio
+import json
+import sqlite3
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+WORDS = ("continuous function compact set prime number group ring field ideal module measure "
+         "integral limit sequence series norm metric topology open closed bounded linear map "
+         "kernel image finite infinite sum product order lattice filter basis dimension").split()
+
+
+NW = len(WORDS)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=200_000)
+    ap.add_argument("--queries", type=int, default=30)
+    ap.add_argument("--layers", type=int, default=28)
+    ap.add_argument("--rerank-top", type=int, default=50)
+    args = ap.parse_args()
+
+    import torch
+
+    from lean_explore_amd import loader, search as S
+    from lean_explore_amd.bm25 import NameRetriever
+    from lean_explore_amd.index import FlatIPIndex
+    from lean_explore_amd.util import EmbeddingClient, RerankerClient
+    from lean_explore_amd.util.synthetic import QWEN3_06B, HashTokenizer, random_qwen3
+
+    n, d = args.n, 1024
+    rng = np.random.default_rng(1234)
+    corpus = rng.standard_normal((n, d), dtype=np.float32)
+    corpus /= np.linalg.norm(corpus, axis=1, keepdims=True)
+    names = [f"Mathlib.{WORDS[i % NW].capitalize()}.{WORDS[(i * 7) % NW]}_{WORDS[(i * 13) % NW]}_{i}"
+             for i in range(n)]
+    ids = list(range(1000, 1000 + n))
+
+    tmp = Path(tempfile.mkdtemp(prefix="hybrid_bench_"))
+    db = tmp / "lean_explore.db"
+    con = sqlite3.connect(db)
+    con.execute("CREATE TABLE declarations (id INTEGER PRIMARY KEY, name TEXT, module TEXT, "
+                "docstring TEXT, source_text TEXT, source_link TEXT, dependencies TEXT, "
+                "informalization TEXT, informalization_embedding BLOB)")
+    con.executemany(
+        "INSERT INTO declarations VALUES (?,?,?,?,?,?,?,?,?)",
+        ((ids[i], names[i], "Mathlib.Mod", None, f"theorem t{i} : True", f"http://x/{i}",
+          json.dumps([names[(i * 7 + 1) % n]]) if i % 4 == 0 else None,
+          " ".join(WORDS[(i * (j + 3)) % NW] for j in range(40)), None) for i in range(n)))
+    con.commit()
+    con.close()
+
+    t0 = time.perf_counter()
+    index = FlatIPIndex.from_array(corpus, dtype="f32")
+    lexical = NameRetriever.from_names(ids, names)
+    dt_build = time.perf_counter() - t0
+
+    tok = HashTokenizer(QWEN3_06B["vocab_size"])
+    cfg = dict(num_hidden_layers=args.layers)
+    embedder = EmbeddingClient("random-init Qwen3-Embedding-0.6B shape", device="cuda",
+                               max_length=512, tokenizer=tok,
+                               model=random_qwen3(seed=1, dtype=torch.bfloat16, **cfg))
+    reranker = RerankerClient("random-init Qwen3-Reranker-0.6B shape", device="cuda",
+                              max_length=512, tokenizer=tok, token_true_id=1, token_false_id=2,
+                              model=random_qwen3(causal_lm=True, seed=2, dtype=torch.float16, **cfg))
+    engine = S.SearchEngine(db_path=db, embedding_client=embedder, reranker_client=reranker,
+                            index=index, ids_map=ids, lexical_retriever=lexical)
+    service = S.Service(engine=engine)
+
+    queries = [" ".join(WORDS[(q * (j + 5) + j) % NW] for j in range(8)) for q in range(args.queries)]
+    loop = asyncio.new_event_loop()
+
+    def timed(fn, reps):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(reps):
+            fn(i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps * 1e3
+
+    for q in queries[:3]:  # warm-up (first torch kernels, sqlite cache)
+        loop.run_until_complete(service.search(q, limit=20, rerank_top=args.rerank_top))
+    t_e2e = timed(lambda i: loop.run_until_complete(
+        service.search(queries[i], limit=20, rerank_top=args.rerank_top)), len(queries))
+    t_norr = timed(lambda i: loop.run_until_complete(
+        service.search(queries[i], limit=20, rerank_top=0)), len(queries))
+    # stage timings, each on its own
+    t_embed = timed(lambda i: embedder.encode([queries[i]], is_query=True), len(queries))
+    qv = embedder.encode(queries, is_query=True)
+    t_dense = timed(lambda i: index.search(qv[i:i + 1], 1000), len(queries))
+    t_bm25 = timed(lambda i: lexical(queries[i], 1000), len(queries))
+    docs = [" ".join(WORDS[(i * (j + 3)) % NW] for j in range(48)) for i in range(args.rerank_top)]
+    t_rerank = timed(lambda i: loop.run_until_complete(reranker.rerank(queries[i], docs)),
+                     min(10, len(queries)))
+    print(json.dumps({
+        "config": f"config 5: N={n} d={d} fp32, faiss_k=1000, bm25_k=1000, rerank_top={args.rerank_top}, "
+                  f"limit=20; random-init Qwen3-0.6B-shaped embedder (bf16) and reranker (fp16), "
+                  f"{args.layers} layers; synthetic corpus, hashing tokenizer",
+        "end_to_end_ms_per_query": round(t_e2e, 2), "end_to_end_qps": round(1e3 / t_e2e, 2),
+        "without_rerank_ms_per_query": round(t_norr, 2),
+        "stages_ms": {"embed_query (PyTorch-ROCm)": round(t_embed, 3),
+                      "dense top-1000 (HIP, host API incl. PCIe)": round(t_dense, 3),
+                      "bm25 names x2 top-1000 (HIP, host API)": round(t_bm25, 3),
+                      f"rerank {args.rerank_top} docs (PyTorch-ROCm)": round(t_rerank, 3)},
+        "dense_share_of_end_to_end": round(t_dense / t_e2e, 4),
+        "index_build_s": round(dt_build, 2)}))
+
+
+if __name__ == "__main__":
+    main()

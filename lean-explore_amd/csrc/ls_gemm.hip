@@ -39,38 +39,53 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-// ---- queries -> fp16 [nq_pad, d_pad], normalised if asked, zero padded ---------------------------
+// ---- queries -> fp16 MFMA B fragments, normalised if asked, zero padded ---------------------------
+// Output layout = the order in which ls_gemm_filter_kernel consumes it: the 16-byte chunk c of
+// query q (tile qt, wave w, group g2, li = q % 16) is fragment (qt, w, g2, kk = c / 4), lane
+// (c % 4) * 16 + li. One wave load of a B fragment is then one contiguous 1 KiB read.
+__device__ __forceinline__ long long qfrag_chunk(int q, int c, int QG, int KS) {
+    const int QPW = 16 * QG, QT = LS_GEMM_WAVES * QPW;
+    const int qt = q / QT, w = (q % QT) / QPW, g2 = (q % QPW) / 16, li = q % 16;
+    return ((((long long)(qt * LS_GEMM_WAVES + w) * QG + g2) * KS + (c >> 2)) << 6) + ((c & 3) << 4) + li;
+}
+// One wave per query (4 queries per block): the norm is a wave reduction, every lane converts
+// and stores whole 16-byte chunks.
 __global__ __launch_bounds__(256) void ls_prep_f16_kernel(const float* __restrict__ qin,
-                                                          _Float16* __restrict__ qout, int nq,
-                                                          int d, int d_pad, int normalize,
-                                                          u32* __restrict__ overflow) {
-    __shared__ float red[4];
-    const int qi = blockIdx.x;
-    if (threadIdx.x == 0) overflow[qi] = 0u;  // per-query repair flag, cleared for this batch
-    _Float16* dst = qout + (long long)qi * d_pad;
-    if (qi >= nq) {
-        for (int j = threadIdx.x; j < d_pad; j += 256) dst[j] = (_Float16)0.0f;
-        return;
-    }
+                                                          u32x4* __restrict__ qout, int nq,
+                                                          int nq_pad, int d, int d_pad, int QG,
+                                                          int normalize, u32* __restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq_pad) return;
+    const int KS = d_pad / 32, chunks = d_pad / 8;
+    if (lane == 0) overflow[qi] = 0u;  // per-query repair flag, cleared for this batch
     const float* src = qin + (long long)qi * d;
+    const bool live = qi < nq;
     float inv = 1.0f;
-    if (normalize) {
+    if (normalize && live) {
         float ss = 0.0f;
-        for (int j = threadIdx.x; j < d; j += 256) ss = fmaf(src[j], src[j], ss);
+        for (int j = lane; j < d; j += 64) ss = fmaf(src[j], src[j], ss);
         for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-        __syncthreads();
-        ss = (red[0] + red[1]) + (red[2] + red[3]);
         if (ss > 0.0f) inv = 1.0f / sqrtf(ss);
     }
-    for (int j = threadIdx.x; j < d_pad; j += 256)
-        dst[j] = (_Float16)(j < d ? (normalize ? src[j] * inv : src[j]) : 0.0f);
+    for (int c = lane; c < chunks; c += 64) {
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = c * 8 + e;
+            const float v = (live && j < d) ? (normalize ? src[j] * inv : src[j]) : 0.0f;
+            h[e] = (_Float16)v;
+        }
+        qout[qfrag_chunk(qi, c, QG, KS)] = __builtin_bit_cast(u32x4, h);
+    }
 }
 
+int ls_gemm_qg(const ls_geom& g);
 int ls_launch_prep_f16(const float* d_q, void* d_qh, int64_t nq, int64_t nq_pad, const ls_geom& g,
                        bool normalize, u32* d_overflow, hipStream_t s) {
-    hipLaunchKernelGGL(ls_prep_f16_kernel, dim3((unsigned)nq_pad), dim3(256), 0, s, d_q,
-                       (_Float16*)d_qh, (int)nq, g.d, g.d_pad, normalize ? 1 : 0, d_overflow);
+    hipLaunchKernelGGL(ls_prep_f16_kernel, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, s, d_q,
+                       (u32x4*)d_qh, (int)nq, (int)nq_pad, g.d, g.d_pad, ls_gemm_qg(g),
+                       normalize ? 1 : 0, d_overflow);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
@@ -188,13 +203,14 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
 #pragma unroll
     for (int g2 = 0; g2 < QG; ++g2) {
         qj[g2] = (qt * LS_GEMM_WAVES + wave) * QPW + g2 * 16 + li;
-        const u32x4* qrow = qh + (long long)qj[g2] * CHUNKS + qd;
+        // fragment-ordered by ls_prep_f16_kernel: each load below is one contiguous KiB per wave
+        const u32x4* qfrag = qh + ((((long long)(qt * LS_GEMM_WAVES + wave) * QG + g2) * KS) << 6) + lane;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
 #ifdef LS_GEMM_ABL_NOBQ  // timing ablation: no query-fragment loads
             const u32x4 v = {(u32)kk, (u32)cap, (u32)nq, (u32)lane};
 #else
-            const u32x4 v = qrow[4 * kk];
+            const u32x4 v = qfrag[kk << 6];
 #endif
             bq[g2][kk] = __builtin_bit_cast(half8, v);
         }
@@ -407,6 +423,9 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
 // Keeping only 4 per lane can only LOWER the result (if one lane held more than 4 of the best
 // j), i.e. let more rows through: tau is a speculative, verified threshold either way.
 #define LS_TAU_PER_THREAD 8
+#ifndef LS_TAU_PASSES
+#define LS_TAU_PASSES 2
+#endif
 __global__ __launch_bounds__(256) void ls_tau_kernel(const u32* __restrict__ sample_top, int nsplits,
                                                      int nqt, int QG, int nq, int j_rank,
                                                      float* __restrict__ tau) {
@@ -435,7 +454,10 @@ __global__ __launch_bounds__(256) void ls_tau_kernel(const u32* __restrict__ sam
     for (int i = tid; i < 4 * 256; i += 256) hist[i] = 0;
     __syncthreads();
     u32 pref = 0, pmask = 0, krem = (u32)j_rank;
-    for (int pass = 0; pass < 4; ++pass) {
+    // Only the top 16 bits of the order key are resolved (sign, exponent, 7 mantissa bits): the
+    // result is at most 0.8 % below the exact j-th sample score, i.e. still a valid (slightly
+    // more permissive) speculative threshold, for half the passes.
+    for (int pass = 0; pass < LS_TAU_PASSES; ++pass) {
         const int shift = 24 - 8 * pass;
 #pragma unroll
         for (int j = 0; j < LS_TAU_PER_THREAD; ++j)

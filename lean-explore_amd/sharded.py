@@ -154,82 +154,90 @@ class ShardedFlatIPIndex:
         return out_s, out_i
 
     # ------------------------------------------------------------------ pipelined search
-    # Throughput mode for streams of small query batches (the scan path, nq <= 16). Step i:
-    #   1. local HIP search of step i with LS_FLAG_PIPELINE: its launch also finalises step i-1,
-    #      so after it the packed local result of step i-1 is complete (stream order);
-    #   2. the all-gather of step i-1 is started asynchronously (it runs on the backend's own
-    #      stream: the collective's latency hides under the next scans);
-    #   3. the all-gather of step i-2 is waited for and merged.
-    # Results of a step are valid after `flush()`; `depth` ring slots hold the last steps.
-    def search_device_pipelined(self, q, k: int, *, normalize: bool = False, depth: int = 4):
+    # Throughput mode for streams of small query batches (the scan path, nq <= 16). Steps are
+    # grouped M = exchange_every at a time; a group shares ONE packed buffer
+    # [scores f32 M*nq*k | pad | rows i64 M*nq*k], ONE all-gather and ONE merge launch
+    # (fewer, larger collectives: per step only the local scan launch remains).
+    #   step i : local HIP search with LS_FLAG_PIPELINE into slot i % M of group i // M; its launch
+    #            also finalises step i-1 (stream order), so when the first step of group g+1 has
+    #            been queued, group g's packed results are complete;
+    #   then   : the all-gather of group g is started asynchronously (backend's own stream, under
+    #            the next scans) and group g-1 is waited for and merged.
+    # Results of a step are valid after `flush()`; `depth` groups are kept in a ring.
+    def search_device_pipelined(self, q, k: int, *, normalize: bool = False, depth: int = 4,
+                                exchange_every: int = 8):
         import torch
-        import torch.distributed as dist
 
         nq = q.shape[0]
         if nq > 16:
             raise ValueError("pipelined search is for the scan path (nq <= 16)")
-        sbytes = (nq * k * 4 + 7) & ~7
-        block = sbytes + nq * k * 8
+        M = max(1, int(exchange_every))
         p = self._pipe
-        if p is None or p["key"] != (nq, k, depth, q.device):
+        key = (nq, k, depth, M, q.device, bool(normalize))
+        if p is None or p["key"] != key:
             if p is not None:
                 self.flush()
             dev = q.device
+            sbytes = (M * nq * k * 4 + 7) & ~7
+            block = sbytes + M * nq * k * 8
             p = self._pipe = {
-                "key": (nq, k, depth, dev), "i": 0, "sbytes": sbytes, "block": block,
+                "key": key, "i": 0, "sbytes": sbytes, "block": block, "M": M, "nq": nq, "k": k,
                 "packed": [torch.empty(block, dtype=torch.uint8, device=dev) for _ in range(depth)],
                 "gathered": [torch.empty(self.world * block, dtype=torch.uint8, device=dev)
                              for _ in range(depth)],
-                "out": [(torch.empty((nq, k), dtype=torch.float32, device=dev),
-                         torch.empty((nq, k), dtype=torch.int64, device=dev)) for _ in range(depth)],
-                "work": [None] * depth, "normalize": normalize,
+                "out": [(torch.empty((M * nq, k), dtype=torch.float32, device=dev),
+                         torch.empty((M * nq, k), dtype=torch.int64, device=dev))
+                        for _ in range(depth)],
+                "work": [None] * depth,
             }
         i, depth = p["i"], len(p["packed"])
-        slot = i % depth
-        packed = p["packed"][slot]
-        s_loc = packed[: nq * k * 4].view(torch.float32).view(nq, k)
-        i_loc = packed[sbytes:].view(torch.int64).view(nq, k)
+        grp, j = (i // M) % depth, i % M
+        packed = p["packed"][grp]
+        s_loc = packed[: M * nq * k * 4].view(torch.float32).view(M * nq, k)[j * nq:(j + 1) * nq]
+        i_loc = packed[p["sbytes"]:].view(torch.int64).view(M * nq, k)[j * nq:(j + 1) * nq]
         self.local.search_device(q, k, s_loc, i_loc, normalize=normalize, pipeline=True)
-        if i >= 1:
-            self._start_exchange((i - 1) % depth)
-        if i >= 2:
-            self._finish_exchange((i - 2) % depth)
+        if j == 0 and i >= M:  # the launch above finalised the last step of the previous group
+            self._start_exchange((i // M - 1) % depth)
+            if i >= 2 * M:
+                self._finish_exchange((i // M - 2) % depth, M)
         p["i"] = i + 1
-        return p["out"][slot]
+        out_s, out_i = p["out"][grp]
+        return out_s[j * nq:(j + 1) * nq], out_i[j * nq:(j + 1) * nq]
 
-    def _start_exchange(self, slot: int) -> None:
+    def _start_exchange(self, grp: int) -> None:
         import torch.distributed as dist
 
         p = self._pipe
         if self.world == 1 and not self.force_exchange:
-            p["work"][slot] = "local"
+            p["work"][grp] = "local"
             return
-        p["work"][slot] = dist.all_gather_into_tensor(p["gathered"][slot], p["packed"][slot],
-                                                      group=self.group, async_op=True)
+        p["work"][grp] = dist.all_gather_into_tensor(p["gathered"][grp], p["packed"][grp],
+                                                     group=self.group, async_op=True)
 
-    def _finish_exchange(self, slot: int) -> None:
+    def _finish_exchange(self, grp: int, steps: int) -> None:
+        """Wait for group `grp`'s all-gather and merge its first `steps` steps."""
         import torch
 
         from . import native
 
         p = self._pipe
-        work = p["work"][slot]
+        work = p["work"][grp]
         if work is None:
             return
-        nq, k = p["key"][0], p["key"][1]
-        out_s, out_i = p["out"][slot]
+        M, nq, k = p["M"], p["nq"], p["k"]
+        out_s, out_i = p["out"][grp]
         if work == "local":
-            packed = p["packed"][slot]
-            out_s.copy_(packed[: nq * k * 4].view(torch.float32).view(nq, k))
-            out_i.copy_(packed[p["sbytes"]:].view(torch.int64).view(nq, k))
+            packed = p["packed"][grp]
+            out_s.copy_(packed[: M * nq * k * 4].view(torch.float32).view(M * nq, k))
+            out_i.copy_(packed[p["sbytes"]:].view(torch.int64).view(M * nq, k))
         else:
             work.wait()  # the current stream waits for the collective
-            g = p["gathered"][slot]
+            g = p["gathered"][grp]
             native.check(native.load().ls_merge_topk_strided(
-                g.data_ptr(), g.data_ptr() + p["sbytes"], p["block"], self.world, nq, k,
+                g.data_ptr(), g.data_ptr() + p["sbytes"], p["block"], self.world, steps * nq, k,
                 out_s.data_ptr(), out_i.data_ptr(), g.device.index or 0,
                 torch.cuda.current_stream(g.device).cuda_stream))
-        p["work"][slot] = None
+        p["work"][grp] = None
 
     def flush(self) -> None:
         """Drain the pipeline: the last step's finalize, the outstanding exchanges and merges."""
@@ -239,11 +247,12 @@ class ShardedFlatIPIndex:
         self.local.check()  # launches the pending finalize and synchronises the stream
         if p is None or p["i"] == 0:
             return
-        i, depth = p["i"], len(p["packed"])
-        self._start_exchange((i - 1) % depth)
-        if i >= 2:
-            self._finish_exchange((i - 2) % depth)
-        self._finish_exchange((i - 1) % depth)
+        i, M, depth = p["i"], p["M"], len(p["packed"])
+        last = (i - 1) // M  # group of the newest step; it holds (i - 1) % M + 1 steps
+        if last >= 1:
+            self._finish_exchange((last - 1) % depth, M)  # started, not yet merged
+        self._start_exchange(last % depth)
+        self._finish_exchange(last % depth, (i - 1) % M + 1)
         torch.cuda.synchronize()
         p["i"] = 0
 

@@ -41,7 +41,7 @@ class EmbeddingResponse(BaseModel):
 class EmbeddingClient:
     def __init__(self, model_name: str, device: str | None = None, max_length: int | None = None,
                  batch_size: int | None = None, *, model: Any = None, tokenizer: Any = None,
-                 dtype: Any = None, query_prompt: str = QUERY_PROMPT):
+                 dtype: Any = None, query_prompt: str = QUERY_PROMPT, use_graphs: bool = False):
         import torch
 
         self.model_name = model_name
@@ -60,6 +60,14 @@ class EmbeddingClient:
                                                   else torch.float32))
         self.tokenizer = tokenizer
         self.model = model.to(self.device).eval()
+        from .graphs import GraphRunner
+
+        # hipGraph replay per (batch, padded length) bucket; off by default like the reference
+        self._forward = GraphRunner(self._last_token, enabled=use_graphs)
+
+    def _last_token(self, input_ids, attention_mask):
+        hidden = self.model(input_ids=input_ids, attention_mask=attention_mask).last_hidden_state
+        return hidden[:, -1].float()  # left padding: the last position is the last token
 
     def encode(self, texts: list[str], is_query: bool = False) -> np.ndarray:
         """float32 [len(texts), d], rows L2-normalised (the pipeline's own Normalize layer)."""
@@ -73,8 +81,7 @@ class EmbeddingClient:
                 enc = self.tokenizer(texts[i:i + self.batch_size], padding=True, truncation=True,
                                      max_length=self.max_length or 512, return_tensors="pt")
                 enc = {k: v.to(self.device) for k, v in enc.items()}
-                hidden = self.model(**enc).last_hidden_state
-                pooled = hidden[:, -1].float()  # left padding: the last position is the last token
+                pooled = self._forward(enc["input_ids"], enc["attention_mask"])
                 out.append(torch.nn.functional.normalize(pooled, p=2, dim=1).cpu().numpy())
         return np.concatenate(out, axis=0) if out else np.zeros((0, 0), np.float32)
 

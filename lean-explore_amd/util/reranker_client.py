@@ -41,7 +41,7 @@ class RerankerClient:
                  max_length: int = 512, instruction: str = DEFAULT_INSTRUCTION,
                  batch_size: int | None = None, *, model: Any = None, tokenizer: Any = None,
                  token_true_id: int | None = None, token_false_id: int | None = None,
-                 dtype: Any = None):
+                 dtype: Any = None, use_graphs: bool = False):
         import torch
 
         self.model_name = model_name
@@ -61,10 +61,18 @@ class RerankerClient:
                                                   else torch.float32))
         self.tokenizer = tokenizer
         self.model = model.to(self.device).eval()
+        from .graphs import GraphRunner
+
+        self._forward = GraphRunner(self._last_logits, batch_step=self.batch_size,
+                                    enabled=use_graphs)
         self._token_true_id = (token_true_id if token_true_id is not None
                                else tokenizer.convert_tokens_to_ids("true"))
         self._token_false_id = (token_false_id if token_false_id is not None
                                 else tokenizer.convert_tokens_to_ids("false"))
+
+    def _last_logits(self, input_ids, attention_mask):
+        return self.model(input_ids=input_ids, attention_mask=attention_mask,
+                          logits_to_keep=1).logits[:, -1, :].float()
 
     def _format_pair(self, query: str, document: str) -> str:
         return f"<Instruct>: {self.instruction}\n<Query>: {query}\n<Document>: {document}"
@@ -76,7 +84,7 @@ class RerankerClient:
             enc = self.tokenizer(pairs, padding=True, truncation=True, max_length=self.max_length,
                                  return_tensors="pt")
             enc = {k: v.to(self.device) for k, v in enc.items()}
-            logits = self.model(**enc, logits_to_keep=1).logits[:, -1, :].float()
+            logits = self._forward(enc["input_ids"], enc["attention_mask"])
             stacked = torch.stack([logits[:, self._token_false_id],
                                    logits[:, self._token_true_id]], dim=1)
             return torch.nn.functional.log_softmax(stacked, dim=1)[:, 1].exp().cpu().tolist()

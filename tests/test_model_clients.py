@@ -54,3 +54,27 @@ def test_reranker_scores_and_batching():
     assert run(rr.rerank("compact", [])).scores == []
     assert rr._format_pair("q", "d") == (
         "<Instruct>: Find relevant Lean 4 math declarations\n<Query>: q\n<Document>: d")
+
+
+@pytest.mark.gpu
+def test_graph_replay_matches_eager_on_gpu():
+    """hipGraph replay (bucketed left padding, filler rows) against the eager forward."""
+    import torch
+
+    tok = HashTokenizer(512)
+    texts = ["a b c", "one two three four five six seven eight nine ten eleven", "p q"]
+    outs = []
+    for graphs in (False, True):
+        emb = EmbeddingClient("tiny", device="cuda", max_length=64, batch_size=4, use_graphs=graphs,
+                              model=random_qwen3(seed=1, dtype=torch.float32, **TINY), tokenizer=tok)
+        outs.append((emb.encode(texts), emb.encode(texts[:1], is_query=True), emb._forward.replays))
+    assert outs[0][2] == 0 and outs[1][2] >= 2  # the graphed client really replayed
+    assert np.allclose(outs[0][0], outs[1][0], atol=1e-4)
+    assert np.allclose(outs[0][1], outs[1][1], atol=1e-4)
+    scores = []
+    for graphs in (False, True):
+        rr = RerankerClient("tiny", device="cuda", max_length=64, batch_size=4, use_graphs=graphs,
+                            model=random_qwen3(causal_lm=True, seed=2, dtype=torch.float32, **TINY),
+                            tokenizer=tok, token_true_id=5, token_false_id=9)
+        scores.append(run(rr.rerank("compact", ["d one", "d two two", "d3", "d 4 4 4", "d5", "d6"])).scores)
+    assert np.allclose(scores[0], scores[1], atol=1e-4)

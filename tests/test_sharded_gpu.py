@@ -41,24 +41,28 @@ def _worker(rank, world, port, cfg, ret):
         else:
             _, _, S = oracle.np_search(corpus, q, k, f16=(dtype == "f16"))
             ok = oracle.compare_topk(D, I, Dr, Ir, S)["recall"] == 1.0
-        # the pipelined mode: a stream of single queries, results valid after flush()
+        # the pipelined mode: a stream of single queries, grouped M per exchange, results valid
+        # after flush(); every step still in the ring (depth 4 groups) is checked
         if nq <= 16:
             tq = torch.from_numpy(q).cuda()
-            outs = []
-            for j in range(7):
-                qq = tq[j % nq: j % nq + 1]
-                s_, i_ = ix.search_device_pipelined(qq, k)
-                outs.append((j % nq, s_, i_))
-                if len(outs) >= 3 or j == 6:
-                    pass
-            ix.flush()
-            for (qi, s_, i_) in outs[-3:]:  # the ring keeps the last steps
-                got_s, got_i = s_.cpu().numpy(), i_.cpu().numpy()
-                if ints:
-                    ok = ok and np.array_equal(got_s, Dr[qi:qi + 1]) and np.array_equal(got_i, Ir[qi:qi + 1])
-                else:
-                    ok = ok and oracle.compare_topk(got_s, got_i, Dr[qi:qi + 1], Ir[qi:qi + 1],
-                                                    S[qi:qi + 1])["recall"] == 1.0
+            for M, steps in ((1, 7), (3, 11), (8, 21)):
+                outs = []
+                for j in range(steps):
+                    qq = tq[j % nq: j % nq + 1]
+                    s_, i_ = ix.search_device_pipelined(qq, k, exchange_every=M)
+                    outs.append((j % nq, j // M, s_, i_))
+                ix.flush()
+                newest = (steps - 1) // M
+                for (qi, grp, s_, i_) in outs:
+                    if grp < newest - 3:
+                        continue  # overwritten in the ring
+                    got_s, got_i = s_.cpu().numpy(), i_.cpu().numpy()
+                    if ints:
+                        ok = ok and np.array_equal(got_s, Dr[qi:qi + 1]) \
+                            and np.array_equal(got_i, Ir[qi:qi + 1])
+                    else:
+                        ok = ok and oracle.compare_topk(got_s, got_i, Dr[qi:qi + 1], Ir[qi:qi + 1],
+                                                        S[qi:qi + 1])["recall"] == 1.0
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -106,9 +110,10 @@ def _nccl_single(port, ret):
         Dr, Ir = oracle.c_search(corpus, q, 77)
         ok = np.array_equal(D, Dr) and np.array_equal(I, Ir)
         tq = torch.from_numpy(q).cuda()
-        outs = [ix.search_device_pipelined(tq[j % 4: j % 4 + 1], 77) for j in range(10)]
+        outs = [ix.search_device_pipelined(tq[j % 4: j % 4 + 1], 77, exchange_every=4)
+                for j in range(10)]
         ix.flush()
-        for j in (7, 8, 9):
+        for j in range(10):
             ok = ok and np.array_equal(outs[j][0].cpu().numpy(), Dr[j % 4: j % 4 + 1]) \
                 and np.array_equal(outs[j][1].cpu().numpy(), Ir[j % 4: j % 4 + 1])
         ret[0] = bool(ok)

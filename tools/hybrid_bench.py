@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--queries", type=int, default=30)
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--rerank-top", type=int, default=50)
+    ap.add_argument("--graphs", type=int, default=1, help="replay the model forwards as hipGraphs")
     args = ap.parse_args()
 
     import torch
@@ -78,10 +79,11 @@ def main():
     tok = HashTokenizer(QWEN3_06B["vocab_size"])
     cfg = dict(num_hidden_layers=args.layers)
     embedder = EmbeddingClient("random-init Qwen3-Embedding-0.6B shape", device="cuda",
-                               max_length=512, tokenizer=tok,
+                               max_length=512, tokenizer=tok, use_graphs=bool(args.graphs),
                                model=random_qwen3(seed=1, dtype=torch.bfloat16, **cfg))
     reranker = RerankerClient("random-init Qwen3-Reranker-0.6B shape", device="cuda",
                               max_length=512, tokenizer=tok, token_true_id=1, token_false_id=2,
+                              use_graphs=bool(args.graphs),
                               model=random_qwen3(causal_lm=True, seed=2, dtype=torch.float16, **cfg))
     engine = S.SearchEngine(db_path=db, embedding_client=embedder, reranker_client=reranker,
                             index=index, ids_map=ids, lexical_retriever=lexical)
@@ -98,7 +100,7 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / reps * 1e3
 
-    for q in queries[:3]:  # warm-up (first torch kernels, sqlite cache)
+    for q in queries[:6]:  # warm-up (first torch kernels, sqlite cache)
         loop.run_until_complete(service.search(q, limit=20, rerank_top=args.rerank_top))
     t_e2e = timed(lambda i: loop.run_until_complete(
         service.search(queries[i], limit=20, rerank_top=args.rerank_top)), len(queries))
@@ -113,6 +115,7 @@ def main():
     t_rerank = timed(lambda i: loop.run_until_complete(reranker.rerank(queries[i], docs)),
                      min(10, len(queries)))
     print(json.dumps({
+        "hipgraph_replay": bool(args.graphs),
         "config": f"config 5: N={n} d={d} fp32, faiss_k=1000, bm25_k=1000, rerank_top={args.rerank_top}, "
                   f"limit=20; random-init Qwen3-0.6B-shaped embedder (bf16) and reranker (fp16), "
                   f"{args.layers} layers; synthetic corpus, hashing tokenizer",

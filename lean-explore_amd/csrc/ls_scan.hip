@@ -293,7 +293,14 @@ int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu) {
     }
     const int64_t TR = (int64_t)scan_unroll(g.V) * (LS_WAVE / g.L);
     const int64_t NT = (n + TR - 1) / TR;
-    int64_t b = (NT + LS_SCAN_WAVES - 1) / LS_SCAN_WAVES;  // one tile per wave at most
+    static int tpw = -1;  // minimum tiles per wave. Small shards: fewer blocks -> fewer candidate keys
+    // for the piggy-backed finalize, which bounds the launch there (N=25k: 18.6 -> 11.7 us/step)
+    if (tpw < 0) {
+        const char* e = getenv("LS_SCAN_TPW");
+        tpw = e ? atoi(e) : 4;
+        if (tpw < 1) tpw = 1;
+    }
+    int64_t b = (NT + LS_SCAN_WAVES * tpw - 1) / (LS_SCAN_WAVES * tpw);
     const int64_t cap = (int64_t)n_cu * bpc;
     if (b > cap) b = cap;
     if (b < 1) b = 1;

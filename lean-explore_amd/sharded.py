@@ -173,10 +173,16 @@ class ShardedFlatIPIndex:
             raise ValueError("pipelined search is for the scan path (nq <= 16)")
         M = max(1, int(exchange_every))
         p = self._pipe
-        key = (nq, k, depth, M, q.device, bool(normalize))
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        key = (nq, k, depth, M, q.device, bool(normalize), stream)
         if p is None or p["key"] != key:
             if p is not None:
                 self.flush()
+            if not (q.dtype == torch.float32 and q.dim() == 2 and q.is_contiguous()
+                    and q.shape[1] == self.local.d):
+                raise ValueError("expected a contiguous float32 CUDA tensor [nq, d]")
+            from . import native
+
             dev = q.device
             sbytes = (M * nq * k * 4 + 7) & ~7
             block = sbytes + M * nq * k * 8
@@ -189,20 +195,31 @@ class ShardedFlatIPIndex:
                          torch.empty((M * nq, k), dtype=torch.int64, device=dev))
                         for _ in range(depth)],
                 "work": [None] * depth,
+                # the per-step host path is a bare ctypes call on cached addresses: small shards
+                # are bound by the host's launch rate, not by the GPU
+                "call": native.load().ls_search_device, "check": native.check,
+                "handle": self.local._ensure_built(), "stream": stream,
+                "flags": native.LS_FLAG_PIPELINE | (native.LS_FLAG_NORMALIZE if normalize else 0),
             }
-        i, depth = p["i"], len(p["packed"])
+            slots = []
+            for g in range(depth):
+                base = p["packed"][g].data_ptr()
+                os_, oi_ = p["out"][g]
+                slots.append([(base + j * nq * k * 4, base + sbytes + j * nq * k * 8,
+                               os_[j * nq:(j + 1) * nq], oi_[j * nq:(j + 1) * nq])
+                              for j in range(M)])
+            p["slots"] = slots
+        i = p["i"]
         grp, j = (i // M) % depth, i % M
-        packed = p["packed"][grp]
-        s_loc = packed[: M * nq * k * 4].view(torch.float32).view(M * nq, k)[j * nq:(j + 1) * nq]
-        i_loc = packed[p["sbytes"]:].view(torch.int64).view(M * nq, k)[j * nq:(j + 1) * nq]
-        self.local.search_device(q, k, s_loc, i_loc, normalize=normalize, pipeline=True)
+        s_ptr, i_ptr, out_s, out_i = p["slots"][grp][j]
+        p["check"](p["call"](p["handle"], q.data_ptr(), nq, k, p["flags"], s_ptr, i_ptr,
+                             p["stream"]))
         if j == 0 and i >= M:  # the launch above finalised the last step of the previous group
             self._start_exchange((i // M - 1) % depth)
             if i >= 2 * M:
                 self._finish_exchange((i // M - 2) % depth, M)
         p["i"] = i + 1
-        out_s, out_i = p["out"][grp]
-        return out_s[j * nq:(j + 1) * nq], out_i[j * nq:(j + 1) * nq]
+        return out_s, out_i
 
     def _start_exchange(self, grp: int) -> None:
         import torch.distributed as dist

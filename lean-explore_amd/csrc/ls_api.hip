@@ -434,7 +434,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             for (int i = 0; i < NQ; ++i)
                 LS_HIP(hipMemcpyAsync(ix->d_qpad + (size_t)i * g.d,
                                       d_q + (q0 + std::min(i, real - 1)) * g.d,
-                                      sizeof(float) * g.d, hipMemcpyDeviceToDevice, s));
+                                      sizeof(float) * g.d, hipMemcpyDefault, s));
             qsrc = ix->d_qpad;
         }
         a.d_q = qsrc;
@@ -671,6 +671,11 @@ static int check_search_args(const ls_index* ix, const void* q, int64_t nq, int3
     return LS_OK;
 }
 
+#ifndef LS_ZC_IN_DEFAULT
+#define LS_ZC_IN_DEFAULT 1
+#define LS_ZC_OUT_DEFAULT 1
+#endif
+
 extern "C" {
 
 int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flags,
@@ -697,13 +702,24 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         if ((rc = grow_pinned(&ix->h_out_i, &c2, on)) != LS_OK) return rc;
         ix->h_out_cap = std::min(c1, c2);
     }
+    // Pinned host buffers are device-visible: kernels read the queries from h_q and write the
+    // results into h_out_* over PCIe themselves, which saves the copy commands' serial latency
+    // (LS_ZC_IN / LS_ZC_OUT; measured in tools/hostapi_time.py).
+    static const int zc_in = getenv("LS_ZC_IN") ? atoi(getenv("LS_ZC_IN")) : LS_ZC_IN_DEFAULT;
+    static const int zc_out = getenv("LS_ZC_OUT") ? atoi(getenv("LS_ZC_OUT")) : LS_ZC_OUT_DEFAULT;
+    const bool in_direct = zc_in && nq <= LS_SCAN_MAX_NQ;    // big batches: one bulk copy is better
+    const bool out_direct = zc_out && on <= (size_t)(1 << 16);
     memcpy(ix->h_q, q, qn * sizeof(float));
-    LS_HIP(hipMemcpyAsync(ix->d_qraw, ix->h_q, qn * sizeof(float), hipMemcpyHostToDevice, s));
-    rc = search_on_stream(ix, ix->d_qraw, nq, k, flags & LS_FLAG_NORMALIZE, ix->d_out_s,
-                          ix->d_out_i, s, true);
+    if (!in_direct)
+        LS_HIP(hipMemcpyAsync(ix->d_qraw, ix->h_q, qn * sizeof(float), hipMemcpyHostToDevice, s));
+    rc = search_on_stream(ix, in_direct ? ix->h_q : ix->d_qraw, nq, k, flags & LS_FLAG_NORMALIZE,
+                          out_direct ? ix->h_out_s : ix->d_out_s,
+                          out_direct ? ix->h_out_i : ix->d_out_i, s, true);
     if (rc != LS_OK) return rc;
-    LS_HIP(hipMemcpyAsync(ix->h_out_s, ix->d_out_s, on * sizeof(float), hipMemcpyDeviceToHost, s));
-    LS_HIP(hipMemcpyAsync(ix->h_out_i, ix->d_out_i, on * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (!out_direct) {
+        LS_HIP(hipMemcpyAsync(ix->h_out_s, ix->d_out_s, on * sizeof(float), hipMemcpyDeviceToHost, s));
+        LS_HIP(hipMemcpyAsync(ix->h_out_i, ix->d_out_i, on * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    }
     LS_HIP(hipStreamSynchronize(s));
     memcpy(out_scores, ix->h_out_s, on * sizeof(float));
     memcpy(out_indices, ix->h_out_i, on * sizeof(int64_t));

@@ -100,11 +100,14 @@ __device__ __forceinline__ void wg_coords(int b, int nqt, int* split, int* qt) {
 __host__ __device__ __forceinline__ int wg_index(int split, int qt, int nqt) {
     return (((split >> 3) * nqt + qt) << 3) | (split & 7);
 }
-// Queue of (workgroup b, thread t, query group qg). Query q of a launch with QG groups per wave:
-// tile qt = q / (128*QG), wave w = (q % (128*QG)) / (16*QG), group qg = (q % (16*QG)) / 16,
-// li = q % 16; its 4 lanes in every workgroup are t = w*64 + quarter*16 + li.
-__host__ __device__ __forceinline__ long long queue_id(int b, int t, int qg, int QG) {
-    return ((long long)b * LS_GEMM_THREADS + t) * QG + qg;
+// Query q of a launch with QG groups per wave lives in tile qt = q / (128*QG), wave
+// w = (q % (128*QG)) / (16*QG), group qg = (q % (16*QG)) / 16, li = q % 16; in every workgroup of
+// its tile 4 lanes (quarter = 0..3) own a private queue for it. Queues, their lengths and the
+// sample tops are stored QUERY-MAJOR, [query][slice][quarter]: everything the tau and select
+// kernels read for one query is contiguous (they are the consumers with a dependent round trip;
+// the producers' scattered 16-byte stores cost nothing).
+__host__ __device__ __forceinline__ long long queue_id(int q, int split, int quarter, int nsplits) {
+    return ((long long)q * nsplits + split) * 4 + quarter;
 }
 
 // top-4 of a lane's sample scores, descending: branch-free insert on the floats themselves
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     const int qd = lane >> 4, li = lane & 15;  // quarter (k-chunk / row group), index in group
     int split, qt;
     wg_coords((int)blockIdx.x, nqt, &split, &qt);
+    const int nsplits = (int)gridDim.x / nqt;
     const long long r_begin = (long long)split * rows_per_split;
     long long r_end = r_begin + rows_per_split;
     if (r_end > n) r_end = n;
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     float top[QG][4];
 #pragma unroll
     for (int g2 = 0; g2 < QG; ++g2) {
-        myq[g2] = reinterpret_cast<uint2*>(queues) + queue_id((int)blockIdx.x, tid, g2, QG) * cap;
+        myq[g2] = reinterpret_cast<uint2*>(queues) + queue_id(qj[g2], split, qd, nsplits) * cap;
         cnt[g2] = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) top[g2][e] = -FLT_MAX;
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
         }
 #pragma unroll
         for (int g2 = 0; g2 < QG; ++g2)
-            reinterpret_cast<uint4*>(sample_top)[queue_id((int)blockIdx.x, tid, g2, QG)] =
+            reinterpret_cast<uint4*>(sample_top)[queue_id(qj[g2], split, qd, nsplits)] =
                 top4_keys(top[g2]);
         return;
     }
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     }
 #pragma unroll
     for (int g2 = 0; g2 < QG; ++g2) {
-        const long long qid = queue_id((int)blockIdx.x, tid, g2, QG);
+        const long long qid = queue_id(qj[g2], split, qd, nsplits);
         if (SAMPLE) {
             reinterpret_cast<uint4*>(sample_top)[qid] = top4_keys(top[g2]);
         } else {
@@ -436,9 +440,9 @@ __global__ __launch_bounds__(256) void ls_tau_kernel(const u32* __restrict__ sam
         if (tid == 0) tau[q] = FLT_MAX;  // padded query: nothing passes
         return;
     }
-    const int QT = LS_GEMM_WAVES * 16 * QG, QPW = 16 * QG;
-    const int qt = q / QT, w = (q % QT) / QPW, qg = (q % QPW) / 16, li = q % 16;
-    const int total = nsplits * 4 * 4;  // values of this query
+    (void)nqt;
+    (void)QG;
+    const int total = nsplits * 4 * 4;  // values of this query, contiguous
     u32 v[LS_TAU_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < LS_TAU_PER_THREAD; ++j) {
@@ -446,8 +450,7 @@ __global__ __launch_bounds__(256) void ls_tau_kernel(const u32* __restrict__ sam
         u32 x = 0;
         if (idx < total) {
             const int e = idx & 3, sq = idx >> 2, quarter = sq & 3, split = sq >> 2;
-            const int b = wg_index(split, qt, nqt);
-            x = sample_top[queue_id(b, w * 64 + quarter * 16 + li, qg, QG) * 4 + e];
+            x = sample_top[queue_id(q, split, quarter, nsplits) * 4 + e];  // == q*total + idx
         }
         v[j] = x;
     }
@@ -505,8 +508,8 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
     __shared__ u32 nkeys;
     __shared__ u32 wsum[8];
     const int q = blockIdx.x, tid = threadIdx.x;
-    const int QT = LS_GEMM_WAVES * 16 * QG, QPW = 16 * QG;
-    const int qt = q / QT, w = (q % QT) / QPW, qg = (q % QPW) / 16, li = q % 16;
+    (void)nqt;
+    (void)QG;
     // gather: the query owns 4 queues per slice (<= 512); thread t takes queues t and t + 256:
     // one load each for their lengths, a block-wide prefix for the slot ranges in LDS, then the
     // (few) live entries
@@ -514,15 +517,21 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
     u32 c[2] = {0, 0};
     const u64* qptr[2] = {nullptr, nullptr};
     long long r_begin[2] = {0, 0};
+    // the first four entries of each queue are fetched together with its length (their address
+    // does not depend on it): one round trip instead of two for the typical <= 4-entry queue
+    uint4 ea[2], eb[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int qi = tid + h * 256;
+        ea[h] = eb[h] = make_uint4(0, 0, 0, 0);
         if (qi < nqueues) {
             const int quarter = qi & 3, split = qi >> 2;
             r_begin[h] = (long long)split * rows_per_split;
-            const long long qid = queue_id(wg_index(split, qt, nqt), w * 64 + quarter * 16 + li, qg, QG);
+            const long long qid = queue_id(q, split, quarter, nsplits);
             c[h] = counts[qid];
             qptr[h] = queues + qid * cap;
+            ea[h] = reinterpret_cast<const uint4*>(qptr[h])[0];
+            eb[h] = reinterpret_cast<const uint4*>(qptr[h])[1];
         }
     }
     {
@@ -539,8 +548,6 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
         for (int i = 0; i < wv; ++i) off += wsum[i];
         if (tid == 0) nkeys = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         u32 start = off + inc - ct;
-        // entries are read four at a time (two 16-byte loads in flight per step): a queue holds
-        // ~3 entries on average, so most threads need a single round trip
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const u32 ch = c[h];
@@ -551,9 +558,12 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
                     keys[start + e] = row < n ? ls_make_key(__uint_as_float(bits), (u32)row) : 0ull;
                 }
             };
+            uint4 a = ea[h], b = eb[h];
             for (u32 e0 = 0; e0 < ch; e0 += 4) {  // cap is a multiple of 4: loads stay in the queue
-                const uint4 a = reinterpret_cast<const uint4*>(qptr[h] + e0)[0];
-                const uint4 b = reinterpret_cast<const uint4*>(qptr[h] + e0)[1];
+                if (e0) {
+                    a = reinterpret_cast<const uint4*>(qptr[h] + e0)[0];
+                    b = reinterpret_cast<const uint4*>(qptr[h] + e0)[1];
+                }
                 put(e0, a.x, a.y);
                 put(e0 + 1, a.z, a.w);
                 put(e0 + 2, b.x, b.y);
@@ -570,7 +580,13 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
     }
     if (overflow[q]) return;  // a queue overflowed in the GEMM pass
     __syncthreads();
+#if defined(LS_BSEL_ABL) && LS_BSEL_ABL == 1  // timing ablation: gather only
+    if (cap > 0) return;
+#endif
     const int nvalid = lds_topk(keys, cnt, k, res, tmp, hist, misc, tid, 256);
+#if defined(LS_BSEL_ABL) && LS_BSEL_ABL == 2  // timing ablation: no output
+    if (cap > 0) return;
+#endif
     __syncthreads();
     if (nvalid < k && tid == 0) overflow[q] = 2u;  // the speculative tau let < k rows through
     for (int i = tid; i < k; i += 256) {

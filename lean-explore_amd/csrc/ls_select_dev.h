@@ -176,6 +176,9 @@ static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* t
         pmask |= 255u << shift;
         krem = ms[1];
         neq = ms[2];
+        // every key of the selected bin is needed: the prefix alone (low bits 0) already is a
+        // threshold that admits exactly kk keys, so the remaining passes are skipped
+        if (neq == krem) break;
     }
     const u32 T_hi = pref;
     u32 T_lo = 0;

@@ -374,6 +374,9 @@ def main():
                                           "scan + select launches per query")},
             "effective_gbs": round(algorithmic_bytes(n_local, d, elem, nq, k) * args.steps / dt / 1e9, 1),
             "recall_at_k": recall,
+            # queries the batched path handed to the exact scan path (speculative threshold let
+            # < k rows through, or a candidate queue overflowed) over the whole run
+            "repaired_queries": local.debug_counter(8) if (nq > 16 and dtype == "f16") else 0,
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:

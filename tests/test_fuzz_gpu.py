@@ -1,0 +1,72 @@
+"""Randomised parity sweep: random (n, d, k, nq, storage, normalise, data kind) against the
+oracle. Integer-valued data makes every product and partial sum exact in fp32 and fp16, so those
+cases are compared bit for bit (scores AND tie order); Gaussian data goes through compare_topk.
+Seeded and bounded (LS_FUZZ_SECONDS, default 45 s of cases) so the GPU suite stays short."""
+
+import os
+import time
+
+import numpy as np
+import pytest
+
+from lean_explore_amd.index import FlatIPIndex
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rng):
+    kind = rng.choice(["int", "int", "gauss", "clustered"])
+    dtype = rng.choice(["f32", "f16"])
+    d = int(rng.choice([1, 3, 8, 17, 64, 100, 128, 200, 384, 385, 512, 768, 1000, 1024]))
+    big = rng.random() < 0.35
+    n = int(rng.integers(40_000, 260_000)) if big else int(rng.integers(1, 6000))
+    nq = int(rng.choice([1, 1, 2, 3, 5, 8, 9, 17, 33, 130, 300, 520]))
+    k = int(rng.choice([1, 2, 7, 50, 100, 128, 129, 500, 1000, 2048]))
+    while n * d * nq > 1.2e10:  # keep the CPU oracle in seconds
+        nq = max(1, nq // 2)
+    return kind, dtype, n, d, nq, k, bool(rng.random() < 0.3)
+
+
+def test_random_parity_sweep():
+    budget = float(os.environ.get("LS_FUZZ_SECONDS", "45"))
+    rng = np.random.default_rng(int(os.environ.get("LS_FUZZ_SEED", "20260928")))
+    t0, cases = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget or cases < 8:
+        kind, dtype, n, d, nq, k, normalize = _case(rng)
+        seed = int(rng.integers(1 << 30))
+        if kind == "int":
+            corpus, q = H.int_corpus(seed, n, d), H.int_corpus(seed + 1, nq, d)
+            normalize = False  # normalisation would leave the exact-integer regime
+        elif kind == "gauss":
+            corpus, q = H.gauss(seed, n, d), H.gauss(seed + 1, nq, d)
+        else:  # a tight cluster: most rows nearly identical, top-k decided by tiny differences
+            base = H.gauss(seed, 1, d)
+            corpus = (base + 1e-3 * H.gauss(seed + 2, n, d, normalize=False)).astype(np.float32)
+            q = H.gauss(seed + 1, nq, d)
+        label = f"{kind} {dtype} n={n} d={d} nq={nq} k={k} norm={normalize} seed={seed}"
+        ix = FlatIPIndex.from_array(corpus, dtype=dtype)
+        try:
+            if min(k, n) > 2048:
+                continue
+            D, I = ix.search(q, k, normalize=normalize)
+        finally:
+            ix.close()
+        f16 = dtype == "f16"
+        Dr, Ir = oracle.c_search(corpus, q, k, f16=f16, normalize=normalize, fast=True)
+        if kind == "int":
+            assert np.array_equal(I, Ir), label
+            assert np.array_equal(D, Dr), label
+        else:
+            qn = oracle.c_normalize_l2(q) if normalize else q
+            _, _, S = oracle.np_search(corpus, qn, k, f16=f16)
+            try:
+                # fp16 + normalise: the rounded query itself depends on the norm's last ulp
+                tie = 1e-5 if (f16 and normalize) or kind == "clustered" else 2e-6
+                tol = 1e-5 if not (f16 and normalize) else 2e-4
+                oracle.compare_topk(D, I, Dr, Ir, S, tie_eps=tie, score_tol=tol)
+            except AssertionError as e:
+                raise AssertionError(f"{label}: {e}") from None
+        cases += 1
+    assert cases >= 8

@@ -77,6 +77,79 @@ __device__ __forceinline__ void block_bitonic_desc(u64* a, int m, int tid, int n
     __syncthreads();
 }
 
+// ---- the same network with the keys in registers ---------------------------------------------
+// NT threads hold E keys each (element index = e*NT + tid; NT*E >= m, missing elements are 0 and
+// sink to the end). Strides >= NT are compare-exchanges inside a thread, strides < 64 are lane
+// shuffles, and only strides 64 .. NT/2 go through LDS (a[] doubles as the exchange buffer and
+// receives the result). 1024 keys on 1024 threads: 10 LDS exchanges instead of 55 LDS stages.
+template <int NT, int E>
+__device__ __forceinline__ void block_bitonic_desc_regs(u64* a, int m, int tid) {
+    // E == 1 also serves m < NT: threads >= m idle (they still reach every barrier)
+    const bool active = E > 1 || tid < m;
+    u64 v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = active ? a[e * NT + tid] : 0ull;
+    __syncthreads();
+    for (int k2 = 2; k2 <= m; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            if (j >= NT) {  // partner in the same thread (compile-time register indices only)
+#pragma unroll
+                for (int JE = E / 2; JE >= 1; JE >>= 1) {
+                    if (j != JE * NT) continue;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if ((e & JE) != 0) continue;
+                        const int idx = e * NT + tid;
+                        const bool desc = (idx & k2) == 0;
+                        const u64 lo = v[e], hi = v[e | JE];
+                        const bool swap = (lo < hi) == desc;
+                        v[e] = swap ? hi : lo;
+                        v[e | JE] = swap ? lo : hi;
+                    }
+                }
+            } else if (j < 64) {  // partner lane
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int idx = e * NT + tid;
+                    const u64 other = __shfl_xor(v[e], j, 64);
+                    const bool take_max = ((idx & k2) == 0) == ((idx & j) == 0);
+                    v[e] = ((other > v[e]) == take_max) ? other : v[e];
+                }
+            } else {  // partner in another wave: through LDS
+                if (active) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) a[e * NT + tid] = v[e];
+                }
+                __syncthreads();
+                if (active) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int idx = e * NT + tid;
+                        const u64 other = a[idx ^ j];
+                        const bool take_max = ((idx & k2) == 0) == ((idx & j) == 0);
+                        v[e] = ((other > v[e]) == take_max) ? other : v[e];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) a[e * NT + tid] = v[e];
+    }
+    __syncthreads();
+}
+// m: power of two. Dispatch on the keys-per-thread count; anything else takes the LDS network.
+template <int NT>
+__device__ __forceinline__ void lds_sort_desc(u64* a, int m, int tid) {
+    if (m <= NT) block_bitonic_desc_regs<NT, 1>(a, m, tid);
+    else if (m == 2 * NT) block_bitonic_desc_regs<NT, 2>(a, m, tid);
+    else if (m == 4 * NT) block_bitonic_desc_regs<NT, 4>(a, m, tid);
+    else if (m == 8 * NT) block_bitonic_desc_regs<NT, 8>(a, m, tid);
+    else block_bitonic_desc(a, m, tid, NT);
+}
+
 __device__ __forceinline__ int next_pow2(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -144,6 +217,12 @@ __device__ __forceinline__ void wave_hist_add(u32* hist, u32 digit, bool active,
 // descending, kk = min(k, #non-zero). tmp: LDS scratch of LS_RES_CAP keys. k <= LS_RES_CAP.
 // hist: 8 * 256 counters (one histogram per radix pass, zeroed here), misc: 8 * 8 words.
 // The caller must have synchronised the workgroup after writing keys.
+#ifdef LS_FIN_TIMING  // developer instrumentation: phase stamps (100 MHz ticks) of one finalize
+__device__ unsigned long long g_fin_stamp[8];
+#define LS_STAMP(i) do { if (tid == 0) g_fin_stamp[i] = wall_clock64(); } while (0)
+#else
+#define LS_STAMP(i) do {} while (0)
+#endif
 static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* tmp, u32* hist, u32* misc,
                         int tid, int nt) {
     if (k > cnt) k = cnt;
@@ -180,6 +259,7 @@ static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* t
         // threshold that admits exactly kk keys, so the remaining passes are skipped
         if (neq == krem) break;
     }
+    LS_STAMP(2);
     const u32 T_hi = pref;
     u32 T_lo = 0;
     if (neq > krem) {  // several candidates share the k-th score: split them on the row half
@@ -211,20 +291,31 @@ static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* t
         if (key != 0ull && key >= T) dst[atomicAdd(&misc[7 * 8 + 7], 1u)] = key;
     }
     __syncthreads();
+    LS_STAMP(3);
     if (kk <= 256) {  // order by counting: rank = number of larger survivors
-        if (tid < kk) {
-            const u64 mine = tmp[tid];
-            int rank = 0;
-            for (int j = 0; j < kk; ++j) rank += tmp[j] > mine;
-            res[rank] = mine;
+        // the 1024-thread finalize lets 4 threads share one survivor (each counts a slice of the
+        // others; the slices are summed by lane shuffles): the serial LDS walk is kk / 4 long
+        const int G = nt >= 1024 ? 4 : 1;  // (measured: sharing does not pay with 256 threads)
+        const int me = tid / G, part = tid % G;
+        u64 mine = 0;
+        int rank = 0;
+        if (me < kk) {
+            mine = tmp[me];
+            for (int j = part; j < kk; j += G) rank += tmp[j] > mine;
         }
+        if (G >= 2) rank += __shfl_xor(rank, 1, 64);
+        if (G == 4) rank += __shfl_xor(rank, 2, 64);
+        if (me < kk && part == 0) res[rank] = mine;
         __syncthreads();
     } else {
         const int m = next_pow2(kk);
         for (int i = kk + tid; i < m; i += nt) res[i] = 0ull;
         __syncthreads();
-        block_bitonic_desc(res, m, tid, nt);
+        if (nt == 1024) lds_sort_desc<1024>(res, m, tid);
+        else if (nt == 256) lds_sort_desc<256>(res, m, tid);
+        else block_bitonic_desc(res, m, tid, nt);
     }
+    LS_STAMP(4);
     return kk;
 }
 
@@ -334,6 +425,7 @@ static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem
     u32* hist = reinterpret_cast<u32*>(red + 16);
     u32* misc = hist + 8 * 256;
 
+    LS_STAMP(0);
     const int mc = p.blocks * p.kprime;
     int nvalid = 0;
     bool done = (p.n <= 0);
@@ -354,6 +446,7 @@ static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem
         __syncthreads();
         mb = 0;
         for (int w = 0; w < NT / 64; ++w) mb = red[w] > mb ? red[w] : mb;
+        LS_STAMP(1);
         nvalid = lds_topk(keys, mc, keff, res, tmp, hist, misc, tid, NT);
         T = (nvalid == keff && keff > 0) ? res[keff - 1] : 0ull;
         done = (mb == 0ull) || (T != 0ull && mb < T);
@@ -392,4 +485,9 @@ static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem
         p.out_scores[i] = ls_key_score(key);
         p.out_indices[i] = ls_key_index(key, p.base);
     }
+    LS_STAMP(5);
+#ifdef LS_FIN_TIMING
+    if (tid == 0 && p.counters)
+        for (int i = 0; i < 5; ++i) p.counters[2 + i] = (u32)(g_fin_stamp[i + 1] - g_fin_stamp[i]);
+#endif
 }

@@ -6,9 +6,11 @@ import sys; sys.path.insert(0,'/root/repo')
 import numpy as np
 from lean_explore_amd.index import FlatIPIndex
 from tests import helpers as H
-c=H.gauss(1234,200000,384); q=H.gauss(5678,1,384)
+import os
+D=int(os.environ.get("HT_D","384")); K=int(os.environ.get("HT_K","50"))
+c=H.gauss(1234,200000,D); q=H.gauss(5678,1,D)
 ix=FlatIPIndex.from_array(c)
-for _ in range(400): ix.search(q,50)
+for _ in range(400): ix.search(q,K)
 PY
 rocprofv3 --kernel-trace --output-format csv -d /tmp/ht -o t -- python /tmp/ht.py >/dev/null 2>&1
 python - <<'PY'

@@ -484,7 +484,9 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
 // ---- batched MFMA path (ls_gemm.hip) ---------------------------------------------------------------
 static bool batched_eligible(const ls_index* ix, int64_t nq, int32_t k) {
     return ix->opt_gemm && ix->dtype == LS_DTYPE_F16 && nq > LS_SCAN_MAX_NQ &&
-           k <= LS_GEMM_MAX_K && ix->g.chunks <= LS_GEMM_MAX_CHUNKS && ix->n >= LS_GEMM_MIN_ROWS;
+           k <= LS_GEMM_MAX_K && ix->g.chunks <= LS_GEMM_MAX_CHUNKS &&
+           (ix->n >= LS_GEMM_MIN_ROWS ||
+            (ix->n >= LS_GEMM_MIN_ROWS_BIGNQ && nq >= LS_GEMM_BIGNQ));
 }
 
 // Re-run the queries of the last batched call whose candidate queues overflowed (or were short)

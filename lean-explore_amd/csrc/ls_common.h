@@ -37,7 +37,9 @@ typedef unsigned int u32;
 #define LS_GEMM_WG_PER_CU (8 / LS_GEMM_WAVES)
 #define LS_GEMM_MAX_K 128            // batched path handles k <= this (larger k: scan path)
 #define LS_GEMM_MAX_CHUNKS 128       // ... and stored rows <= 2 KiB (d <= 1024 fp16)
-#define LS_GEMM_MIN_ROWS 32768       // ... and shards at least this big
+#define LS_GEMM_MIN_ROWS 32768       // ... and shards at least this big,
+#define LS_GEMM_MIN_ROWS_BIGNQ 8192  // or this big when the batch has >= LS_GEMM_BIGNQ queries
+#define LS_GEMM_BIGNQ 128            // (small shards of a many-GPU run: ~60 us fixed vs nq/8 scans)
 #define LS_GEMM_QCAP 32              // entries per private candidate queue
 #define LS_GEMM_SAMPLE_ROWS 128      // sample pass: rows per workgroup
 #define LS_GEMM_MAX_SPLITS 128       // corpus slices (the select kernel walks 4 queues per slice)

@@ -22,6 +22,8 @@ def _case(rng):
     d = int(rng.choice([1, 3, 8, 17, 64, 100, 128, 200, 384, 385, 512, 768, 1000, 1024]))
     big = rng.random() < 0.35
     n = int(rng.integers(40_000, 260_000)) if big else int(rng.integers(1, 6000))
+    if rng.random() < 0.2:
+        n = int(rng.integers(7_000, 40_000))  # small shards of the batched path
     nq = int(rng.choice([1, 1, 2, 3, 5, 8, 9, 17, 33, 130, 300, 520]))
     k = int(rng.choice([1, 2, 7, 50, 100, 128, 129, 500, 1000, 2048]))
     while n * d * nq > 1.2e10:  # keep the CPU oracle in seconds
@@ -62,8 +64,9 @@ def test_random_parity_sweep():
             qn = oracle.c_normalize_l2(q) if normalize else q
             _, _, S = oracle.np_search(corpus, qn, k, f16=f16)
             try:
-                # fp16 + normalise: the rounded query itself depends on the norm's last ulp
-                tie = 1e-5 if (f16 and normalize) or kind == "clustered" else 2e-6
+                # fp16 + normalise: the ROUNDED query depends on the norm's last ulp; one flipped
+                # fp16 rounding moves a score by ~ulp16(q_j)*c_j (1e-5..1e-4 for small d)
+                tie = 1e-4 if (f16 and normalize) else (1e-5 if kind == "clustered" else 2e-6)
                 tol = 1e-5 if not (f16 and normalize) else 2e-4
                 oracle.compare_topk(D, I, Dr, Ir, S, tie_eps=tie, score_tol=tol)
             except AssertionError as e:

@@ -29,6 +29,9 @@
 // path, so the result is always exact.
 #include "ls_select_dev.h"
 
+#ifndef LS_GEMM_PF
+#define LS_GEMM_PF 1
+#endif
 #ifndef LS_GEMM_CHECK_NUM
 #define LS_GEMM_CHECK_NUM 1
 #define LS_GEMM_CHECK_DEN 1
@@ -269,14 +272,21 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // the PREVIOUS tile's accumulators are filtered CPK elements per k-step.
     auto run_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], bool have_prev,
                         int prev_row0, int buf) {
-        half8 a[2][NRB];
+        // A fragments are read LS_GEMM_PF k-steps ahead of their MFMAs
+        constexpr int PF = LS_GEMM_PF, NA = PF + 1;
+        half8 a[NA][NRB];
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) a[0][rb] = a_frag(buf, rb, 0);
+        for (int p0 = 0; p0 < PF; ++p0) {
+            if (p0 < KS) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) a[p0][rb] = a_frag(buf, rb, p0);
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            if (kk + 1 < KS) {
+            if (kk + PF < KS) {
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) a[(kk + 1) & 1][rb] = a_frag(buf, rb, kk + 1);
+                for (int rb = 0; rb < NRB; ++rb) a[(kk + PF) % NA][rb] = a_frag(buf, rb, kk + PF);
             }
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                     } else {
                         c = cur[rb][g2];
                     }
-                    cur[rb][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk & 1][rb], bq[g2][kk],
+                    cur[rb][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk % NA][rb], bq[g2][kk],
                                                                         c, 0, 0, 0);
                 }
             }

@@ -127,10 +127,17 @@ int ls_merge_topk_strided(const void* d_scores_in, const void* d_indices_in,
 int ls_set_profiling(ls_index* index, int32_t enabled);
 int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
 
-/* Test / tuning hooks. option 0: force the number of keys k' each scan workgroup emits
- * (0 = automatic); option 1: force the finalize kernel's general
- * exact path; option 2: alternate sweep direction; option 3: two-lane overlap (default on). counter 0: searches whose finalize
- * step left the fast path (rescue or general); counter 1: those that took the general path. */
+/* Test / tuning hooks.
+ * option 0: force the number of keys k' each scan workgroup emits (0 = automatic);
+ * option 1: force the finalize step's general exact path; option 2: alternate the sweep
+ * direction of consecutive scans (default off); option 3: piggy-back the finalize of a query
+ * group on the next scan launch (default on); option 4: allow the batched MFMA path (default on);
+ * option 5: speculative, verified sample threshold on the batched path (default on; off = the
+ * certified k-th sample score); option 6: several queries per corpus pass on the scan path
+ * (default on).
+ * counter 0: searches whose finalize step left the fast path (rescue or general); counter 1:
+ * those that took the general path; counter 8: queries of batched calls that were repaired by
+ * the exact scan path. */
 int ls_debug_option(ls_index* index, int32_t which, int32_t value);
 int64_t ls_debug_counter(ls_index* index, int32_t which);
 /* Copy the score vector S[0..count) of the most recent per-query scan to host memory. */

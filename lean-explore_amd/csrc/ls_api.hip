@@ -41,9 +41,8 @@ struct ls_index {
 
     // scratch (grown on demand, reused by every search on this handle)
     float* d_qraw = nullptr;   size_t qraw_cap = 0;   // floats
-    float* d_qprep = nullptr;  size_t qprep_cap = 0;  // floats
-    // per-query scan scratch, LS_NSETS copies so that consecutive queries may overlap on
-    // different streams (the finalize of one hides under the scan of the next)
+    // per-query scan scratch, LS_NSETS generations: launch i's piggy-backed finalize of group i-1
+    // reads one generation while its scan of group i fills the other
     struct scratch_set {
         float* d_S = nullptr;        // n floats
         u64* d_cand = nullptr;       // max_blocks * LS_KP_MAX
@@ -93,7 +92,7 @@ struct ls_index {
     // options / instrumentation
     int32_t opt_kprime = 0;  // 0 = automatic
     int32_t opt_force_slow = 0;
-    int32_t opt_overlap = 1;    // multi-query calls use two stream lanes
+    int32_t opt_overlap = 1;    // finalize of group i-1 rides on the scan launch of group i
     int32_t opt_alternate = 0;  // alternate sweep direction between consecutive scans
     uint64_t sweep_count = 0;
     // profiling: hipEvent pairs around EVERY scan launch (and the finalize after it), recorded
@@ -215,7 +214,6 @@ void ls_destroy(ls_index* ix) {
     if (ix->own_stream) (void)hipStreamSynchronize(ix->own_stream);
     (void)hipFree(ix->d_corpus);
     (void)hipFree(ix->d_qraw);
-    (void)hipFree(ix->d_qprep);
     for (auto& st : ix->sets) {
         (void)hipFree(st.d_S);
         (void)hipFree(st.d_cand);
@@ -874,7 +872,7 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->opt_gemm = value != 0;
         return LS_OK;
     }
-    if (which == 3) {  // two-lane overlap of consecutive queries inside one call (default on)
+    if (which == 3) {  // piggy-back the finalize on the next scan launch (default on)
         ix->opt_overlap = value != 0;
         return LS_OK;
     }

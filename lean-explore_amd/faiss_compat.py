@@ -32,6 +32,30 @@ class IndexFlatIP(FlatIPIndex):
         super().__init__(d, dtype=dtype, device=device)
 
 
+class IndexIVFFlat(FlatIPIndex):
+    """faiss.IndexIVFFlat(quantizer, d, nlist, metric) as the reference's index builder drives it
+    (reference src/lean_explore/extract/index.py:103-116: construct, ``train``, ``add``;
+    ``nprobe`` is set by the engine, search/engine.py:247-248). There is nothing to train: the
+    rows are searched exactly, i.e. the answer IVF approximates; ``nlist`` / ``nprobe`` are kept
+    as plain attributes. ``write_index`` stores it in the flat container."""
+
+    def __init__(self, quantizer, d: int, nlist: int, metric: int = METRIC_INNER_PRODUCT,
+                 dtype="f32", device: int = 0):
+        if metric != METRIC_INNER_PRODUCT:
+            raise ValueError("only METRIC_INNER_PRODUCT is supported")
+        super().__init__(d, dtype=dtype, device=device)
+        self.quantizer, self.nlist, self.nprobe, self.is_trained = quantizer, int(nlist), 1, False
+
+    def train(self, x: np.ndarray) -> None:
+        self.is_trained = True
+
+
+def get_num_gpus() -> int:
+    """faiss.get_num_gpus(): 0, so callers take their CPU-index code path (extract/index.py:106);
+    the rows go to HBM when the index is first searched either way."""
+    return 0
+
+
 # ------------------------------------------------------------------ container format helpers
 def _fourcc(s: str) -> int:
     return struct.unpack("<I", s.encode("ascii"))[0]

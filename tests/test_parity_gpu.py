@@ -51,6 +51,29 @@ def test_reference_known_answer_e0():
         ix.close()
 
 
+def test_reference_index_builder_calls(tmp_path):
+    """The call sequence of the reference's _build_faiss_index (extract/index.py:80-118) and
+    the asserts of its tests (index_test.py:164-205, 274-281) against the faiss_compat shim."""
+    from lean_explore_amd import faiss_compat as faiss
+
+    emb, q = H.kat_inputs(7)
+    nlist = max(256, int(np.sqrt(emb.shape[0])))
+    quantizer = faiss.IndexFlatIP(emb.shape[1])
+    index = faiss.IndexIVFFlat(quantizer, emb.shape[1], nlist, faiss.METRIC_INNER_PRODUCT)
+    assert faiss.get_num_gpus() == 0
+    index.train(emb)
+    index.add(emb)
+    assert isinstance(index, faiss.IndexIVFFlat) and index.ntotal == 300 and index.d == 768
+    index.nprobe = 10
+    D, I = index.search(q, 1)
+    assert I[0][0] == 0
+    faiss.write_index(index, str(tmp_path / "t.index"))
+    loaded = faiss.read_index(str(tmp_path / "t.index"))
+    assert loaded.ntotal == 300
+    D2, I2 = loaded.search(q, 1)
+    assert I2[0][0] == 0 and D2[0][0] == D[0][0]
+
+
 def test_golden_vectors():
     meta, arr = H.load_golden()
     for name, m in meta.items():

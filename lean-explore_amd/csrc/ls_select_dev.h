@@ -293,9 +293,9 @@ static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* t
     __syncthreads();
     LS_STAMP(3);
     if (kk <= 256) {  // order by counting: rank = number of larger survivors
-        // the 1024-thread finalize lets 4 threads share one survivor (each counts a slice of the
-        // others; the slices are summed by lane shuffles): the serial LDS walk is kk / 4 long
-        const int G = nt >= 1024 ? 4 : 1;  // (measured: sharing does not pay with 256 threads)
+        // with threads to spare, 4 of them share one survivor (each counts a slice of the others;
+        // the slices are summed by lane shuffles): the serial LDS walk is kk / 4 long
+        const int G = (kk * 4 <= nt) ? 4 : 1;  // (2-way sharing measured slower than none)
         const int me = tid / G, part = tid % G;
         u64 mine = 0;
         int rank = 0;

@@ -416,3 +416,29 @@ def test_multi_query_ordered_batch_uses_piggyback(dtype):
     q = H.gauss(62, 16, 768)
     for nq in (2, 3, 16):
         check(c, q[:nq], 100, dtype=dtype)
+
+
+def test_no_device_memory_leak_over_index_lifetimes():
+    """ls_create / search (all three paths) / ls_destroy in a loop gives every byte back."""
+    import torch
+
+    corpus, q1, qb = H.gauss(1, 40_000, 128), H.gauss(2, 1, 128), H.gauss(3, 64, 128)
+
+    def cycle():
+        for dtype in ("f32", "f16"):
+            ix = FlatIPIndex.from_array(corpus, dtype=dtype)
+            ix.search(q1, 10)          # scan path, synchronous host API
+            ix.search(qb, 10)          # multi-query groups (f32) / batched MFMA path (f16)
+            tq = torch.from_numpy(q1).cuda()
+            ix.search_device(tq, 10, pipeline=True)
+            ix.check()
+            ix.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(8):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB"

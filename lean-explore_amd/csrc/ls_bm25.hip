@@ -4,16 +4,18 @@
 //
 // The index is a CSC matrix, one column per vocabulary token: rows = documents containing the
 // token, data = idf * tf-part - nonoccurrence (float32). A query adds the columns of its tokens
-// into a zeroed score vector IN TOKEN ORDER (one launch per token: a column never repeats a
+// into an all-zero score vector IN TOKEN ORDER (one launch per token: a column never repeats a
 // document, so the adds need no atomics and the float32 sum has the same order as bm25s's
 // numpy loop -> bit-identical scores), adds sum(nonoccurrence[tokens]) and selects the top k
 // with the same machinery as the dense path (per-workgroup candidates + bounds -> finalize).
 //
 // HBM-bound integer/byte work: bytes per query = sum over tokens of 8 B * |column| (row id +
-// value) + 12 B * n_docs (zero, shift + candidate sweep of the score vector).
+// value) + 12 B * n_docs (the candidate sweep: read the sums, write the final scores, reset the
+// accumulator to zero for the next query).
 #include "ls_select_dev.h"
 
 #include <algorithm>
+#include <cstring>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -25,11 +27,13 @@ struct ls_bm25 {
     std::vector<float> h_nonocc;
     int32_t* d_indices = nullptr;
     float* d_data = nullptr;
-    float* d_S = nullptr;
+    float* d_S = nullptr;   // accumulator: all zeros between searches (the candidate sweep resets it)
+    float* d_F = nullptr;   // final scores of the last search (the finalize step's rescue path)
+    bool dirty = false;     // a search failed between its first add and its sweep
+    float* h_out_s = nullptr;    // pinned, device-visible: the finalize step writes results here
+    int64_t* h_out_i = nullptr;
     u64* d_cand = nullptr;
     u64* d_bound = nullptr;
-    float* d_out_s = nullptr;
-    int64_t* d_out_i = nullptr;
     u32* d_counters = nullptr;
     int32_t blocks = 1;
     hipStream_t stream = nullptr;
@@ -49,9 +53,11 @@ __global__ __launch_bounds__(256) void bm25_add_column_kernel(float* __restrict_
         S[rows[i]] += vals[i];
 }
 
-// S[r] += shift (the query's non-occurrence sum), then per-workgroup best kprime keys + bound,
-// exactly what the dense scan emits, so finalize_body can prove / complete the top-k.
-__global__ __launch_bounds__(256) void bm25_candidates_kernel(float* __restrict__ S, long long n,
+// F[r] = S[r] + shift (the query's non-occurrence sum), S[r] = 0 for the next search (no separate
+// zeroing launch), then per-workgroup best kprime keys + bound, exactly what the dense scan emits,
+// so finalize_body can prove / complete the top-k.
+__global__ __launch_bounds__(256) void bm25_candidates_kernel(float* __restrict__ S,
+                                                              float* __restrict__ F, long long n,
                                                               float shift, u64* __restrict__ cand,
                                                               u64* __restrict__ bound, int kprime) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -65,7 +71,8 @@ __global__ __launch_bounds__(256) void bm25_candidates_kernel(float* __restrict_
         float s = 0.0f;
         if (valid) {
             s = S[row] + shift;
-            S[row] = s;
+            F[row] = s;
+            S[row] = 0.0f;
         }
         const u64 key = valid ? ls_make_key(s, (u32)row) : 0ull;
         u64 mask = __ballot(key > thr);
@@ -101,10 +108,11 @@ void ls_bm25_destroy(ls_bm25* ix) {
     (void)hipFree(ix->d_indices);
     (void)hipFree(ix->d_data);
     (void)hipFree(ix->d_S);
+    (void)hipFree(ix->d_F);
+    if (ix->h_out_s) (void)hipHostFree(ix->h_out_s);
+    if (ix->h_out_i) (void)hipHostFree(ix->h_out_i);
     (void)hipFree(ix->d_cand);
     (void)hipFree(ix->d_bound);
-    (void)hipFree(ix->d_out_s);
-    (void)hipFree(ix->d_out_i);
     (void)hipFree(ix->d_counters);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
@@ -160,10 +168,14 @@ int ls_bm25_create(ls_bm25** out, const int64_t* indptr, const int32_t* indices,
     if (hipMalloc((void**)&ix->d_indices, nz * 4) != hipSuccess) return fail("hipMalloc");
     if (hipMalloc((void**)&ix->d_data, nz * 4) != hipSuccess) return fail("hipMalloc");
     if (hipMalloc((void**)&ix->d_S, nd * 4) != hipSuccess) return fail("hipMalloc");
+    if (hipMalloc((void**)&ix->d_F, nd * 4) != hipSuccess) return fail("hipMalloc");
+    if (hipMemset(ix->d_S, 0, nd * 4) != hipSuccess) return fail("hipMemset");
+    if (hipHostMalloc((void**)&ix->h_out_s, LS_MAX_K * 4, hipHostMallocDefault) != hipSuccess)
+        return fail("hipHostMalloc");
+    if (hipHostMalloc((void**)&ix->h_out_i, LS_MAX_K * 8, hipHostMallocDefault) != hipSuccess)
+        return fail("hipHostMalloc");
     if (hipMalloc((void**)&ix->d_cand, (size_t)ix->blocks * LS_KP_MAX * 8) != hipSuccess) return fail("hipMalloc");
     if (hipMalloc((void**)&ix->d_bound, (size_t)ix->blocks * 8) != hipSuccess) return fail("hipMalloc");
-    if (hipMalloc((void**)&ix->d_out_s, LS_MAX_K * 4) != hipSuccess) return fail("hipMalloc");
-    if (hipMalloc((void**)&ix->d_out_i, LS_MAX_K * 8) != hipSuccess) return fail("hipMalloc");
     if (hipMalloc((void**)&ix->d_counters, 32) != hipSuccess) return fail("hipMalloc");
     if (hipMemset(ix->d_counters, 0, 32) != hipSuccess) return fail("hipMemset");
     if (nnz > 0) {
@@ -201,7 +213,9 @@ int ls_bm25_search(ls_bm25* ix, const int32_t* token_ids, int32_t n_tokens, int3
     hipStream_t s = ix->stream;
     const long long n = ix->n_docs;
     if (n > 0) {
-        hipLaunchKernelGGL(bm25_zero_kernel, dim3(ix->blocks), dim3(256), 0, s, ix->d_S, n);
+        if (ix->dirty)  // a failed search left partial sums behind
+            hipLaunchKernelGGL(bm25_zero_kernel, dim3(ix->blocks), dim3(256), 0, s, ix->d_S, n);
+        ix->dirty = true;
         float shift = 0.0f;
         for (int i = 0; i < n_tokens; ++i) {
             const int64_t a = ix->h_indptr[token_ids[i]], b = ix->h_indptr[token_ids[i] + 1];
@@ -216,12 +230,13 @@ int ls_bm25_search(ls_bm25* ix, const int32_t* token_ids, int32_t n_tokens, int3
         const double lam = (double)keff / ix->blocks;
         int kprime = (int)(lam + 5.0 * __builtin_sqrt(lam) + 3.0);
         kprime = std::max(2, std::min(kprime, LS_KP_MAX - 1));
-        hipLaunchKernelGGL(bm25_candidates_kernel, dim3(ix->blocks), dim3(256), 0, s, ix->d_S, n, shift,
-                           ix->d_cand, ix->d_bound, kprime);
+        hipLaunchKernelGGL(bm25_candidates_kernel, dim3(ix->blocks), dim3(256), 0, s, ix->d_S, ix->d_F,
+                           n, shift, ix->d_cand, ix->d_bound, kprime);
         LS_HIP(hipGetLastError());
+        ix->dirty = false;
         ls_fin_batch jobs{};
         ls_fin_params& p = jobs.p[0];
-        p.S = ix->d_S;
+        p.S = ix->d_F;
         p.n = n;
         p.cand = ix->d_cand;
         p.bound = ix->d_bound;
@@ -231,8 +246,8 @@ int ls_bm25_search(ls_bm25* ix, const int32_t* token_ids, int32_t n_tokens, int3
         p.keys_cap = LS_FINAL_CAP;
         p.force_slow = 0;
         p.base = 0;
-        p.out_scores = ix->d_out_s;
-        p.out_indices = (long long*)ix->d_out_i;
+        p.out_scores = ix->h_out_s;  // pinned host memory, written by the kernel over PCIe
+        p.out_indices = (long long*)ix->h_out_i;
         p.counters = ix->d_counters;
         if (k > LS_MAX_K) {  // only possible when k > n_docs: select LS_MAX_K >= n_docs, pad on host
             p.k = LS_MAX_K;
@@ -240,9 +255,9 @@ int ls_bm25_search(ls_bm25* ix, const int32_t* token_ids, int32_t n_tokens, int3
         int rc = ls_launch_finalize(jobs, 1, s);
         if (rc != LS_OK) return rc;
         const int kk = std::min(k, LS_MAX_K);
-        LS_HIP(hipMemcpyAsync(out_scores, ix->d_out_s, (size_t)kk * 4, hipMemcpyDeviceToHost, s));
-        LS_HIP(hipMemcpyAsync(out_docs, ix->d_out_i, (size_t)kk * 8, hipMemcpyDeviceToHost, s));
         LS_HIP(hipStreamSynchronize(s));
+        memcpy(out_scores, ix->h_out_s, (size_t)kk * 4);
+        memcpy(out_docs, ix->h_out_i, (size_t)kk * 8);
         for (int i = kk; i < k; ++i) {
             out_scores[i] = -FLT_MAX;
             out_docs[i] = -1;

@@ -212,6 +212,25 @@ int ls_bm25_search(ls_bm25* ix, const int32_t* token_ids, int32_t n_tokens, int3
     LS_HIP(hipSetDevice(ix->device));
     hipStream_t s = ix->stream;
     const long long n = ix->n_docs;
+    // No query token has a posting (e.g. the raw-token index asked about a multi-word query, whose
+    // single token is never a name): every document scores exactly `shift`, so under the total
+    // order the answer is documents 0..k-1. The GPU path would produce the same bits the slow way
+    // (200k tied keys defeat the candidate proof), so this one case is answered right here.
+    int64_t postings = 0;
+    for (int i = 0; i < n_tokens; ++i)
+        postings += ix->h_indptr[token_ids[i] + 1] - ix->h_indptr[token_ids[i]];
+    if (n > 0 && postings == 0) {
+        float shift = 0.0f;
+        for (int i = 0; i < n_tokens; ++i) shift = shift + ix->h_nonocc[token_ids[i]];
+        shift = 0.0f + shift;              // what the sweep computes: S[row] (= 0) + shift
+        const bool ok = shift > -FLT_MAX;  // (NaN / -inf rows are never returned)
+        for (int i = 0; i < k; ++i) {
+            const bool live = ok && i < n;
+            out_scores[i] = live ? shift : -FLT_MAX;
+            out_docs[i] = live ? i : -1;
+        }
+        return LS_OK;
+    }
     if (n > 0) {
         if (ix->dirty)  // a failed search left partial sums behind
             hipLaunchKernelGGL(bm25_zero_kernel, dim3(ix->blocks), dim3(256), 0, s, ix->d_S, n);

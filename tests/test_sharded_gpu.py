@@ -79,6 +79,9 @@ def _free_port():
     (3, (50_001, 128, 5, 100, "f32", True)),      # ragged shards, exact integer data, ties
     (2, (90_000, 384, 64, 100, "f16", False)),    # batched MFMA path per shard (sync + repair)
     (2, (300, 64, 2, 1000, "f32", True)),         # k > rows per shard: -1 padded shard lists
+    (3, (7_777, 200, 4, 300, "f32", True)),       # odd sizes, k > 256 (bitonic finalize), ties
+    (2, (70_000, 768, 160, 100, "f16", True)),    # long rows, batched path per shard, exact ints
+    (3, (30_000, 384, 130, 64, "f16", False)),    # small shards (10k rows): batched via BIGNQ rule
 ])
 def test_two_ranks_one_gpu(world, cfg):
     ctx = mp.get_context("spawn")

@@ -350,6 +350,12 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
 #ifdef LS_GEMM_ABL_NOSTAGE  // timing ablation: no tile hand-over (results are garbage)
 #define LS_STAGE(t, b) if (cap < 0) stage(t, b)
 #define LS_TILE_BARRIER() if (cap < 0) __syncthreads()
+#elif defined(LS_GEMM_ABL_NODMA)  // timing ablation: barriers but no tile traffic
+#define LS_STAGE(t, b) if (cap < 0) stage(t, b)
+#define LS_TILE_BARRIER() __syncthreads()
+#elif defined(LS_GEMM_ABL_NOBARRIER)  // timing ablation: tile traffic but no barrier (racy)
+#define LS_STAGE(t, b) stage(t, b)
+#define LS_TILE_BARRIER() if (cap < 0) __syncthreads()
 #else
 #define LS_STAGE(t, b) stage(t, b)
 #define LS_TILE_BARRIER() __syncthreads()

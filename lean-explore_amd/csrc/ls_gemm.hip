@@ -29,6 +29,9 @@
 // path, so the result is always exact.
 #include "ls_select_dev.h"
 
+#ifndef LS_GEMM_LOADERS
+#define LS_GEMM_LOADERS 2  // loader waves per workgroup for long rows (0 = MFMA waves issue the DMA)
+#endif
 #ifndef LS_GEMM_PF
 #define LS_GEMM_PF 1
 #endif
@@ -129,8 +132,18 @@ __device__ __forceinline__ uint4 top4_keys(const float (&t)[4]) {  // 0 = "no sa
                       t[2] == -FLT_MAX ? 0u : ls_ord(t[2]), t[3] == -FLT_MAX ? 0u : ls_ord(t[3]));
 }
 
+// Long rows, full pass: two extra LOADER waves per workgroup issue the tile DMA. An LDS-DMA piece
+// costs the issuing wave ~150 cycles (tools/pmc_c4_sq.sh), six pieces per wave are 900 of a
+// long-row tile's ~2400 cycles; with dedicated loaders the eight MFMA waves never issue it.
+// (10 waves = 3 on two of the SIMDs: needs <= 168 registers, which only the long-row kernel,
+// with one query group per wave, has.)
+__host__ __device__ constexpr int ls_gemm_loaders(int chunks, bool sample) {
+    return (LS_GEMM_LOADERS && chunks == 96 && !sample) ? LS_GEMM_LOADERS : 0;
+}
 template <int CHUNKS, int QG, bool SAMPLE>
-__global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_gemm_filter_kernel(
+__global__ __launch_bounds__(LS_GEMM_THREADS + 64 * ls_gemm_loaders(CHUNKS, SAMPLE),
+                             ls_gemm_loaders(CHUNKS, SAMPLE) ? 3 : LS_GEMM_WAVES_PER_SIMD)
+void ls_gemm_filter_kernel(
     const u32x4* __restrict__ corpus, long long n, const u32x4* __restrict__ qh, int nq, int nqt,
     const float* __restrict__ tau, long long rows_per_split, int tile_stride,
     u64* __restrict__ queues, u32* __restrict__ counts, int cap, u32* __restrict__ overflow,
@@ -170,6 +183,53 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     const int nt = (ntiles_all + tile_stride - 1) / tile_stride;  // tiles this launch visits
 #endif
 
+    constexpr int NLOAD = ls_gemm_loaders(CHUNKS, SAMPLE);
+    if (NLOAD > 0 && wave >= LS_GEMM_WAVES) {  // ---- loader waves: the tile DMA and nothing else
+        const int lw = wave - LS_GEMM_WAVES;
+        constexpr int PPL = TILE_CHUNKS / 64 / (NLOAD > 0 ? NLOAD : 1);  // 1 KiB pieces per loader
+        int lgoff[PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const int Lc = (lw + j * NLOAD) * 64 + lane;
+            const int r = Lc / CHUNKS, sl = Lc % CHUNKS;
+            lgoff[j] = r * CHUNKS + (sl ^ (r & 15));
+        }
+        auto lstage = [&](int ti, int buf) {
+            const u32x4* base = corpus + (r_begin + (long long)ti * TM) * CHUNKS;
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                unsigned char* dst = smem + buf * TILE_BYTES + (lw + j * NLOAD) * 1024;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + lgoff[j]), (lds_ptr_t)dst, 16, 0, 0);
+            }
+        };
+        // Ring of three tile buffers, two tiles ahead. Same barrier sequence as the MFMA waves
+        // (one before tile 0, one per tile). The loader has no other vector-memory traffic, so
+        // "tile i+1 has landed, tile i+2 may still fly" is exactly vmcnt(PPL): written by hand,
+        // with the bare barrier (a __syncthreads() would drain everything).
+        static_assert(NLOAD == 0 || PPL < 64, "vmcnt immediate");
+        constexpr int W = NLOAD > 0 ? PPL : 0;
+        auto hand_over = [&](bool newer_in_flight) {
+            asm volatile("" ::: "memory");
+            if (newer_in_flight)
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (W & 15) | ((W >> 4) << 14));
+            else
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        if (nt > 0) lstage(0, 0);
+        if (nt > 1) lstage(tile_stride, 1);
+        hand_over(nt > 1);
+        int b = 0;  // ring slot of tile i
+        for (int i = 0; i < nt; ++i) {
+            const int b2 = b == 0 ? 2 : b - 1;  // slot of tile i+2 == slot of tile i-1 (consumed)
+            if (i + 2 < nt) lstage((i + 2) * tile_stride, b2);
+            hand_over(i + 2 < nt);
+            b = b == 2 ? 0 : b + 1;
+        }
+        return;
+    }
+
     // ---- corpus tiles: HBM/L2 -> LDS by DMA (global_load_lds, 16 B per lane), double buffered --
     // Wave w, load j fills the 64 consecutive LDS chunks starting at (w*LOADS + j)*64: chunk Lc
     // is tile row r = Lc / CHUNKS, slot sl = Lc % CHUNKS and receives SOURCE chunk sl ^ (r & 15)
@@ -184,6 +244,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
         goff[j] = r * CHUNKS + (sl ^ (r & 15));
     }
     auto stage = [&](int ti, int buf) {
+        if (NLOAD > 0) return;  // the loader waves do it
         const u32x4* base = corpus + (r_begin + (long long)ti * TM) * CHUNKS;
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) {
@@ -243,8 +304,8 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     int lo4[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) lo4[m] = li * ROW_BYTES + (((4 * m + qd) ^ li) * 16);
-    auto a_frag = [&](int buf, int rb, int kk) -> half8 {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + lo4[kk & 3] + buf * TILE_BYTES +
+    auto a_frag = [&](int bufoff, int rb, int kk) -> half8 {  // bufoff: byte offset of the tile
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + lo4[kk & 3] + bufoff +
                                                         rb * 16 * ROW_BYTES + (kk >> 2) * 256);
         return __builtin_bit_cast(half8, v);
     };
@@ -271,7 +332,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // One tile: NRB*QG independent accumulator chains advance together, one k-step at a time;
     // the PREVIOUS tile's accumulators are filtered CPK elements per k-step.
     auto run_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], bool have_prev,
-                        int prev_row0, int buf) {
+                        int prev_row0, int bufoff) {
         // A fragments are read LS_GEMM_PF k-steps ahead of their MFMAs
         constexpr int PF = LS_GEMM_PF, NA = PF + 1;
         half8 a[NA][NRB];
@@ -279,14 +340,14 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
         for (int p0 = 0; p0 < PF; ++p0) {
             if (p0 < KS) {
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) a[p0][rb] = a_frag(buf, rb, p0);
+                for (int rb = 0; rb < NRB; ++rb) a[p0][rb] = a_frag(bufoff, rb, p0);
             }
         }
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             if (kk + PF < KS) {
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) a[(kk + PF) % NA][rb] = a_frag(buf, rb, kk + PF);
+                for (int rb = 0; rb < NRB; ++rb) a[(kk + PF) % NA][rb] = a_frag(bufoff, rb, kk + PF);
             }
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
@@ -330,8 +391,8 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     if (sample_upfront) {
         __syncthreads();
         run_tile(accA, accB, false, 0, 0);
-        if (nt > 1) run_tile(accB, accA, true, tile_row0(0), 1);
-        if (nt > 2) run_tile(accA, accB, true, tile_row0(1), 2);
+        if (nt > 1) run_tile(accB, accA, true, tile_row0(0), TILE_BYTES);
+        if (nt > 2) run_tile(accA, accB, true, tile_row0(1), 2 * TILE_BYTES);
         const int row0 = tile_row0(nt - 1);
         if ((nt - 1) & 1) {
 #pragma unroll
@@ -360,13 +421,26 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
 #define LS_STAGE(t, b) stage(t, b)
 #define LS_TILE_BARRIER() __syncthreads()
 #endif
-    for (int i = 0; i < nt; i += 2) {
+    if (NLOAD > 0) {  // loader waves fill a ring of three tiles, two ahead; this wave only computes
+        int b = 0;
+        for (int i = 0; i < nt; i += 2) {
+            run_tile(accA, accB, i > 0, tile_row0(i - 1), b * TILE_BYTES);
+            __syncthreads();
+            b = b == 2 ? 0 : b + 1;
+            if (i + 1 < nt) {
+                run_tile(accB, accA, true, tile_row0(i), b * TILE_BYTES);
+                __syncthreads();
+                b = b == 2 ? 0 : b + 1;
+            }
+        }
+    }
+    for (int i = 0; i < (NLOAD > 0 ? 0 : nt); i += 2) {
         if (i + 1 < nt) LS_STAGE((i + 1) * tile_stride, 1);
         run_tile(accA, accB, i > 0, tile_row0(i - 1), 0);
         LS_TILE_BARRIER();
         if (i + 1 < nt) {
             if (i + 2 < nt) LS_STAGE((i + 2) * tile_stride, 0);
-            run_tile(accB, accA, true, tile_row0(i), 1);
+            run_tile(accB, accA, true, tile_row0(i), TILE_BYTES);
             LS_TILE_BARRIER();
         }
     }
@@ -404,10 +478,11 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
                           int cap, u32* d_overflow, u32* d_sample_top, hipStream_t s) {
     const int QG = ls_gemm_qg(g);
     const int nqt = (int)(nq_pad / (LS_GEMM_WAVES * 16 * QG));
-    const dim3 grid((unsigned)(nsplits * nqt)), block(LS_GEMM_THREADS);
+    const dim3 grid((unsigned)(nsplits * nqt));
     // two tile buffers; the sample pass takes a third when it fits (all its tiles up front)
     const size_t tile_bytes = (size_t)ls_gemm_tile_rows(g) * g.chunks * 16;
-    const size_t smem = tile_bytes * ((!d_tau && 3 * tile_bytes <= 144 * 1024) ? 3 : 2);
+    const size_t smem = tile_bytes * (((!d_tau || ls_gemm_loaders(g.chunks, false)) &&
+                                       3 * tile_bytes <= 144 * 1024) ? 3 : 2);
 #define LS_GEMM_LAUNCH(C, Q, SMP)                                                                 \
     {                                                                                             \
         auto kern = ls_gemm_filter_kernel<C, Q, SMP>;                                             \
@@ -417,7 +492,8 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));  \
             attr_set = true;                                                                      \
         }                                                                                         \
-        hipLaunchKernelGGL(kern, grid, block, smem, s, (const u32x4*)d_corpus, (long long)n,      \
+        const dim3 blk(LS_GEMM_THREADS + 64 * ls_gemm_loaders(C, SMP));                           \
+        hipLaunchKernelGGL(kern, grid, blk, smem, s, (const u32x4*)d_corpus, (long long)n,        \
                            (const u32x4*)d_qh, (int)nq, nqt, d_tau, (long long)rows_per_split,     \
                            tile_stride, d_queues, d_counts, cap, d_overflow, d_sample_top);       \
         LS_HIP(hipGetLastError());                                                                \

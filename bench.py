@@ -1,23 +1,29 @@
 #!/usr/bin/env python
 """bench.py — queries/sec of the dense-retrieval hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2p|c3|c1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2p|c3|c1|c4]
 
 One "step" = one pass of the hot path (ls_search_device: prep -> scan -> select [-> all-gather
 -> merge]) over one batch of synthetic queries, with corpus, queries and outputs resident in HBM.
 
 Workloads (BASELINE.json configs):
   c2  (default) N=200k d=384 fp32, nq=1,    k=50    HBM-bound     <- the headline metric
-  c3            N=200k d=384 fp16, nq=1024, k=100   MFMA-bound
+  c3            N=200k d=384 fp16, nq=1024, k=100   MFMA-bound    <- the metric's "batch=1024" half
   c2p           N=200k d=1024 fp32, nq=1,   k=1000  the reference's real call shape
   c1            N=10k  d=384 fp32, nq=1,    k=50    the reference's CPU-runnable case
   c4            N=12.5M rows PER GPU (100M at 8 GPUs), d=768 fp16, nq=256, k=100; rows are
                 generated on the device per shard (seed 1234+rank); weak scaling
 
-N > 1: the corpus is row-sharded over the ranks (strong scaling: the same corpus, the same
-queries; every rank ends with the identical merged top-k after one RCCL all-gather).
+The ONE JSON line rank 0 prints carries the headline workload at the top level and, by default,
+  "secondary": the other half of BASELINE's metric (c3 at N=1; c3 + the weak-scaled c4 shard at N>1),
+               each with its own roofline / recall / cpu_baseline,
+  "host_api":  the synchronous host-array call the reference makes (ls_search, nq=1, PCIe and sync
+               inclusive; reference search/engine.py:250) for c2 and c2p.
 
-Prints ONE JSON line on rank 0.
+N > 1: the corpus is row-sharded over the ranks (strong scaling for c1..c3: the same corpus, the
+same queries; every rank ends with the identical merged top-k after one RCCL all-gather).
+`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run
+with N ranks; the run aborts unless the communicator really has N ranks on N distinct devices.
 """
 
 from __future__ import annotations
@@ -25,6 +31,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -45,6 +53,7 @@ WORKLOADS = {
 EXCHANGE_EVERY = 8          # N > 1, batch-1 steps: one all-gather + merge per 8 steps
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA peak
+PREWARM_S = 0.4            # untimed: lets the clocks ramp before warm-up and the timed region
 
 
 def gauss(seed, n, d):
@@ -106,7 +115,7 @@ def cpu_baseline(corpus, queries, k, f16, budget_s=14.0):
         r, _, _ = rate(t, 0.6, 50)
         if r > best_r:
             best_t, best_r = t, r
-    r, done, dt = rate(best_t, budget_s - 0.6 * len(cands), 5000 if nq == 1 else 200)
+    r, done, dt = rate(best_t, max(2.0, budget_s - 0.6 * len(cands)), 5000 if nq == 1 else 200)
     what = (f"{done} single-query searches" if nq == 1
             else f"{done} batches of {sample.shape[0]} of the {nq} queries")
     return {"value": round(r, 2), "unit": "queries/s", "cores": best_t, "kind": "port",
@@ -115,47 +124,82 @@ def cpu_baseline(corpus, queries, k, f16, budget_s=14.0):
                       "cores; faiss is not installed on this box"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--c4-rows", type=int, default=0, help="rows per GPU for c4 (default 12.5M)")
-    args = ap.parse_args()
+class Env:
+    """Process-wide facts of this run: the communicator and this rank's device."""
 
-    import torch
-    import torch.distributed as dist
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    rehearse = bool(os.environ.get("LS_BENCH_FORCE_EXCHANGE"))  # 1-GPU rehearsal of the N > 1 step
-    if world > 1 or rehearse:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        self.torch, self.dist, self.args = torch, dist, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}; "
+                             "refusing to report a rank count that was not run")
+        ndev = torch.cuda.device_count()
+        # development rehearsal only: N ranks on fewer devices, collectives over gloo
+        self.share_gpu = bool(os.environ.get("LS_BENCH_SHARE_GPU")) and self.world > ndev
+        if self.world > ndev and not self.share_gpu:
+            raise SystemExit(f"bench.py: {self.world} ranks but only {ndev} visible GPUs")
+        self.device_index = self.local_rank % max(1, ndev)
+        torch.cuda.set_device(self.device_index)
+        self.dev = torch.device("cuda", self.device_index)
+        self.rehearse = bool(os.environ.get("LS_BENCH_FORCE_EXCHANGE"))  # 1-GPU rehearsal of N > 1
+        self.ranks_seen = 1
+        if self.world > 1 or self.rehearse:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if self.share_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
+            if dist.get_world_size() != args.gpus:
+                raise SystemExit(f"bench.py: communicator has {dist.get_world_size()} ranks, "
+                                 f"--gpus {args.gpus}")
+            # every rank contributes (host, device ordinal) through the collective itself: the
+            # count of DISTINCT pairs is what "n_gpus" may claim
+            ident = f"{socket.gethostname()}:{self.device_index}:{torch.cuda.get_device_properties(self.dev).name}"
+            seen = [None] * self.world
+            dist.all_gather_object(seen, ident)
+            self.ranks_seen = len(seen)
+            self.devices_seen = len(set(seen))
+            if self.devices_seen != self.world and not self.share_gpu:
+                raise SystemExit(f"bench.py: {self.world} ranks landed on {self.devices_seen} devices")
+        else:
+            self.devices_seen = 1
 
-    from lean_explore_amd import native
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def close(self):
+        if self.world > 1 or self.rehearse:
+            self.dist.destroy_process_group()
+
+
+def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: bool, verify: bool,
+              c4_rows: int = 0, cpu_budget_s: float = 14.0) -> dict:
+    """Build the workload's shard on this rank, time `steps` passes of the hot path, verify the
+    timed arrays against the oracle, and return the result block."""
+    torch, dist = env.torch, env.dist
+    world, rank, dev = env.world, env.rank, env.dev
     from lean_explore_amd.index import FlatIPIndex
     from lean_explore_amd.sharded import ShardedFlatIPIndex, shard_bounds
 
-    n, d, dtype, nq, k = WORKLOADS[args.workload]
+    n, d, dtype, nq, k = WORKLOADS[workload]
     elem = 2 if dtype == "f16" else 4
-    c4 = args.workload == "c4"
+    c4 = workload == "c4"
     c4_ref = None
+    NV_C4 = 16  # queries of the c4 batch checked against the torch reference
     if c4:
         # config 4: every rank generates its own shard in HBM (the 153.6 GB corpus never exists
         # on the host); queries come from one seed, identical on every rank
-        rows = args.c4_rows or n
+        rows = c4_rows or n
         n, lo, hi = rows * world, rank * rows, (rank + 1) * rows
         gen = torch.Generator(device=dev)
         gen.manual_seed(1234 + rank)
@@ -169,10 +213,10 @@ def main():
         local = FlatIPIndex.from_device_tensor(shard, dtype=dtype, base=lo)
         queries = tq.cpu().numpy()
         corpus = shard[:200_000].cpu().numpy()  # the CPU baseline's bounded sample
-        if not args.no_verify:
+        if verify:
             # torch fp32 reference of the same op on this rank's shard (fp16-rounded operands,
-            # fp32 accumulate), 4 queries, in row blocks: the oracle cannot hold 12.5 M rows
-            nv = 4
+            # fp32 accumulate), NV_C4 queries, in row blocks: the oracle cannot hold 12.5 M rows
+            nv = NV_C4
             q16 = tq[:nv].half().float()
             best_s = torch.full((nv, 0), 0.0, device=dev)
             best_i = torch.zeros((nv, 0), dtype=torch.int64, device=dev)
@@ -191,7 +235,7 @@ def main():
         queries = gauss(5678, nq, d)
         lo, hi = shard_bounds(n, world, rank)
         local = FlatIPIndex.from_array(np.ascontiguousarray(corpus[lo:hi]), dtype=dtype,
-                                       device=local_rank, base=lo)
+                                       device=env.device_index, base=lo)
         tq = torch.from_numpy(queries).to(dev)
     index = ShardedFlatIPIndex(local, n)
 
@@ -207,14 +251,14 @@ def main():
     # N > 1, small batches: the sharded pipeline (local search of step i carries the finalize of
     # step i-1; the all-gather of step i-1 runs asynchronously; step i-2 is merged)
     sharded_pipe = world > 1 and nq <= 16
-    if rehearse:
+    if env.rehearse:
         index.force_exchange = True
         sharded_pipe, pipelined = nq <= 16, False
 
     # 1 GPU, large batches (MFMA path): calls are queued asynchronously; the verification flags of
     # up to 16 outstanding batches are checked (and flagged queries repaired) by local.check()
     # inside the timed region, instead of one host round trip per batch
-    batched_async = world == 1 and not pipelined and not rehearse
+    batched_async = world == 1 and not pipelined and not env.rehearse
 
     def step():
         o = out_ring[step_i[0] & 15]
@@ -230,110 +274,123 @@ def main():
     def drain():
         if sharded_pipe:
             index.flush()
+        elif world > 1 or env.rehearse:
+            index.finish()  # looks at the gathered verification flags, repairs + re-exchanges if any
         else:
             local.check()
 
-    # ---- verification on the very arrays that are timed. It runs AFTER the timed region: the
-    # oracle's OpenMP / BLAS worker threads keep spinning for a while after a call and were
-    # measured to double the host's launch cost of the steps that follow (33 vs 15 us per
-    # step at N=10k).
-    def verify():
-        recall = None
-        if not args.no_verify and c4:
-            # this rank's shard result (before the exchange) against the torch reference; the
-            # exchange + merge of an N > 1 run is covered by tests/test_sharded_*.py
-            s, i = local.search_device(tq[:4].contiguous(), k)
+    # ---- verification on the very arrays AND the very code path that were timed. It runs AFTER
+    # the timed region: the oracle's OpenMP / BLAS worker threads keep spinning for a while after
+    # a call and were measured to double the host's launch cost of the steps that follow.
+    def verify_fn():
+        if not verify:
+            step()
+            drain()
+            return None
+        if c4:
+            # the full nq-query batch through the timed path (batched MFMA kernels); at N > 1 the
+            # merged rows that belong to THIS shard must be exactly this shard's reference rows
+            # that survive the merge, so compare on the local result before the exchange
+            s, i = local.search_device(tq, k, asynchronous=True)
             local.check()
             rs, ri = c4_ref
-            hit = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(i.cpu().numpy(), ri))
-            recall = hit / float(ri.size)
-            if not np.allclose(s.cpu().numpy(), rs, rtol=0, atol=2e-5):
+            gs, gi = s[:NV_C4].cpu().numpy(), i[:NV_C4].cpu().numpy()
+            hit = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(gi, ri))
+            if not np.allclose(gs, rs, rtol=0, atol=2e-5):
                 raise SystemExit("c4: scores differ from the torch fp32 reference")
             step()
             drain()
-        elif not args.no_verify and rank == 0:
-            from oracle import oracle
-
-            s, i = step()
-            drain()
-            nv = min(nq, 16)
-            Dr, Ir = oracle.c_search(corpus, queries[:nv], k, f16=(dtype == "f16"))
-            _, _, S = oracle.np_search(corpus, queries[:nv], k, f16=(dtype == "f16"))
-            rep = oracle.compare_topk(s[:nv].cpu().numpy(), i[:nv].cpu().numpy(), Dr, Ir, S)
-            recall = rep["recall"]
-        elif not args.no_verify:
+            return hit / float(ri.size)
+        if rank != 0:
             step()
             drain()
+            return None
+        from oracle import oracle
 
-        return recall
+        s, i = step()
+        drain()
+        nv = min(nq, 16)
+        Dr, Ir = oracle.c_search(corpus, queries[:nv], k, f16=(dtype == "f16"))
+        _, _, S = oracle.np_search(corpus, queries[:nv], k, f16=(dtype == "f16"))
+        rep = oracle.compare_topk(s[:nv].cpu().numpy(), i[:nv].cpu().numpy(), Dr, Ir, S)
+        return rep["recall"]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    # untimed pre-warm: a 20-step driver run is ~1 ms of GPU time, shorter than the clock ramp
+    t_pw = time.perf_counter()
+    while time.perf_counter() - t_pw < PREWARM_S:
+        for _ in range(8):
+            step()
+        drain()
+    for _ in range(warmup):
         step()
-    barrier()
+    env.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     ev1.record()
     drain()  # flushes the pipeline and synchronises
-    barrier()
+    env.barrier()
     dt = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
         t = torch.tensor([dt, dev_ms], dtype=torch.float64, device=dev)
+        if env.share_gpu:
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dev_ms = t.tolist()
 
-    # ---- dominant-kernel duration: hipEvents around EVERY scan launch, on the stream it runs
-    # on, over a second pass of the same pipelined steps (events would perturb the timed pass)
+    # ---- dominant-kernel duration: hipEvents around EVERY launch of it, on the stream it runs
+    # on, over a second pass of the same steps (events would perturb the timed pass)
     local.set_profiling(True)
-    n_prof = min(args.steps, 4096 // max(1, min(nq, 16)))
+    n_prof = min(steps, 4096 // max(1, min(nq, 16)))
     for _ in range(n_prof):
         step()
     drain()
-    barrier()
-    scan_ms_avg, total_ms_avg = local.last_kernel_ms()
+    env.barrier()
+    scan_ms_avg, _total = local.last_kernel_ms()
     local.set_profiling(False)
-    recall = verify()
+    recall = verify_fn()
+    repaired = local.debug_counter(8) if (nq > 16 and dtype == "f16") else 0
     ev_ms = scan_ms_avg
     roof_src = "mean of hipEvent pairs bracketing each launch (second pass of the same steps)"
     if pipelined and nq == 1:
         # one launch per step, back to back on one stream: the timed region's own hipEvents give
         # the average launch duration (kernel boundary included) without per-launch event overhead
-        scan_ms_avg = dev_ms / args.steps
+        scan_ms_avg = dev_ms / steps
         roof_src = ("timed region: hipEvent pair around the K back-to-back launches / K "
                     "(kernel boundary included); event-bracketed mean in kernel_ms_bracketed")
     n_local = hi - lo
+    batch_ms = dt * 1e3 / steps
+    mfma_path = nq > 16 and dtype == "f16"
     if c4:  # 256 FLOP/B, just under the ridge (312): HBM-bound; the MFMA fraction rides along
         ab = algorithmic_bytes(n_local, d, elem, nq, k)
         ach = ab / (scan_ms_avg * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                 "mfma_frac": round(2.0 * nq * n_local * d / (scan_ms_avg * 1e-3) / 1e12
-                                   / MFMA_F16_PEAK_TF, 4)}
-    elif args.workload == "c3":
+                                   / MFMA_F16_PEAK_TF, 4),
+                "frac_whole_batch": round(ab / (batch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    elif workload == "c3":
         flops = 2.0 * nq * n_local * d
         ach = flops / (scan_ms_avg * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F16_PEAK_TF,
-                "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TF, 4), "traffic": None}
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TF, 4), "traffic": None,
+                # the same flops over the WHOLE batch (prep, sample pass, tau, MFMA pass, select)
+                "frac_whole_batch": round(flops / (batch_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4)}
     else:
         ab = algorithmic_bytes(n_local, d, elem, 1, k)
         ach = ab / (scan_ms_avg * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-    roof["kernel"] = "ls_gemm_filter_kernel" if args.workload in ("c3", "c4") else "ls_scan_kernel"
+    roof["kernel"] = "ls_gemm_filter_kernel" if mfma_path else "ls_scan_kernel"
     roof["kernel_ms"] = round(scan_ms_avg, 5)
     roof["kernel_ms_source"] = roof_src
     roof["kernel_ms_bracketed"] = round(ev_ms, 5)
-    roof["launches_timed"] = args.steps if (pipelined and nq == 1) else n_prof * (nq if nq <= 16 else 1)
-    pmc = ROOT / "profiles" / f"pmc_{args.workload}.json"
-    if pmc.exists():  # HBM bytes per launch from rocprofv3 --pmc (profiles/collect_pmc.sh)
+    roof["launches_timed"] = steps if (pipelined and nq == 1) else n_prof * (nq if nq <= 16 else 1)
+    pmc = ROOT / "profiles" / f"pmc_{workload}.json"
+    if pmc.exists():  # HBM bytes per launch from rocprofv3 --pmc (profiles/collect.sh)
         try:
             roof["traffic"] = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
             roof["traffic_source"] = f"profiles/{pmc.name}"
@@ -341,54 +398,172 @@ def main():
             pass
     roof["algorithmic_bytes"] = algorithmic_bytes(n_local, d, elem, 1 if nq <= 16 else nq, k)
 
-    if rank == 0:
-        qps = nq * args.steps / dt
+    res = {
+        "value": round(nq * steps / dt, 1),
+        "unit": "queries/s",
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(batch_ms, 5),
+        "device_ms_per_step": round(dev_ms / steps, 5),
+        "scaling": "weak" if c4 else "strong",
+        "dtype": dtype,
+        "data": ("synthetic (standard-normal rows, L2-normalised; generated in HBM per shard, "
+                 "corpus seed 1234+rank, query seed 5678)" if c4 else
+                 "synthetic (standard-normal rows, L2-normalised; corpus seed 1234, query seed 5678)"),
+        "config": {"workload": f"{workload}: N={n} d={d} {dtype} nq={nq} k={k}",
+                   "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
+                   "exchange": (f"pipelined: one packed all-gather + merge per {EXCHANGE_EVERY} "
+                                "steps, overlapping the next scans"
+                                if sharded_pipe else ("one all-gather per step" if world > 1
+                                                      else "none")),
+                   "launches_per_step": (1 if pipelined else
+                                         round(1 + 2.0 / EXCHANGE_EVERY, 3) if sharded_pipe else
+                                         (local.debug_counter(9) if mfma_path else 2 * nq)
+                                         + (2 if world > 1 else 0)),
+                   "note": "each launch = scan(step i) + one workgroup finalising step i-1"
+                   if (pipelined or sharded_pipe) else
+                   ("batched MFMA path: sample pass (+ query prep), tau, MFMA pass, select"
+                    if mfma_path else "scan + select launches per query")},
+        "effective_gbs": round(algorithmic_bytes(n_local, d, elem, nq, k) * steps / dt / 1e9, 1),
+        "recall_at_k": recall,
+        # queries the batched path handed to the exact scan path (speculative threshold let
+        # < k rows through, or a candidate queue overflowed) over the whole run
+        "repaired_queries": repaired,
+        "roofline": roof,
+    }
+    if want_cpu and rank == 0 and world == 1:
+        cb = cpu_baseline(corpus, queries, k, dtype == "f16", budget_s=cpu_budget_s)
+        if c4:  # timed on the first 200k rows; a flat scan is linear in the row count
+            cb["value"] = round(cb["value"] * corpus.shape[0] / n, 3)
+            cb["sample"] = (f"first {corpus.shape[0]} of the {n} rows, rate scaled by "
+                            f"{corpus.shape[0]}/{n}; " + cb["sample"])
+        res["cpu_baseline"] = cb
+    local.close()
+    del index, local, out_ring, tq
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_host_api(env: Env, workload: str, calls: int = 300) -> dict:
+    """The call the reference actually makes (search/engine.py:238-250): host float32 [1, d] in,
+    host (D, I) out, synchronous. Wall-clock per call, PCIe transfers and the stream sync
+    included; normalisation fused (LS_FLAG_NORMALIZE) as INTEGRATION.md's patch does."""
+    from lean_explore_amd.index import FlatIPIndex
+
+    n, d, dtype, nq, k = WORKLOADS[workload]
+    corpus = gauss(1234, n, d)
+    q = gauss(5678, 1, d)
+    ix = FlatIPIndex.from_array(corpus, dtype=dtype, device=env.device_index)
+    del corpus
+    for _ in range(30):
+        ix.search(q, k, normalize=True)
+    lat = np.empty(calls)
+    for i in range(calls):
+        t0 = time.perf_counter()
+        ix.search(q, k, normalize=True)
+        lat[i] = time.perf_counter() - t0
+    ix.close()
+    mean = float(lat.mean())
+    return {"workload": f"{workload}: N={n} d={d} {dtype} nq=1 k={k}", "calls": calls,
+            "us_per_call_mean": round(mean * 1e6, 2),
+            "us_per_call_p50": round(float(np.median(lat)) * 1e6, 2),
+            "us_per_call_p90": round(float(np.quantile(lat, 0.9)) * 1e6, 2),
+            "queries_per_s": round(1.0 / mean, 1),
+            "hbm_frac_of_call": round(algorithmic_bytes(n, d, 4 if dtype == "f32" else 2, 1, k)
+                                      / mean / 1e9 / HBM_PEAK_GBS, 4),
+            "what": "ls_search(host q[1,d], LS_FLAG_NORMALIZE) -> host (D, I); H2D, kernels, D2H "
+                    "and stream sync inside the timed call"}
+
+
+def self_spawn(args) -> int:
+    """`python bench.py --gpus N` with no launcher: run N ranks under torch.distributed.run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--secondary", default="auto",
+                    help="auto | none | comma list of workloads reported under 'secondary'")
+    ap.add_argument("--no-host-api", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--c4-rows", type=int, default=0, help="rows per GPU for c4 (default 12.5M)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
+
+    env = Env(args)
+    head = run_dense(env, args.workload, args.steps, args.warmup,
+                     want_cpu=not args.no_cpu_baseline, verify=not args.no_verify,
+                     c4_rows=args.c4_rows)
+    if args.secondary == "auto":
+        sec = []
+        if args.workload == "c2":  # the default, driver-timed run carries both halves of the metric
+            sec = ["c3"] if env.world == 1 else ["c3", "c4"]
+    elif args.secondary in ("none", ""):
+        sec = []
+    else:
+        sec = [w for w in args.secondary.split(",") if w in WORKLOADS and w != args.workload]
+    secondary = {}
+    for w in sec:
+        nq = WORKLOADS[w][3]
+        st, wu = (1000, 50) if nq <= 16 else ((300, 20) if w == "c3" else (30, 3))
+        secondary[w] = run_dense(env, w, st, wu, want_cpu=not args.no_cpu_baseline,
+                                 verify=not args.no_verify, c4_rows=args.c4_rows, cpu_budget_s=9.0)
+    host_api = None
+    if not args.no_host_api and env.world == 1 and args.workload == "c2" and env.rank == 0:
+        host_api = {w: run_host_api(env, w) for w in ("c2", "c2p")}
+
+    if env.rank == 0:
         out = {
             "metric": "queries/sec (exact inner-product top-k, recall vs FAISS-flat restatement)",
-            "value": round(qps, 1),
-            "unit": "queries/s",
-            "n_gpus": world,
+            "value": head["value"],
+            "unit": head["unit"],
+            "n_gpus": env.world,
+            "rccl_ranks_seen": env.ranks_seen,
+            "devices_seen": env.devices_seen,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt * 1e3 / args.steps, 5),
-            "device_ms_per_step": round(dev_ms / args.steps, 5),
+            "ms_per_step": head["ms_per_step"],
+            "device_ms_per_step": head["device_ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak" if c4 else "strong",
+            "scaling": head["scaling"],
             "vs_baseline": None,
-            "dtype": dtype,
-            "data": ("synthetic (standard-normal rows, L2-normalised; generated in HBM per shard, "
-                     "corpus seed 1234+rank, query seed 5678)" if c4 else
-                     "synthetic (standard-normal rows, L2-normalised; corpus seed 1234, query seed 5678)"),
-            "config": {"workload": f"{args.workload}: N={n} d={d} {dtype} nq={nq} k={k}",
-                       "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
-                       "exchange": (f"pipelined: one packed all-gather + merge per {EXCHANGE_EVERY} steps, overlapping the next scans"
-                                    if sharded_pipe else ("one all-gather per step" if world > 1
-                                                          else "none")),
-                       "launches_per_step": (1 if pipelined else
-                                             round(1 + 2.0 / EXCHANGE_EVERY, 3) if sharded_pipe else
-                                             (5 if nq > 16 and dtype == "f16" else 2 * nq)
-                                             + (2 if world > 1 else 0)),
-                       "note": "each launch = scan(step i) + one workgroup finalising step i-1"
-                       if (pipelined or sharded_pipe) else ("prep, sample pass, tau, MFMA pass + select per batch"
-                                          if nq > 16 and dtype == "f16" else
-                                          "scan + select launches per query")},
-            "effective_gbs": round(algorithmic_bytes(n_local, d, elem, nq, k) * args.steps / dt / 1e9, 1),
-            "recall_at_k": recall,
-            # queries the batched path handed to the exact scan path (speculative threshold let
-            # < k rows through, or a candidate queue overflowed) over the whole run
-            "repaired_queries": local.debug_counter(8) if (nq > 16 and dtype == "f16") else 0,
-            "roofline": roof,
+            "dtype": head["dtype"],
+            "data": head["data"],
+            "config": head["config"],
+            "effective_gbs": head["effective_gbs"],
+            "recall_at_k": head["recall_at_k"],
+            "repaired_queries": head["repaired_queries"],
+            "prewarm_s": PREWARM_S,
+            "roofline": head["roofline"],
         }
-        if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline(corpus, queries, k, dtype == "f16")
-            if c4:  # timed on the first 200k rows; a flat scan is linear in the row count
-                cb["value"] = round(cb["value"] * corpus.shape[0] / n, 3)
-                cb["sample"] = (f"first {corpus.shape[0]} of the {n} rows, rate scaled by "
-                                f"{corpus.shape[0]}/{n}; " + cb["sample"])
-            out["cpu_baseline"] = cb
+        if "cpu_baseline" in head:
+            out["cpu_baseline"] = head["cpu_baseline"]
+        if secondary:
+            out["secondary"] = secondary
+        if host_api:
+            out["host_api"] = host_api
+        if env.share_gpu:
+            out["rehearsal"] = (f"{env.world} ranks share {env.devices_seen} GPU(s) over gloo: "
+                                "exercises the N > 1 code path only, the value is not a result")
         print(json.dumps(out), flush=True)
-    if world > 1 or rehearse:
-        dist.destroy_process_group()
+    env.close()
 
 
 if __name__ == "__main__":

@@ -9,7 +9,7 @@
  *   reference call                                                    replaced by
  *   ---------------------------------------------------------------  -------------------------
  *   faiss.read_index(path)            search/engine.py:159            ls_create (+ Python loader)
- *   faiss.IndexFlatIP(d); index.add(x)   extract/index.py:103,116     ls_create
+ *   faiss.IndexFlatIP(d); index.add(x)   extract/index.py:103,116     ls_create / ls_add
  *   faiss.normalize_L2(x)             search/engine.py:242            ls_normalize_l2
  *   index.search(x, k) -> (D, I)      search/engine.py:250            ls_search
  *   index.ntotal / index.d            tests/extract/index_test.py:172-173   ls_ntotal / ls_dim
@@ -23,7 +23,9 @@
  *     number of valid rows hold index -1 and score -FLT_MAX (IndexFlat's heap-neutral padding,
  *     which the reference relies on at search/engine.py:254). Rows whose score is NaN or
  *     <= -FLT_MAX are never returned.
- *   - ls_search / ls_search_device may be called concurrently on one handle (serialised inside).
+ *   - ls_search / ls_search_device may be called concurrently on one handle, from several threads
+ *     and on several streams: calls are serialised inside, and device work that shares the
+ *     handle's scratch is fenced across streams by events.
  *   - there is no CPU fallback: with no usable HIP device every compute entry point fails with
  *     LS_ERR_NO_DEVICE.
  */
@@ -41,7 +43,7 @@ extern "C" {
 #define LS_ERR_NO_DEVICE (-2)     /* no HIP device / device id out of range                   */
 #define LS_ERR_HIP (-3)           /* a HIP runtime call failed (message has the HIP string)   */
 #define LS_ERR_K_TOO_LARGE (-4)   /* min(k, ntotal) exceeds LS_MAX_K                          */
-#define LS_ERR_OVERFLOW (-5)      /* ls_check: async batched search needs a synchronous redo  */
+#define LS_ERR_OVERFLOW (-5)      /* reserved (ls_check repairs flagged queries itself)       */
 
 #define LS_DTYPE_F32 0 /* corpus stored in HBM as fp32 (what the reference stores)           */
 #define LS_DTYPE_F16 1 /* corpus rounded to fp16 in HBM; queries are rounded to fp16 as well, */
@@ -72,6 +74,16 @@ int ls_create(ls_index** out, const float* corpus, int64_t n, int32_t d, int32_t
 int ls_create_from_device(ls_index** out, const void* d_corpus, int64_t n, int32_t d,
                           int32_t dtype, int32_t device);
 
+/* index.add(x) on an existing index (reference extract/index.py:116): append `n_add` host
+ * float32 rows [n_add, d]. The rows already stored stay in HBM (device-to-device carry-over); only
+ * the new rows cross PCIe. Synchronises the handle's outstanding work first. */
+int ls_add(ls_index* index, const float* rows, int64_t n_add);
+
+/* index.reconstruct_n(row0, count): copy stored rows back to host float32 [count, d]. An fp16
+ * index returns the rounded values. (faiss.write_index needs the rows; the Python wrapper keeps no
+ * host copy of the corpus.) */
+int ls_reconstruct(ls_index* index, int64_t row0, int64_t count, float* out);
+
 void ls_destroy(ls_index* index);
 
 int64_t ls_ntotal(const ls_index* index); /* index.ntotal */
@@ -91,17 +103,33 @@ int ls_search(ls_index* index, const float* q, int64_t nq, int32_t k, uint32_t f
  * on `stream` (a hipStream_t; NULL = default stream). Without LS_FLAG_ASYNC it synchronises
  * the stream before returning. With LS_FLAG_ASYNC it returns after queueing (results ordered on
  * `stream`); with LS_FLAG_PIPELINE it returns after queueing on internal lanes (see the flag).
- * Call ls_check before trusting the results of batched (MFMA path) or pipelined searches. */
+ * Lifetimes of an async / pipelined call: the QUERY buffer may be reused as soon as the work
+ * queued on `stream` so far has consumed it (stream order; the library keeps its own copy for
+ * repairs); the OUTPUT buffers must stay valid until the ls_check that covers the call, because a
+ * repaired query is re-written in place. Call ls_check before trusting the results of batched
+ * (MFMA path, nq > 16 on an fp16 index) or pipelined searches. */
 int ls_search_device(ls_index* index, const void* d_q, int64_t nq, int32_t k, uint32_t flags,
                      void* d_out_scores, void* d_out_indices, void* stream);
 
-/* Synchronise `stream` and the index's internal lanes, and report on the async / pipelined
- * searches queued since the last ls_check: LS_OK if all results are exact, LS_ERR_OVERFLOW if
- * some batched query overflowed its candidate queues (re-issue those without LS_FLAG_ASYNC). */
+/* Synchronise `stream` and the index's internal lanes and make the results of every async /
+ * pipelined search queued since the last ls_check final: queries of batched calls whose
+ * speculative threshold let fewer than k rows through, or whose candidate queues overflowed, are
+ * re-run here by the exact per-query scan path (from the library's own copy of the queries) and
+ * their output rows re-written. Returns LS_OK once everything is exact. Up to 16 batched calls
+ * may be outstanding; the 17th triggers the same repair step on its own. */
 int ls_check(ls_index* index, void* stream);
 
+/* Copy the per-query verification flags of the most recent search queued on this handle into
+ * d_dst (device memory on the index's device, uint32 [nq]) in `stream` order: non-zero = that
+ * query's output rows are provisional until ls_check. Scan-path searches export zeros. Lets a
+ * sharded caller ship the flags with the results instead of synchronising before the exchange. */
+int ls_export_flags(ls_index* index, void* d_dst, int64_t nq, void* stream);
+
 /* faiss.normalize_L2(x): in-place row normalisation of host float32 [nq, d];
- * rows with zero norm are left unchanged. Runs on `device`. */
+ * rows with zero norm are left unchanged. Runs on `device` (cached pinned staging buffers that the
+ * kernel reads and writes directly; no allocation per call). The squared norm is summed in the
+ * library's one documented order (ls_common.h, ls_wave_sumsq), the same the fused
+ * LS_FLAG_NORMALIZE uses, so both routes give bit-identical queries. */
 int ls_normalize_l2(float* x, int64_t nq, int32_t d, int32_t device);
 
 /* Merge `n_lists` per-shard results (each [nq, k], sorted by the total order, -1 padded)
@@ -135,6 +163,7 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * option 5: speculative, verified sample threshold on the batched path (default on; off = the
  * certified k-th sample score); option 6: several queries per corpus pass on the scan path
  * (default on).
+ * counter 9: kernel launches of the most recent batched call.
  * counter 0: searches whose finalize step left the fast path (rescue or general); counter 1:
  * those that took the general path; counter 8: queries of batched calls that were repaired by
  * the exact scan path. */

@@ -51,18 +51,25 @@ struct ls_index {
     } sets[LS_NSETS];
     uint64_t set_rr = 0;
     int32_t last_set = 0;
-    // batched (MFMA) path scratch, allocated on first use
+    // batched (MFMA) path scratch, allocated on first use. ONE set per handle: calls on
+    // different streams are fenced by `bc_done` (recorded behind the last kernel of a call, waited
+    // for by the next call's stream), so they never overlap on it.
     void* d_qh = nullptr;      size_t qh_cap = 0;       // bytes: fp16 queries [nq_pad, d_pad]
-    u64* d_queues = nullptr;   size_t queues_cap = 0;   // private candidate queues
-    u32* d_counts = nullptr;   size_t counts_cap = 0;
+    unsigned char* d_rec = nullptr;   size_t rec_cap = 0;    // bytes: (query, slice) records
+    u32* d_rcnt = nullptr;     size_t rcnt_cap = 0;
+    unsigned char* d_spill = nullptr; size_t spill_cap = 0;  // bytes: per-lane HBM spill queues
+    u32* d_scnt = nullptr;     size_t scnt_cap = 0;
     float* d_tau = nullptr;    size_t tau_cap = 0;
     u32* d_overflow = nullptr; size_t overflow_cap = 0;
     u32* d_sample_top = nullptr; size_t sample_top_cap = 0;  // 4 best sample scores per lane
     u32* h_overflow = nullptr; size_t h_overflow_cap = 0;  // pinned
-    // async batched calls not yet checked: each keeps its own flag slice of d_overflow so that
-    // several batches can be in flight before one ls_check repairs whatever was flagged
+    hipEvent_t bc_done = nullptr;
+    hipStream_t bc_last_stream = nullptr;
+    bool bc_used = false;
+    // async batched calls not yet checked: each keeps its own flag slice of d_overflow AND its own
+    // copy of the raw queries (d_qkeep), so that several batches can be in flight before one
+    // ls_check repairs whatever was flagged, whatever the caller did to its query buffer meanwhile
     struct batched_call {
-        const float* d_q = nullptr;
         int64_t nq = 0;
         int32_t k = 0;
         uint32_t flags = 0;
@@ -73,7 +80,12 @@ struct ls_index {
     };
     std::vector<batched_call> bc_pending;
     int64_t bc_slot_stride = 0;  // u32 per flag slot
+    float* d_qkeep = nullptr;  size_t qkeep_cap = 0;  // LS_BC_SLOTS x bc_qkeep_stride floats
+    int64_t bc_qkeep_stride = 0;
+    u32* d_last_flags = nullptr;  // flag slice of the most recent batched call (ls_export_flags)
+    int64_t last_flags_n = 0;
     uint64_t n_batched_fallback = 0;  // queries repaired by the scan path (host counter)
+    int32_t n_batched_launches = 0;   // kernel launches of the most recent batched call
     int32_t opt_gemm = 1;             // allow the batched MFMA path
     int32_t opt_spec_tau = 1;         // speculative (verified) sample threshold
 
@@ -173,7 +185,6 @@ static int create_common(ls_index** out, int64_t n, int32_t d, int32_t dtype, in
     ix->n = n;
     ix->dtype = dtype;
     ix->g = g;
-    if (const char* e = getenv("LS_SCAN_ALT")) ix->opt_alternate = atoi(e) != 0;
     int cu = 0;
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
         cu > 0)
@@ -182,28 +193,77 @@ static int create_common(ls_index** out, int64_t n, int32_t d, int32_t dtype, in
     return LS_OK;
 }
 
-static int alloc_index_buffers(ls_index* ix) {
+// (Re)allocate what depends on the row count: the corpus with its zero pad rows (old rows are
+// carried over device-to-device when the index grows) and the scan path's per-query scratch.
+static int alloc_rows(ls_index* ix, int64_t new_n) {
     const size_t row_bytes = (size_t)ix->g.chunks * 16;
-    // the batched path reads whole 64-row tiles: keep LS_CORPUS_PAD_ROWS zero rows past n
-    if (ix->n > 0) {
-        LS_HIP(hipMalloc(&ix->d_corpus, (size_t)(ix->n + LS_CORPUS_PAD_ROWS) * row_bytes));
-        LS_HIP(hipMemset((char*)ix->d_corpus + (size_t)ix->n * row_bytes, 0,
+    // the batched path reads whole tiles: keep LS_CORPUS_PAD_ROWS zero rows past n
+    void* d_new = nullptr;
+    if (new_n > 0) {
+        LS_HIP(hipMalloc(&d_new, (size_t)(new_n + LS_CORPUS_PAD_ROWS) * row_bytes));
+        if (ix->d_corpus && ix->n > 0)
+            LS_HIP(hipMemcpy(d_new, ix->d_corpus, (size_t)std::min(ix->n, new_n) * row_bytes,
+                             hipMemcpyDeviceToDevice));
+        LS_HIP(hipMemset((char*)d_new + (size_t)new_n * row_bytes, 0,
                          (size_t)LS_CORPUS_PAD_ROWS * row_bytes));
     }
-    LS_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
-    ix->max_blocks = ls_scan_blocks(ix->n > 0 ? ix->n : 1, ix->g, ix->n_cu);
-    ix->s_stride = ((ix->n > 0 ? ix->n : 1) + 63) / 64 * 64;
+    if (ix->d_corpus) LS_HIP(hipFree(ix->d_corpus));
+    ix->d_corpus = d_new;
+    ix->max_blocks = ls_scan_blocks(new_n > 0 ? new_n : 1, ix->g, ix->n_cu);
+    ix->s_stride = ((new_n > 0 ? new_n : 1) + 63) / 64 * 64;
     for (auto& st : ix->sets) {  // room for LS_SCAN_NQ_MAX queries per generation
+        if (st.d_S) LS_HIP(hipFree(st.d_S));
+        if (st.d_cand) LS_HIP(hipFree(st.d_cand));
+        if (st.d_bound) LS_HIP(hipFree(st.d_bound));
+        st.d_S = nullptr; st.d_cand = nullptr; st.d_bound = nullptr;
         LS_HIP(hipMalloc((void**)&st.d_S, sizeof(float) * (size_t)ix->s_stride * LS_SCAN_NQ_MAX));
         LS_HIP(hipMalloc((void**)&st.d_cand,
                          sizeof(u64) * (size_t)ix->max_blocks * LS_KP_MAX * LS_SCAN_NQ_MAX));
         LS_HIP(hipMalloc((void**)&st.d_bound, sizeof(u64) * (size_t)ix->max_blocks * LS_SCAN_NQ_MAX));
-
     }
+    return LS_OK;
+}
 
+static int alloc_index_buffers(ls_index* ix) {
+    LS_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
+    int rc = alloc_rows(ix, ix->n);
+    if (rc != LS_OK) return rc;
     LS_HIP(hipMalloc((void**)&ix->d_counters, sizeof(u32) * 8));
     LS_HIP(hipMemset(ix->d_counters, 0, sizeof(u32) * 8));
     return LS_OK;
+}
+
+// Host fp32 rows [count, d] -> stored rows [row0, row0 + count) of the HBM corpus.
+static int upload_rows(ls_index* ix, int64_t row0, const float* rows, int64_t count) {
+    const ls_geom& g = ix->g;
+    const int32_t d = g.d;
+    char* dst = (char*)ix->d_corpus + (size_t)row0 * g.chunks * 16;
+    if (ix->dtype == LS_DTYPE_F32 && g.d_pad == d) {
+        // stored layout == caller's layout: one straight copy into HBM
+        LS_HIP(hipMemcpy(dst, rows, (size_t)count * d * sizeof(float), hipMemcpyHostToDevice));
+        return LS_OK;
+    }
+    // upload in slabs of rows through a staging buffer, converting on the device
+    const int64_t slab = std::max<int64_t>(1, (int64_t)(256ll << 20) / ((int64_t)d * 4));
+    float* stage = nullptr;
+    LS_HIP(hipMalloc((void**)&stage, (size_t)std::min(slab, count) * d * sizeof(float)));
+    int rc = LS_OK;
+    for (int64_t r0 = 0; rc == LS_OK && r0 < count; r0 += slab) {
+        const int64_t nr = std::min(slab, count - r0);
+        if (hipMemcpy(stage, rows + r0 * d, (size_t)nr * d * sizeof(float),
+                      hipMemcpyHostToDevice) != hipSuccess) {
+            ls_set_error("corpus upload failed");
+            rc = LS_ERR_HIP;
+            break;
+        }
+        rc = ls_launch_convert(stage, dst + (size_t)r0 * g.chunks * 16, nr, g, ix->own_stream);
+        if (rc == LS_OK && hipStreamSynchronize(ix->own_stream) != hipSuccess) {
+            ls_set_error("corpus conversion failed");
+            rc = LS_ERR_HIP;
+        }
+    }
+    (void)hipFree(stage);
+    return rc;
 }
 
 extern "C" {
@@ -218,16 +278,18 @@ void ls_destroy(ls_index* ix) {
         (void)hipFree(st.d_S);
         (void)hipFree(st.d_cand);
         (void)hipFree(st.d_bound);
-
     }
-
     (void)hipFree(ix->d_out_s);
     (void)hipFree(ix->d_out_i);
     (void)hipFree(ix->d_counters);
     (void)hipFree(ix->d_qpad);
     (void)hipFree(ix->d_qh);
-    (void)hipFree(ix->d_queues);
-    (void)hipFree(ix->d_counts);
+    (void)hipFree(ix->d_rec);
+    (void)hipFree(ix->d_rcnt);
+    (void)hipFree(ix->d_spill);
+    (void)hipFree(ix->d_scnt);
+    (void)hipFree(ix->d_qkeep);
+    if (ix->bc_done) (void)hipEventDestroy(ix->bc_done);
     (void)hipFree(ix->d_tau);
     (void)hipFree(ix->d_overflow);
     (void)hipFree(ix->d_sample_top);
@@ -250,44 +312,7 @@ int ls_create(ls_index** out, const float* corpus, int64_t n, int32_t d, int32_t
     int rc = create_common(out, n, d, dtype, device, &ix);
     if (rc != LS_OK) return rc;
     rc = alloc_index_buffers(ix);
-    if (rc == LS_OK && n > 0) {
-        const ls_geom& g = ix->g;
-        if (dtype == LS_DTYPE_F32 && g.d_pad == d) {
-            // stored layout == caller's layout: one straight copy into HBM
-            hipError_t e = hipMemcpy(ix->d_corpus, corpus, (size_t)n * d * sizeof(float),
-                                     hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                ls_set_error("corpus upload failed: %s", hipGetErrorString(e));
-                rc = LS_ERR_HIP;
-            }
-        } else {
-            // upload in slabs of rows through a staging buffer, converting on the device
-            const int64_t slab = std::max<int64_t>(1, (int64_t)(256ll << 20) / ((int64_t)d * 4));
-            float* stage = nullptr;
-            hipError_t e = hipMalloc((void**)&stage, (size_t)std::min(slab, n) * d * sizeof(float));
-            if (e != hipSuccess) {
-                ls_set_error("staging alloc failed: %s", hipGetErrorString(e));
-                rc = LS_ERR_HIP;
-            }
-            for (int64_t r0 = 0; rc == LS_OK && r0 < n; r0 += slab) {
-                const int64_t rows = std::min(slab, n - r0);
-                e = hipMemcpy(stage, corpus + r0 * d, (size_t)rows * d * sizeof(float),
-                              hipMemcpyHostToDevice);
-                if (e != hipSuccess) {
-                    ls_set_error("corpus upload failed: %s", hipGetErrorString(e));
-                    rc = LS_ERR_HIP;
-                    break;
-                }
-                rc = ls_launch_convert(stage, (char*)ix->d_corpus + (size_t)r0 * g.chunks * 16,
-                                       rows, g, ix->own_stream);
-                if (rc == LS_OK && hipStreamSynchronize(ix->own_stream) != hipSuccess) {
-                    ls_set_error("corpus conversion failed");
-                    rc = LS_ERR_HIP;
-                }
-            }
-            if (stage) (void)hipFree(stage);
-        }
-    }
+    if (rc == LS_OK && n > 0) rc = upload_rows(ix, 0, corpus, n);
     if (rc != LS_OK) {
         ls_destroy(ix);
         return rc;
@@ -487,8 +512,8 @@ static bool batched_eligible(const ls_index* ix, int64_t nq, int32_t k) {
             (ix->n >= LS_GEMM_MIN_ROWS_BIGNQ && nq >= LS_GEMM_BIGNQ));
 }
 
-// Re-run the queries of the last batched call whose candidate queues overflowed (or were short)
-// through the exact per-query scan path. Synchronises the stream.
+// Re-run the queries of the pending batched calls whose candidate queues overflowed (or were
+// short) through the exact per-query scan path, from the calls' OWN query copies. Synchronises.
 static int batched_repair(ls_index* ix) {
     if (ix->bc_pending.empty()) return LS_OK;
     std::vector<ls_index::batched_call> pend;
@@ -503,11 +528,12 @@ static int batched_repair(ls_index* ix) {
     bool any = false;
     for (const auto& bc : pend) {
         const u32* fl = ix->h_overflow + (size_t)bc.slot * ix->bc_slot_stride;
+        const float* qk = ix->d_qkeep + (size_t)bc.slot * ix->bc_qkeep_stride;
         for (int64_t q = 0; q < bc.nq; ++q) {
             if (!fl[q]) continue;
             ix->n_batched_fallback++;
             any = true;
-            int rc = scan_search_on_stream(ix, bc.d_q + q * ix->g.d, 1, bc.k,
+            int rc = scan_search_on_stream(ix, qk + q * ix->g.d, 1, bc.k,
                                            bc.flags & LS_FLAG_NORMALIZE, bc.d_out_s + q * bc.k,
                                            bc.d_out_i + q * bc.k, s);
             if (rc != LS_OK) return rc;
@@ -522,17 +548,21 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
                                     hipStream_t s) {
     int rc = flush_pending(ix);
     if (rc != LS_OK) return rc;
-    const int QG = ls_gemm_qg(ix->g);
+    const ls_geom& g = ix->g;
+    const int QG = ls_gemm_qg(g);
     const int QT = LS_GEMM_WAVES * 16 * QG;  // queries per workgroup
-    const int TM = ls_gemm_tile_rows(ix->g);
-    const int64_t nq_pad0 = (nq + QT - 1) / QT * QT;
+    const int TM = ls_gemm_tile_rows(g);
+    const int64_t nq_pad = (nq + QT - 1) / QT * QT;
+    const int64_t qkeep_need = nq * g.d;
     if ((int)ix->bc_pending.size() >= LS_BC_SLOTS ||
-        (!ix->bc_pending.empty() && nq_pad0 > ix->bc_slot_stride)) {
-        rc = batched_repair(ix);  // flag slots exhausted (or too small): check what is pending
+        (!ix->bc_pending.empty() &&
+         (nq_pad > ix->bc_slot_stride || qkeep_need > ix->bc_qkeep_stride))) {
+        rc = batched_repair(ix);  // slots exhausted (or too small): check what is pending
         if (rc != LS_OK) return rc;
     }
-    const ls_geom& g = ix->g;
-    const int64_t nq_pad = nq_pad0;
+    // One scratch set per handle: a call on another stream waits for the previous call's kernels.
+    if (!ix->bc_done) LS_HIP(hipEventCreateWithFlags(&ix->bc_done, hipEventDisableTiming));
+    if (ix->bc_used && ix->bc_last_stream != s) LS_HIP(hipStreamWaitEvent(s, ix->bc_done, 0));
     const int nqt = (int)(nq_pad / QT);
     // corpus slices: one 8-wave workgroup per CU in total, a multiple of the 8 XCDs
     int nsplits = (LS_GEMM_WG_PER_CU * ix->n_cu / nqt) / 8 * 8;
@@ -541,33 +571,48 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     rps = (rps + TM - 1) / TM * TM;
     const int tiles_per_split = (int)(rps / TM);
     // the sample is a fixed FRACTION of the corpus (~1/24 of every slice, at least
-    // LS_GEMM_SAMPLE_ROWS rows): the expected number of rows passing tau, ~j*N/M0, then does
-    // not grow with N
+    // LS_GEMM_SAMPLE_ROWS rows; ~1/48 for slices of more than 1536 tiles, where the sample pass
+    // itself is what costs): the expected number of rows passing tau, ~j*N/M0, then does not
+    // grow with N
+    const int frac = tiles_per_split > 1536 ? 48 : 24;
     const int sample_tiles = std::max(std::max(1, LS_GEMM_SAMPLE_ROWS / TM),
-                                      (tiles_per_split + 23) / 24);
+                                      (tiles_per_split + frac - 1) / frac);
     const int sample_stride = std::max(1, (tiles_per_split + sample_tiles - 1) / sample_tiles);
-    const int cap = LS_GEMM_QCAP;
-    const size_t nwg = (size_t)nsplits * nqt;
+    const size_t nrec = (size_t)nq_pad * nsplits;
 
     size_t c;
     c = ix->qh_cap;
     if ((rc = grow((unsigned char**)&ix->d_qh, &c, (size_t)nq_pad * g.d_pad * 2)) != LS_OK) return rc;
     ix->qh_cap = c;
-    if ((rc = grow(&ix->d_queues, &ix->queues_cap, nwg * LS_GEMM_THREADS * QG * cap)) != LS_OK)
-        return rc;
-    if ((rc = grow(&ix->d_counts, &ix->counts_cap, nwg * LS_GEMM_THREADS * QG)) != LS_OK) return rc;
+    if ((rc = grow(&ix->d_rec, &ix->rec_cap, nrec * LS_GEMM_REC * 8)) != LS_OK) return rc;
+    if ((rc = grow(&ix->d_rcnt, &ix->rcnt_cap, nrec)) != LS_OK) return rc;
+    if ((rc = grow(&ix->d_spill, &ix->spill_cap, nrec * 4 * LS_GEMM_SCAP * 8)) != LS_OK) return rc;
+    if ((rc = grow(&ix->d_scnt, &ix->scnt_cap, nrec * 4)) != LS_OK) return rc;
     if ((rc = grow(&ix->d_tau, &ix->tau_cap, (size_t)nq_pad)) != LS_OK) return rc;
-    if (ix->bc_pending.empty() && nq_pad > ix->bc_slot_stride) ix->bc_slot_stride = nq_pad;
+    if (ix->bc_pending.empty()) {
+        if (nq_pad > ix->bc_slot_stride) ix->bc_slot_stride = nq_pad;
+        if (qkeep_need > ix->bc_qkeep_stride) ix->bc_qkeep_stride = qkeep_need;
+    }
     if ((rc = grow(&ix->d_overflow, &ix->overflow_cap,
                    (size_t)ix->bc_slot_stride * LS_BC_SLOTS)) != LS_OK)
         return rc;
+    if ((rc = grow(&ix->d_qkeep, &ix->qkeep_cap,
+                   (size_t)ix->bc_qkeep_stride * LS_BC_SLOTS)) != LS_OK)
+        return rc;
     const int slot = (int)ix->bc_pending.size();
     u32* d_flags = ix->d_overflow + (size_t)slot * ix->bc_slot_stride;
-    if ((rc = grow(&ix->d_sample_top, &ix->sample_top_cap, nwg * LS_GEMM_THREADS * QG * 4)) != LS_OK)
-        return rc;
+    float* d_qkeep = ix->d_qkeep + (size_t)slot * ix->bc_qkeep_stride;
+    if ((rc = grow(&ix->d_sample_top, &ix->sample_top_cap, nrec * 16)) != LS_OK) return rc;
     if ((rc = grow_pinned(&ix->h_overflow, &ix->h_overflow_cap,
                           (size_t)ix->bc_slot_stride * LS_BC_SLOTS)) != LS_OK)
         return rc;
+    ls_gemm_bufs bufs;
+    bufs.d_rec = ix->d_rec;
+    bufs.d_rcnt = ix->d_rcnt;
+    bufs.d_spill = ix->d_spill;
+    bufs.d_scnt = ix->d_scnt;
+    bufs.d_overflow = d_flags;
+    bufs.d_sample_top = ix->d_sample_top;
 
     const bool prof = ix->profiling && ix->prof_n < LS_PROF_MAX;
     hipEvent_t* pe = nullptr;
@@ -579,13 +624,12 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         }
         pe = &ix->prof_ev[2 * ix->prof_n];
     }
-    rc = ls_launch_prep_f16(d_q, ix->d_qh, nq, nq_pad, g, (flags & LS_FLAG_NORMALIZE) != 0,
-                            d_flags, s);
+    rc = ls_launch_prep_f16(d_q, ix->d_qh, d_qkeep, nq, nq_pad, g,
+                            (flags & LS_FLAG_NORMALIZE) != 0, d_flags, s);
     if (rc != LS_OK) return rc;
-    // sample pass: LS_GEMM_SAMPLE_ROWS rows of every slice, spread over the slice
+    // sample pass: a few tiles of every slice, spread over the slice
     rc = ls_launch_gemm_filter(ix->d_corpus, ix->n, g, ix->d_qh, nq, nq_pad, nullptr, nsplits, rps,
-                               sample_stride, ix->d_queues, ix->d_counts, cap, d_flags,
-                               ix->d_sample_top, s);
+                               sample_stride, bufs, s);
     if (rc != LS_OK) return rc;
     // Speculative threshold. The k-th best SAMPLE score is a certified lower bound of the final
     // k-th best but passes ~k*N/M0 rows per query. The j-th best sample score (j < k) passes only
@@ -605,28 +649,26 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
             }
         }
     }
-    static const bool abl_nopass = getenv("LS_GEMM_ABL_NOPASS") != nullptr;  // timing ablation only
-    rc = ls_launch_tau(ix->d_sample_top, nsplits, nq, nq_pad, g, jrank, ix->d_tau, s);
-    if (abl_nopass)  // every tau = FLT_MAX: the epilogue never appends (results are garbage)
-        LS_HIP(hipMemsetD32Async((hipDeviceptr_t)ix->d_tau, 0x7f7fffff, (size_t)nq_pad, s));
+    rc = ls_launch_tau(ix->d_sample_top, nsplits, nq, nq_pad, jrank, ix->d_tau, s);
     if (rc != LS_OK) return rc;
     // full pass
     if (prof) LS_HIP(hipEventRecord(pe[0], s));
     rc = ls_launch_gemm_filter(ix->d_corpus, ix->n, g, ix->d_qh, nq, nq_pad, ix->d_tau, nsplits,
-                               rps, 1, ix->d_queues, ix->d_counts, cap, d_flags,
-                               ix->d_sample_top, s);
+                               rps, 1, bufs, s);
     if (rc != LS_OK) return rc;
     if (prof) {
         LS_HIP(hipEventRecord(pe[1], s));
         ix->prof_n++;
     }
-    if (abl_nopass) return LS_OK;
-    rc = ls_launch_batch_select(ix->d_queues, ix->d_counts, cap, nsplits, nq, nq_pad, g, k, ix->base,
-                                ix->n, rps,
-                                d_flags, d_out_s, d_out_i, s);
+    rc = ls_launch_batch_select(bufs, nsplits, nq, k, ix->base, ix->n, rps, d_out_s, d_out_i, s);
     if (rc != LS_OK) return rc;
+    LS_HIP(hipEventRecord(ix->bc_done, s));
+    ix->bc_used = true;
+    ix->bc_last_stream = s;
+    ix->n_batched_launches = 5;
+    ix->d_last_flags = d_flags;
+    ix->last_flags_n = nq;
     ls_index::batched_call bc;
-    bc.d_q = d_q;
     bc.nq = nq;
     bc.k = k;
     bc.flags = flags;
@@ -646,6 +688,8 @@ static int search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t 
         uint32_t f = host_api ? (flags & ~(LS_FLAG_ASYNC | LS_FLAG_PIPELINE)) : flags;
         return batched_search_on_stream(ix, d_q, nq, k, f, d_out_s, d_out_i, s);
     }
+    ix->d_last_flags = nullptr;  // the scan path is exact in stream order: nothing to verify
+    ix->last_flags_n = 0;
     return scan_search_on_stream(ix, d_q, nq, k, flags, d_out_s, d_out_i, s);
 }
 
@@ -671,10 +715,6 @@ static int check_search_args(const ls_index* ix, const void* q, int64_t nq, int3
     return LS_OK;
 }
 
-#ifndef LS_ZC_IN_DEFAULT
-#define LS_ZC_IN_DEFAULT 1
-#define LS_ZC_OUT_DEFAULT 1
-#endif
 
 extern "C" {
 
@@ -704,11 +744,9 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
     }
     // Pinned host buffers are device-visible: kernels read the queries from h_q and write the
     // results into h_out_* over PCIe themselves, which saves the copy commands' serial latency
-    // (LS_ZC_IN / LS_ZC_OUT; measured in tools/hostapi_time.py).
-    static const int zc_in = getenv("LS_ZC_IN") ? atoi(getenv("LS_ZC_IN")) : LS_ZC_IN_DEFAULT;
-    static const int zc_out = getenv("LS_ZC_OUT") ? atoi(getenv("LS_ZC_OUT")) : LS_ZC_OUT_DEFAULT;
-    const bool in_direct = zc_in && nq <= LS_SCAN_MAX_NQ;    // big batches: one bulk copy is better
-    const bool out_direct = zc_out && on <= (size_t)(1 << 16);
+    // (measured in tools/hostapi_time.py).
+    const bool in_direct = nq <= LS_SCAN_MAX_NQ;    // big batches: one bulk copy is better
+    const bool out_direct = on <= (size_t)(1 << 16);
     memcpy(ix->h_q, q, qn * sizeof(float));
     if (!in_direct)
         LS_HIP(hipMemcpyAsync(ix->d_qraw, ix->h_q, qn * sizeof(float), hipMemcpyHostToDevice, s));
@@ -756,6 +794,78 @@ int ls_check(ls_index* ix, void* stream) {
     return LS_OK;
 }
 
+// index.add(x) on a built index (reference extract/index.py:116): the stored rows are carried over
+// device-to-device, only the new rows cross PCIe. Synchronises the handle first.
+int ls_add(ls_index* ix, const float* rows, int64_t n_add) {
+    if (!ix || n_add < 0 || (n_add > 0 && !rows)) {
+        ls_set_error("ls_add: bad argument");
+        return LS_ERR_INVALID_ARG;
+    }
+    if (n_add == 0) return LS_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->n + n_add >= 0xffffffffll) {
+        ls_set_error("ls_add: %lld rows exceed the 2^32-1 rows one shard can index",
+                     (long long)(ix->n + n_add));
+        return LS_ERR_INVALID_ARG;
+    }
+    LS_HIP(hipSetDevice(ix->device));
+    int rc = flush_pending(ix);
+    if (rc == LS_OK) rc = batched_repair(ix);
+    if (rc != LS_OK) return rc;
+    LS_HIP(hipDeviceSynchronize());  // nothing queued on any stream may still read the old buffers
+    const int64_t old_n = ix->n;
+    rc = alloc_rows(ix, old_n + n_add);
+    if (rc != LS_OK) return rc;
+    ix->n = old_n + n_add;
+    return upload_rows(ix, old_n, rows, n_add);
+}
+
+// index.reconstruct_n(row0, count): the stored rows as float32 [count, d] in host memory (fp16
+// storage returns the rounded values). Used to write an index file without keeping a host copy.
+int ls_reconstruct(ls_index* ix, int64_t row0, int64_t count, float* out) {
+    if (!ix || row0 < 0 || count < 0 || row0 + count > ix->n || (count > 0 && !out)) {
+        ls_set_error("ls_reconstruct: bad argument");
+        return LS_ERR_INVALID_ARG;
+    }
+    if (count == 0) return LS_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    LS_HIP(hipSetDevice(ix->device));
+    const ls_geom& g = ix->g;
+    const char* src = (const char*)ix->d_corpus + (size_t)row0 * g.chunks * 16;
+    if (ix->dtype == LS_DTYPE_F32 && g.d_pad == g.d) {
+        LS_HIP(hipMemcpy(out, src, (size_t)count * g.d * sizeof(float), hipMemcpyDeviceToHost));
+        return LS_OK;
+    }
+    const int64_t slab = std::max<int64_t>(1, (int64_t)(256ll << 20) / ((int64_t)g.d * 4));
+    float* stage = nullptr;
+    LS_HIP(hipMalloc((void**)&stage, (size_t)std::min(slab, count) * g.d * sizeof(float)));
+    int rc = LS_OK;
+    for (int64_t r0 = 0; rc == LS_OK && r0 < count; r0 += slab) {
+        const int64_t nr = std::min(slab, count - r0);
+        rc = ls_launch_unconvert(src + (size_t)r0 * g.chunks * 16, stage, nr, g, ix->own_stream);
+        if (rc == LS_OK && (hipStreamSynchronize(ix->own_stream) != hipSuccess ||
+                            hipMemcpy(out + r0 * g.d, stage, (size_t)nr * g.d * sizeof(float),
+                                      hipMemcpyDeviceToHost) != hipSuccess)) {
+            ls_set_error("ls_reconstruct: HIP copy/launch failed");
+            rc = LS_ERR_HIP;
+        }
+    }
+    (void)hipFree(stage);
+    return rc;
+}
+
+// faiss.normalize_L2 on a host array: per-device pinned staging buffers that the kernel reads and
+// writes over PCIe itself, cached across calls (no allocation, no copy command, one stream
+// sync per call).
+struct ls_norm_cache {
+    std::mutex mu;
+    float* h_in = nullptr;
+    float* h_out = nullptr;
+    size_t cap = 0;  // floats
+    hipStream_t s = nullptr;
+};
+static ls_norm_cache g_norm[64];
+
 int ls_normalize_l2(float* x, int64_t nq, int32_t d, int32_t device) {
     if (nq < 0 || d <= 0 || (nq > 0 && !x)) {
         ls_set_error("ls_normalize_l2: bad argument");
@@ -764,28 +874,56 @@ int ls_normalize_l2(float* x, int64_t nq, int32_t d, int32_t device) {
     int rc = check_device(device);
     if (rc != LS_OK) return rc;
     if (nq == 0) return LS_OK;
-    LS_HIP(hipSetDevice(device));
-    float *din = nullptr, *dout = nullptr;
-    const size_t bytes = (size_t)nq * d * sizeof(float);
-    LS_HIP(hipMalloc((void**)&din, bytes));
-    hipError_t e = hipMalloc((void**)&dout, bytes);
-    if (e != hipSuccess) {
-        (void)hipFree(din);
-        ls_set_error("ls_normalize_l2: hipMalloc failed: %s", hipGetErrorString(e));
-        return LS_ERR_HIP;
+    if (device >= 64) {
+        ls_set_error("ls_normalize_l2: device ordinal %d not supported", device);
+        return LS_ERR_NO_DEVICE;
     }
+    LS_HIP(hipSetDevice(device));
+    ls_norm_cache& nc = g_norm[device];
+    std::lock_guard<std::mutex> lk(nc.mu);
+    if (!nc.s) LS_HIP(hipStreamCreateWithFlags(&nc.s, hipStreamNonBlocking));
     ls_geom g{};
     g.d = d;
     g.d_pad = d;
-    rc = LS_OK;
-    if (hipMemcpy(din, x, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = LS_ERR_HIP;
-    if (rc == LS_OK) rc = ls_launch_prep(din, dout, nq, g, true, false, nullptr);
-    if (rc == LS_OK && hipMemcpy(x, dout, bytes, hipMemcpyDeviceToHost) != hipSuccess)
-        rc = LS_ERR_HIP;
-    if (rc == LS_ERR_HIP) ls_set_error("ls_normalize_l2: HIP copy/launch failed");
-    (void)hipFree(din);
-    (void)hipFree(dout);
-    return rc;
+    const int64_t rows_per_pass = std::max<int64_t>(1, (int64_t)(64ll << 20) / ((int64_t)d * 4));
+    for (int64_t r0 = 0; r0 < nq; r0 += rows_per_pass) {
+        const int64_t rows = std::min(rows_per_pass, nq - r0);
+        const size_t cnt = (size_t)rows * d;
+        if (cnt > nc.cap) {
+            size_t c1 = nc.cap, c2 = nc.cap;
+            if ((rc = grow_pinned(&nc.h_in, &c1, cnt)) != LS_OK) return rc;
+            if ((rc = grow_pinned(&nc.h_out, &c2, cnt)) != LS_OK) return rc;
+            nc.cap = std::min(c1, c2);
+        }
+        memcpy(nc.h_in, x + r0 * d, cnt * sizeof(float));
+        rc = ls_launch_prep(nc.h_in, nc.h_out, rows, g, true, false, nc.s);
+        if (rc != LS_OK) return rc;
+        LS_HIP(hipStreamSynchronize(nc.s));
+        memcpy(x + r0 * d, nc.h_out, cnt * sizeof(float));
+    }
+    return LS_OK;
+}
+
+// Copy the per-query verification flags of the most recent search queued on this handle into
+// d_dst (device memory, u32 [nq]) on `stream`: non-zero = that query will be repaired by the next
+// ls_check. The scan path is always exact, so its calls export zeros.
+int ls_export_flags(ls_index* ix, void* d_dst, int64_t nq, void* stream) {
+    if (!ix || nq < 0 || (nq > 0 && !d_dst)) {
+        ls_set_error("ls_export_flags: bad argument");
+        return LS_ERR_INVALID_ARG;
+    }
+    if (nq == 0) return LS_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    LS_HIP(hipSetDevice(ix->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (ix->d_last_flags && ix->last_flags_n == nq) {
+        if (ix->bc_last_stream != s) LS_HIP(hipStreamWaitEvent(s, ix->bc_done, 0));
+        LS_HIP(hipMemcpyAsync(d_dst, ix->d_last_flags, sizeof(u32) * (size_t)nq,
+                              hipMemcpyDeviceToDevice, s));
+    } else {
+        LS_HIP(hipMemsetAsync(d_dst, 0, sizeof(u32) * (size_t)nq, s));
+    }
+    return LS_OK;
 }
 
 int ls_merge_topk(const void* d_scores_in, const void* d_indices_in, int32_t n_lists, int64_t nq,
@@ -899,9 +1037,10 @@ int ls_debug_read_scores(ls_index* ix, float* out, int64_t count) {
 }
 
 int64_t ls_debug_counter(ls_index* ix, int32_t which) {
-    if (!ix || which < 0 || which > 8) return -1;
+    if (!ix || which < 0 || which > 9) return -1;
     std::lock_guard<std::mutex> lk(ix->mu);
     if (which == 8) return (int64_t)ix->n_batched_fallback;
+    if (which == 9) return (int64_t)ix->n_batched_launches;
     if (hipSetDevice(ix->device) != hipSuccess) return -1;
     u32 v = 0;
     if (hipMemcpy(&v, ix->d_counters + which, sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess)
@@ -910,7 +1049,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
 }
 
 const char* ls_last_error(void) { return g_err; }
-const char* ls_version(void) { return "leansearch-mi355x 0.1.0 (gfx950)"; }
+const char* ls_version(void) { return "leansearch-mi355x 0.2.0 (gfx950)"; }
 int32_t ls_device_count(void) {
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cfloat>
 
 #include "../../include/leansearch.h"
@@ -35,14 +36,16 @@ typedef unsigned int u32;
 #define LS_GEMM_TM_SHORT 64          // corpus rows per LDS tile for stored rows <= 1 KiB
 #endif
 #define LS_GEMM_WG_PER_CU (8 / LS_GEMM_WAVES)
-#define LS_GEMM_MAX_K 128            // batched path handles k <= this (larger k: scan path)
+#define LS_GEMM_MAX_K 1024           // batched path handles k <= this (the reference uses 1000)
 #define LS_GEMM_MAX_CHUNKS 128       // ... and stored rows <= 2 KiB (d <= 1024 fp16)
 #define LS_GEMM_MIN_ROWS 32768       // ... and shards at least this big,
 #define LS_GEMM_MIN_ROWS_BIGNQ 8192  // or this big when the batch has >= LS_GEMM_BIGNQ queries
 #define LS_GEMM_BIGNQ 128            // (small shards of a many-GPU run: ~60 us fixed vs nq/8 scans)
-#define LS_GEMM_QCAP 32              // entries per private candidate queue
+#define LS_GEMM_QL 7                 // candidate-queue entries per (lane, query) kept in LDS
+#define LS_GEMM_REC (4 * LS_GEMM_QL) // entries of one compacted (query, slice) record in HBM
+#define LS_GEMM_SCAP 32              // entries of a lane's HBM spill queue (past the LDS part)
 #define LS_GEMM_SAMPLE_ROWS 128      // sample pass: rows per workgroup
-#define LS_GEMM_MAX_SPLITS 128       // corpus slices (the select kernel walks 4 queues per slice)
+#define LS_GEMM_MAX_SPLITS 256       // corpus slices (the select kernel gives each one a thread)
 
 __host__ __device__ __forceinline__ u32 ls_ord(float f) {
     f = f + 0.0f;  // folds -0.0 into +0.0
@@ -74,6 +77,36 @@ void ls_set_error(const char* fmt, ...);
             return LS_ERR_HIP;                                                           \
         }                                                                                \
     } while (0)
+
+// hipFuncSetAttribute applies to ONE device: remember per (kernel, device) that it was applied.
+struct ls_attr_once {
+    std::atomic<unsigned char> done[64];
+};
+static inline int ls_set_max_dynamic_lds(ls_attr_once& st, const void* fn, int bytes) {
+    int dev = 0;
+    LS_HIP(hipGetDevice(&dev));
+    const bool tracked = dev >= 0 && dev < 64;
+    if (!tracked || !st.done[dev].load(std::memory_order_acquire)) {
+        LS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        if (tracked) st.done[dev].store(1, std::memory_order_release);
+    }
+    return LS_OK;
+}
+
+// ---- the library's ONE summation order for faiss.normalize_L2's squared norm ------------------
+// (reference search/engine.py:242; FAISS's own SIMD order is not observable here, so it is fixed
+// by definition and mirrored by oracle_normalize_l2): lane l of a wave accumulates x[l], x[l+64],
+// ... with fused multiply-adds in increasing index; the 64 partial sums are combined by the xor
+// butterfly 32, 16, 8, 4, 2, 1 (every lane ends with the same value). Every kernel that
+// normalises a query calls this, so a normalised query is bit-identical on every path.
+#ifdef __HIPCC__
+__device__ __forceinline__ float ls_wave_sumsq(const float* __restrict__ x, int d, int lane) {
+    float ss = 0.0f;
+    for (int j = lane; j < d; j += 64) ss = fmaf(x[j], x[j], ss);
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    return ss;
+}
+#endif
 
 // ---- geometry of the HBM-resident corpus -----------------------------------------------------
 // A row is stored as `chunks` 16-byte chunks (4 fp32 or 8 fp16), zero padded so that
@@ -114,6 +147,8 @@ int ls_launch_prep(const float* d_q_in, float* d_q_out, int64_t nq, const ls_geo
 // corpus conversion: dst[n, d_pad] (fp32 or fp16) from src fp32 [n, d]
 int ls_launch_convert(const float* d_src, void* d_dst, int64_t n, const ls_geom& g,
                       hipStream_t s);
+int ls_launch_unconvert(const void* d_src, float* d_dst, int64_t n, const ls_geom& g,
+                        hipStream_t s);
 // scan: scores S[n] for one RAW query (d floats; normalisation / fp16 rounding fused in)
 // + per-workgroup best kprime keys and bound
 int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu);
@@ -143,20 +178,27 @@ int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const ls_s
 // NEXT query's scan launch as one extra workgroup (ls_launch_scan's `fin` argument).
 int ls_launch_finalize(const struct ls_fin_batch& jobs, int njobs, hipStream_t s);
 // batched MFMA path (ls_gemm.hip)
-int ls_launch_prep_f16(const float* d_q, void* d_qh, int64_t nq, int64_t nq_pad, const ls_geom& g,
-                       bool normalize, u32* d_overflow, hipStream_t s);
+struct ls_gemm_bufs {
+    void* d_rec;        // uint2 [nq_pad][nsplits][LS_GEMM_REC]
+    u32* d_rcnt;        // [nq_pad][nsplits]
+    void* d_spill;      // uint2 [nq_pad][nsplits][4][LS_GEMM_SCAP]
+    u32* d_scnt;        // [nq_pad][nsplits][4]
+    u32* d_overflow;    // [nq_pad] repair flags of this call
+    u32* d_sample_top;  // [nq_pad][nsplits][4][4]
+};
+int ls_launch_prep_f16(const float* d_q, void* d_qh, float* d_qkeep, int64_t nq, int64_t nq_pad,
+                       const ls_geom& g, bool normalize, u32* d_overflow, hipStream_t s);
 int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, const void* d_qh,
                           int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
-                          int64_t rows_per_split, int tile_stride, u64* d_queues, u32* d_counts,
-                          int cap, u32* d_overflow, u32* d_sample_top, hipStream_t s);
-int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_pad, const ls_geom& g,
-                  int j_rank, float* d_tau, hipStream_t s);
-int ls_gemm_qg(const ls_geom& g);         // query groups of 16 per wave (2, or 1 for long rows)
+                          int64_t rows_per_split, int tile_stride, const ls_gemm_bufs& b,
+                          hipStream_t s);
+int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_pad, int j_rank,
+                  float* d_tau, hipStream_t s);
+int ls_gemm_qg(const ls_geom& g);         // query groups of 16 per wave (2, or 1 for 2 KiB rows)
 int ls_gemm_tile_rows(const ls_geom& g);  // corpus rows per LDS tile (64, or 32 for long rows)
-int ls_launch_batch_select(const u64* d_queues, const u32* d_counts, int cap, int nsplits,
-                           int64_t nq, int64_t nq_pad, const ls_geom& g, int k, int64_t base, int64_t n, int64_t rows_per_split,
-                           u32* d_overflow, float* d_out_scores, int64_t* d_out_indices,
-                           hipStream_t s);
+int ls_launch_batch_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k, int64_t base,
+                           int64_t n, int64_t rows_per_split, float* d_out_scores,
+                           int64_t* d_out_indices, hipStream_t s);
 // merge of per-shard lists
 int ls_launch_merge(const float* d_scores_in, const int64_t* d_indices_in, int64_t stride_s_bytes,
                     int64_t stride_i_bytes, int32_t n_lists, int64_t nq, int32_t k,

@@ -4,46 +4,51 @@
 // (reference src/lean_explore/search/engine.py:250; the reference itself only ever sends nq=1).
 //
 // Why fused: the score matrix is nq*N fp32 = 819 MB for config 3; writing and re-reading it
-// would cost more HBM time than the whole MFMA budget, so scores never leave registers.
+// would cost more HBM time than the whole MFMA budget, so scores never leave the CU.
 //
 // ls_gemm_filter_kernel — one workgroup = 8 waves x (16*QG queries) x one corpus slice
-//   - v_mfma_f32_16x16x32_f16. A wave owns QG groups of 16 queries (QG = 2 for stored rows
-//     <= 1 KiB, else 1): their fp16 fragments stay in VGPRs for the whole slice, so B costs no
-//     LDS or HBM traffic in the loop.
+//   - v_mfma_f32_16x16x32_f16. A wave owns QG = 2 groups of 16 queries (1 only for stored rows of
+//     2 KiB): their fp16 fragments stay in VGPRs for the whole slice, so B costs no LDS or HBM
+//     traffic in the loop. For 1.5 KiB rows (config 4) that is 192 of the wave's 256 registers;
+//     the kernel then keeps ONE accumulator set and the two waves of a SIMD filter at opposite
+//     ends of a tile, so one of them always feeds the matrix pipe (see run_tile).
 //   - A operand (corpus): tiles of TM rows (64, or 32 for long rows) stream HBM/L2 -> LDS by DMA
 //     (global_load_lds, 16 B/lane, double buffered) and are shared by the 8 waves. LDS rows are
 //     XOR-swizzled on the SOURCE address (chunk ^ (row & 15)): conflict-free ds_read_b128.
-//   - a tile is TM/16 row blocks x QG query groups = up to 8 INDEPENDENT accumulator chains per
-//     wave, each A fragment feeding QG MFMAs: the matrix pipe never waits on a dependent result
-//     (tools/mfma_ub.hip: 4+ chains with interleaved LDS reads run at the pipe's ceiling).
-//   - epilogue: lane (query, quarter) holds 4 row scores per accumulator. The PREVIOUS tile's
-//     accumulators are filtered a few elements per k-step, in the shadow of the matrix pipe: a
-//     score >= tau[query] is appended to the lane's private queue in HBM (no atomics).
+//   - epilogue: lane (query, quarter) holds 4 row scores per accumulator; a score >= tau[query]
+//     is appended to the lane's private queue. The first QL entries of a queue live in the LDS
+//     the tiles leave free (a ds_write_b64, no HBM traffic, no atomics); the rare lane that sees
+//     more spills to a private HBM queue. When the slice is done the four quarter-queues of a
+//     query are compacted into ONE contiguous record per (query, slice) in HBM: the select kernel
+//     reads 1-2 lines per slice instead of walking 4 scattered queues.
 //   - workgroups that share a corpus slice sit on the same XCD (block % 8) so the slice is
 //     fetched from HBM once and served to the other query tiles from that XCD's L2.
 //
-// Phases (ls_api.hip orchestrates): sample pass (two tiles of every slice; each lane keeps its 4
+// Phases (ls_api.hip orchestrates): sample pass (a few tiles of every slice; each lane keeps its 4
 // best sample scores in registers) -> tau kernel (j-th best sample score per query) -> full pass
-// with tau -> select kernel (exact top-k of each query's queues, verifies >= k candidates). A
+// with tau -> select kernel (exact top-k of each query's records, verifies >= k candidates). A
 // flagged query (queue overflow / too few candidates) is re-run by the exact per-query scan
 // path, so the result is always exact.
 #include "ls_select_dev.h"
 
-#ifndef LS_GEMM_LOADERS
-#define LS_GEMM_LOADERS 2  // loader waves per workgroup for long rows (0 = MFMA waves issue the DMA)
-#endif
-#ifndef LS_GEMM_PF
-#define LS_GEMM_PF 1
-#endif
-#ifndef LS_GEMM_CHECK_NUM
-#define LS_GEMM_CHECK_NUM 1
-#define LS_GEMM_CHECK_DEN 1
-#endif
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+#define LS_GEMM_LDS_BYTES (160 * 1024)  // the whole LDS of a CU: one workgroup per CU
+
+// ---- static geometry of one instantiation ------------------------------------------------------
+__host__ __device__ constexpr int gemm_qg(int chunks) { return chunks <= 96 ? 2 : 1; }
+__host__ __device__ constexpr int gemm_tm(int chunks) { return chunks <= 64 ? LS_GEMM_TM_SHORT : 32; }
+__host__ __device__ constexpr int gemm_tile_bytes(int chunks) { return gemm_tm(chunks) * chunks * 16; }
+// LDS queue entries per (lane, query group): what two tile buffers leave free, at most LS_GEMM_QL
+__host__ __device__ constexpr int gemm_ql(int chunks) {
+    const int left = LS_GEMM_LDS_BYTES - 2 * gemm_tile_bytes(chunks);
+    const int per = left / (LS_GEMM_THREADS * gemm_qg(chunks) * 8);
+    return per < 0 ? 0 : (per > LS_GEMM_QL ? LS_GEMM_QL : per);
+}
 
 // ---- queries -> fp16 MFMA B fragments, normalised if asked, zero padded ---------------------------
 // Output layout = the order in which ls_gemm_filter_kernel consumes it: the 16-byte chunk c of
@@ -54,10 +59,13 @@ __device__ __forceinline__ long long qfrag_chunk(int q, int c, int QG, int KS) {
     const int qt = q / QT, w = (q % QT) / QPW, g2 = (q % QPW) / 16, li = q % 16;
     return ((((long long)(qt * LS_GEMM_WAVES + w) * QG + g2) * KS + (c >> 2)) << 6) + ((c & 3) << 4) + li;
 }
-// One wave per query (4 queries per block): the norm is a wave reduction, every lane converts
-// and stores whole 16-byte chunks.
+// One wave per query (4 queries per block): the norm is the library's canonical wave reduction
+// (ls_wave_sumsq), every lane converts and stores whole 16-byte chunks. The raw fp32 queries are
+// also copied into the call's own slot (`qkeep`): a later repair of a flagged query must not
+// depend on the caller keeping its query buffer alive.
 __global__ __launch_bounds__(256) void ls_prep_f16_kernel(const float* __restrict__ qin,
-                                                          u32x4* __restrict__ qout, int nq,
+                                                          u32x4* __restrict__ qout,
+                                                          float* __restrict__ qkeep, int nq,
                                                           int nq_pad, int d, int d_pad, int QG,
                                                           int normalize, u32* __restrict__ overflow) {
     const int lane = threadIdx.x & 63;
@@ -69,11 +77,11 @@ __global__ __launch_bounds__(256) void ls_prep_f16_kernel(const float* __restric
     const bool live = qi < nq;
     float inv = 1.0f;
     if (normalize && live) {
-        float ss = 0.0f;
-        for (int j = lane; j < d; j += 64) ss = fmaf(src[j], src[j], ss);
-        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float ss = ls_wave_sumsq(src, d, lane);
         if (ss > 0.0f) inv = 1.0f / sqrtf(ss);
     }
+    if (live && qkeep)
+        for (int j = lane; j < d; j += 64) qkeep[(long long)qi * d + j] = src[j];
     for (int c = lane; c < chunks; c += 64) {
         half8 h;
 #pragma unroll
@@ -86,11 +94,10 @@ __global__ __launch_bounds__(256) void ls_prep_f16_kernel(const float* __restric
     }
 }
 
-int ls_gemm_qg(const ls_geom& g);
-int ls_launch_prep_f16(const float* d_q, void* d_qh, int64_t nq, int64_t nq_pad, const ls_geom& g,
-                       bool normalize, u32* d_overflow, hipStream_t s) {
+int ls_launch_prep_f16(const float* d_q, void* d_qh, float* d_qkeep, int64_t nq, int64_t nq_pad,
+                       const ls_geom& g, bool normalize, u32* d_overflow, hipStream_t s) {
     hipLaunchKernelGGL(ls_prep_f16_kernel, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, s, d_q,
-                       (u32x4*)d_qh, (int)nq, (int)nq_pad, g.d, g.d_pad, ls_gemm_qg(g),
+                       (u32x4*)d_qh, d_qkeep, (int)nq, (int)nq_pad, g.d, g.d_pad, ls_gemm_qg(g),
                        normalize ? 1 : 0, d_overflow);
     LS_HIP(hipGetLastError());
     return LS_OK;
@@ -103,15 +110,11 @@ __device__ __forceinline__ void wg_coords(int b, int nqt, int* split, int* qt) {
     *split = (j / nqt) * 8 + xcd;
     *qt = j % nqt;
 }
-__host__ __device__ __forceinline__ int wg_index(int split, int qt, int nqt) {
-    return (((split >> 3) * nqt + qt) << 3) | (split & 7);
-}
 // Query q of a launch with QG groups per wave lives in tile qt = q / (128*QG), wave
 // w = (q % (128*QG)) / (16*QG), group qg = (q % (16*QG)) / 16, li = q % 16; in every workgroup of
-// its tile 4 lanes (quarter = 0..3) own a private queue for it. Queues, their lengths and the
-// sample tops are stored QUERY-MAJOR, [query][slice][quarter]: everything the tau and select
-// kernels read for one query is contiguous (they are the consumers with a dependent round trip;
-// the producers' scattered 16-byte stores cost nothing).
+// its tile 4 lanes (quarter = 0..3) filter for it. Everything the tau and select kernels read for
+// one query is contiguous: sample tops and spill queues [query][slice][quarter], records and
+// their lengths [query][slice].
 __host__ __device__ __forceinline__ long long queue_id(int q, int split, int quarter, int nsplits) {
     return ((long long)q * nsplits + split) * 4 + quarter;
 }
@@ -132,38 +135,36 @@ __device__ __forceinline__ uint4 top4_keys(const float (&t)[4]) {  // 0 = "no sa
                       t[2] == -FLT_MAX ? 0u : ls_ord(t[2]), t[3] == -FLT_MAX ? 0u : ls_ord(t[3]));
 }
 
-// Long rows, full pass: two extra LOADER waves per workgroup issue the tile DMA. An LDS-DMA piece
-// costs the issuing wave ~150 cycles (tools/pmc_c4_sq.sh), six pieces per wave are 900 of a
-// long-row tile's ~2400 cycles; with dedicated loaders the eight MFMA waves never issue it.
-// (10 waves = 3 on two of the SIMDs: needs <= 168 registers, which only the long-row kernel,
-// with one query group per wave, has.)
-__host__ __device__ constexpr int ls_gemm_loaders(int chunks, bool sample) {
-    return (LS_GEMM_LOADERS && chunks == 96 && !sample) ? LS_GEMM_LOADERS : 0;
-}
+struct ls_gemm_out {
+    uint2* rec;        // [nq_pad][nsplits][LS_GEMM_REC] (score bits, slice-relative row)
+    u32* rcnt;         // [nq_pad][nsplits] entries in the record | spill mask << 8
+    uint2* spill;      // [nq_pad][nsplits][4][LS_GEMM_SCAP] private HBM queues past the LDS part
+    u32* scnt;         // [nq_pad][nsplits][4] entries a spilling lane wrote
+    u32* overflow;     // [nq_pad] per-query repair flag
+    u32* sample_top;   // [nq_pad][nsplits][4][4] (sample pass)
+};
+
 template <int CHUNKS, int QG, bool SAMPLE>
-__global__ __launch_bounds__(LS_GEMM_THREADS + 64 * ls_gemm_loaders(CHUNKS, SAMPLE),
-                             ls_gemm_loaders(CHUNKS, SAMPLE) ? 3 : LS_GEMM_WAVES_PER_SIMD)
-void ls_gemm_filter_kernel(
+__global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_gemm_filter_kernel(
     const u32x4* __restrict__ corpus, long long n, const u32x4* __restrict__ qh, int nq, int nqt,
-    const float* __restrict__ tau, long long rows_per_split, int tile_stride,
-    u64* __restrict__ queues, u32* __restrict__ counts, int cap, u32* __restrict__ overflow,
-    u32* __restrict__ sample_top) {
-    constexpr int TM = CHUNKS <= 64 ? LS_GEMM_TM_SHORT : 32;  // corpus rows per LDS tile
-    constexpr int NRB = TM / 16;                          // 16-row MFMA blocks per tile
-    constexpr int KS = CHUNKS / 4;                        // k-steps: 32 fp16 = 4 chunks each
-    constexpr int QPW = 16 * QG;                          // queries per wave
-    constexpr int NV = NRB * QG * 4;                      // filter values per lane per tile
-    // The filter's queue appends are global stores, and the tile hand-over barrier drains vmcnt:
-    // a store issued in a tile's last k-steps would hold the barrier for its whole round trip.
-    // So the previous tile is filtered in the FIRST LS_GEMM_CHECK_NUM/DEN of the k-steps only.
-    constexpr int CKS = (KS * LS_GEMM_CHECK_NUM + LS_GEMM_CHECK_DEN - 1) / LS_GEMM_CHECK_DEN;
-    constexpr int CPK = (NV + CKS - 1) / CKS;             // checks interleaved per k-step
+    const float* __restrict__ tau, long long rows_per_split, int tile_stride, ls_gemm_out out) {
+    constexpr int TM = gemm_tm(CHUNKS);    // corpus rows per LDS tile
+    constexpr int NRB = TM / 16;           // 16-row MFMA blocks per tile
+    constexpr int KS = CHUNKS / 4;         // k-steps: 32 fp16 = 4 chunks each
+    constexpr int QPW = 16 * QG;           // queries per wave
+    constexpr int NV = NRB * QG * 4;       // filter values per lane per tile
+    // B fragments of QG groups take KS*QG*4 registers. When that leaves too little for two
+    // accumulator sets, one set is kept and a chain is filtered right before it restarts.
+    constexpr bool ONE_ACC = KS * QG * 4 >= 128;
+    constexpr int CPK = (NV + KS - 1) / KS;  // two sets: checks interleaved per k-step
     constexpr int ROW_BYTES = CHUNKS * 16;
     constexpr int TILE_CHUNKS = TM * CHUNKS;
     constexpr int TILE_BYTES = TILE_CHUNKS * 16;
     constexpr int LOADS = TILE_CHUNKS / LS_GEMM_THREADS;  // 16-byte DMA loads per thread per tile
+    constexpr int QL = SAMPLE ? 0 : gemm_ql(CHUNKS);
     static_assert(TILE_CHUNKS % LS_GEMM_THREADS == 0, "tile must split evenly over the threads");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 tiles
+    static_assert(QL * 4 <= LS_GEMM_REC, "a record holds the four LDS quarter-queues");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // tiles | lane queues
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar DMA addressing
@@ -175,60 +176,7 @@ void ls_gemm_filter_kernel(
     long long r_end = r_begin + rows_per_split;
     if (r_end > n) r_end = n;
     const int ntiles_all = r_begin < r_end ? (int)((r_end - r_begin + TM - 1) / TM) : 0;
-#ifdef LS_GEMM_ABL_NOLOOP  // timing ablation: prologue + epilogue only (cap is never negative)
-    const int nt = cap < 0 ? 1 : 0;
-#elif defined(LS_GEMM_ABL_HALF)  // timing ablation: half the tiles
-    const int nt = ((ntiles_all + tile_stride - 1) / tile_stride) / 2;
-#else
     const int nt = (ntiles_all + tile_stride - 1) / tile_stride;  // tiles this launch visits
-#endif
-
-    constexpr int NLOAD = ls_gemm_loaders(CHUNKS, SAMPLE);
-    if (NLOAD > 0 && wave >= LS_GEMM_WAVES) {  // ---- loader waves: the tile DMA and nothing else
-        const int lw = wave - LS_GEMM_WAVES;
-        constexpr int PPL = TILE_CHUNKS / 64 / (NLOAD > 0 ? NLOAD : 1);  // 1 KiB pieces per loader
-        int lgoff[PPL];
-#pragma unroll
-        for (int j = 0; j < PPL; ++j) {
-            const int Lc = (lw + j * NLOAD) * 64 + lane;
-            const int r = Lc / CHUNKS, sl = Lc % CHUNKS;
-            lgoff[j] = r * CHUNKS + (sl ^ (r & 15));
-        }
-        auto lstage = [&](int ti, int buf) {
-            const u32x4* base = corpus + (r_begin + (long long)ti * TM) * CHUNKS;
-#pragma unroll
-            for (int j = 0; j < PPL; ++j) {
-                unsigned char* dst = smem + buf * TILE_BYTES + (lw + j * NLOAD) * 1024;
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + lgoff[j]), (lds_ptr_t)dst, 16, 0, 0);
-            }
-        };
-        // Ring of three tile buffers, two tiles ahead. Same barrier sequence as the MFMA waves
-        // (one before tile 0, one per tile). The loader has no other vector-memory traffic, so
-        // "tile i+1 has landed, tile i+2 may still fly" is exactly vmcnt(PPL): written by hand,
-        // with the bare barrier (a __syncthreads() would drain everything).
-        static_assert(NLOAD == 0 || PPL < 64, "vmcnt immediate");
-        constexpr int W = NLOAD > 0 ? PPL : 0;
-        auto hand_over = [&](bool newer_in_flight) {
-            asm volatile("" ::: "memory");
-            if (newer_in_flight)
-                __builtin_amdgcn_s_waitcnt(0x0F70 | (W & 15) | ((W >> 4) << 14));
-            else
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        };
-        if (nt > 0) lstage(0, 0);
-        if (nt > 1) lstage(tile_stride, 1);
-        hand_over(nt > 1);
-        int b = 0;  // ring slot of tile i
-        for (int i = 0; i < nt; ++i) {
-            const int b2 = b == 0 ? 2 : b - 1;  // slot of tile i+2 == slot of tile i-1 (consumed)
-            if (i + 2 < nt) lstage((i + 2) * tile_stride, b2);
-            hand_over(i + 2 < nt);
-            b = b == 2 ? 0 : b + 1;
-        }
-        return;
-    }
 
     // ---- corpus tiles: HBM/L2 -> LDS by DMA (global_load_lds, 16 B per lane), double buffered --
     // Wave w, load j fills the 64 consecutive LDS chunks starting at (w*LOADS + j)*64: chunk Lc
@@ -236,26 +184,40 @@ void ls_gemm_filter_kernel(
     // (the DMA destination is lane-linear, so the swizzle goes on the source address). The HBM
     // copy is padded with zero rows past n (ls_api.hip): no clamping. A tile takes ~3 us to
     // consume, longer than the DMA's flight, so one tile of look-ahead suffices.
-    int goff[LOADS];
-#pragma unroll
-    for (int j = 0; j < LOADS; ++j) {
-        const int Lc = (wave * LOADS + j) * 64 + lane;
-        const int r = Lc / CHUNKS, sl = Lc % CHUNKS;
-        goff[j] = r * CHUNKS + (sl ^ (r & 15));
-    }
-    auto stage = [&](int ti, int buf) {
-        if (NLOAD > 0) return;  // the loader waves do it
-        const u32x4* base = corpus + (r_begin + (long long)ti * TM) * CHUNKS;
+    // Register-starved instantiations (ONE_ACC) recompute the per-lane source offsets for every
+    // tile (a handful of VALU ops behind an opaque copy of the lane id): hoisted out of the tile
+    // loop they would be spilled and every reload would wait on the memory pipe.
+    int goff[ONE_ACC ? 1 : LOADS];
+    if constexpr (!ONE_ACC) {
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) {
+            const int Lc = (wave * LOADS + j) * 64 + lane;
+            const int r = Lc / CHUNKS, sl = Lc % CHUNKS;
+            goff[j] = r * CHUNKS + (sl ^ (r & 15));
+        }
+    }
+    auto stage = [&](int ti, int buf) {
+        const u32x4* base = corpus + (r_begin + (long long)ti * TM) * CHUNKS;
+        int lane_v = lane;
+        if constexpr (ONE_ACC) asm volatile("" : "+v"(lane_v));
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) {
+            int off;
+            if constexpr (ONE_ACC) {
+                const int Lc = (wave * LOADS + j) * 64 + lane_v;
+                const int r = Lc / CHUNKS, sl = Lc % CHUNKS;
+                off = r * CHUNKS + (sl ^ (r & 15));
+            } else {
+                off = goff[j];
+            }
             unsigned char* dst = smem + buf * TILE_BYTES + (wave * LOADS + j) * 1024;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + goff[j]), (lds_ptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + off), (lds_ptr_t)dst, 16, 0, 0);
         }
     };
 
     // The first tile(s) are requested BEFORE the query fragments: the HBM round trip of tile 0
     // then overlaps the (L2-resident) query loads instead of queueing behind them.
-    constexpr int NB_ALL = (144 * 1024) / TILE_BYTES;  // tiles that fit in the 144 KiB carve-out
+    constexpr int NB_ALL = LS_GEMM_LDS_BYTES / TILE_BYTES;  // tiles that fit in LDS together
     const bool sample_upfront = SAMPLE && nt > 0 && nt <= NB_ALL && nt <= 3;
     if (nt > 0) stage(0, 0);
     if (sample_upfront) {
@@ -266,7 +228,6 @@ void ls_gemm_filter_kernel(
     // B fragments: group qg holds query qt*8*QPW + wave*QPW + qg*16 + li; k-step kk -> chunk 4kk+qd
     half8 bq[QG][KS];
     int qj[QG];
-    bool qvalid[QG];
     float tauv[QG];
 #pragma unroll
     for (int g2 = 0; g2 < QG; ++g2) {
@@ -274,26 +235,17 @@ void ls_gemm_filter_kernel(
         // fragment-ordered by ls_prep_f16_kernel: each load below is one contiguous KiB per wave
         const u32x4* qfrag = qh + ((((long long)(qt * LS_GEMM_WAVES + wave) * QG + g2) * KS) << 6) + lane;
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-#ifdef LS_GEMM_ABL_NOBQ  // timing ablation: no query-fragment loads
-            const u32x4 v = {(u32)kk, (u32)cap, (u32)nq, (u32)lane};
-#else
-            const u32x4 v = qfrag[kk << 6];
-#endif
-            bq[g2][kk] = __builtin_bit_cast(half8, v);
-        }
-        qvalid[g2] = qj[g2] < nq;
+        for (int kk = 0; kk < KS; ++kk) bq[g2][kk] = __builtin_bit_cast(half8, qfrag[kk << 6]);
         tauv[g2] = SAMPLE ? 0.0f : tau[qj[g2]];
     }
 
-    // private queues of this lane (one per query group), contiguous per lane
-    // entry = {score bits, row relative to the slice}; the select kernel turns it into a key
-    uint2* myq[QG];
+    // This lane's candidate queues, one per query group: entry = {score bits, row relative to the
+    // slice}. Entries 0..QL-1 in LDS (behind the two tile buffers), the rest in the HBM spill queue.
+    uint2* lq = reinterpret_cast<uint2*>(smem + 2 * TILE_BYTES) + (size_t)tid * QG * (QL > 0 ? QL : 1);
     int cnt[QG];
     float top[QG][4];
 #pragma unroll
     for (int g2 = 0; g2 < QG; ++g2) {
-        myq[g2] = reinterpret_cast<uint2*>(queues) + queue_id(qj[g2], split, qd, nsplits) * cap;
         cnt[g2] = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) top[g2][e] = -FLT_MAX;
@@ -310,44 +262,55 @@ void ls_gemm_filter_kernel(
         return __builtin_bit_cast(half8, v);
     };
 
-    // ---- one element of a finished tile: e -> (row block, query group, register) ------------------
+    // ---- one score of a finished tile -------------------------------------------------------------
     // The append is the hot slow path (a wave enters it for ~1 check in 5): no key building, no
     // bounds logic here. Padded queries carry tau = FLT_MAX and never pass; zero-pad rows past n
-    // are dropped by the select kernel; a full queue keeps overwriting its last slot while the
-    // count runs on, which is how the overflow is seen at the end.
-    auto check = [&](const f32x4v (&acc)[NRB][QG], int e, int lrow0) {
-        const int rb = e / (QG * 4), g2 = (e / 4) % QG, reg = e % 4;
-        const float s = acc[rb][g2][reg];
-        const int lrow = lrow0 + rb * 16 + reg;  // lrow0 already includes 4*qd
+    // are dropped by the select kernel; a full spill queue keeps overwriting its last slot while
+    // the count runs on, which is how the overflow is seen at the end.
+    auto check1 = [&](float s, int g2, int lrow) {
         if (SAMPLE) {
             // NaN never enters (fmaxf/fminf drop it); padded queries and zero-pad rows are masked
-            top4_insert(top[g2], (qvalid[g2] && r_begin + lrow < r_end) ? s : -FLT_MAX);
+            top4_insert(top[g2], (qj[g2] < nq && r_begin + lrow < r_end) ? s : -FLT_MAX);
         } else if (s >= tauv[g2]) {
-            const int slot = cnt[g2] < cap ? cnt[g2] : cap - 1;
-            myq[g2][slot] = make_uint2(__float_as_uint(s), (u32)lrow);
-            ++cnt[g2];
+            const int c = cnt[g2];
+            const uint2 ent = make_uint2(__float_as_uint(s), (u32)lrow);
+            if (c < QL) {
+                lq[g2 * QL + c] = ent;
+            } else {
+                const int slot = c - QL < LS_GEMM_SCAP ? c - QL : LS_GEMM_SCAP - 1;
+                out.spill[queue_id(qj[g2], split, qd, nsplits) * LS_GEMM_SCAP + slot] = ent;
+            }
+            cnt[g2] = c + 1;
         }
     };
+    auto check = [&](const f32x4v (&acc)[NRB][QG], int e, int lrow0) {  // e -> (block, group, reg)
+        const int rb = e / (QG * 4), g2 = (e / 4) % QG, reg = e % 4;
+        check1(acc[rb][g2][reg], g2, lrow0 + rb * 16 + reg);  // lrow0 already includes 4*qd
+    };
 
-    // One tile: NRB*QG independent accumulator chains advance together, one k-step at a time;
-    // the PREVIOUS tile's accumulators are filtered CPK elements per k-step.
+    // One tile: NRB*QG independent accumulator chains advance together, one k-step at a time.
+    // Two sets: the PREVIOUS tile's accumulators are filtered CPK elements per k-step, in the
+    // shadow of the matrix pipe. One set (ONE_ACC): the filter cannot hide inside its own wave's
+    // MFMA stream (every check is a branch the MFMAs are not scheduled across), so it hides under
+    // the OTHER wave of the SIMD instead: waves 0-3 filter a tile right after the hand-over
+    // barrier, before they overwrite the accumulators ("early"), waves 4-7 right after their
+    // k-loop, before the barrier ("late"); waves w and w+4 share a SIMD, so one of the pair is
+    // always feeding the matrix pipe while the other one filters.
+    const bool late = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
     auto run_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], bool have_prev,
-                        int prev_row0, int bufoff) {
-        // A fragments are read LS_GEMM_PF k-steps ahead of their MFMAs
-        constexpr int PF = LS_GEMM_PF, NA = PF + 1;
-        half8 a[NA][NRB];
+                        int prev_row0, int cur_row0, int bufoff) {
+        if (ONE_ACC && !late && have_prev) {
 #pragma unroll
-        for (int p0 = 0; p0 < PF; ++p0) {
-            if (p0 < KS) {
-#pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) a[p0][rb] = a_frag(bufoff, rb, p0);
-            }
+            for (int e = 0; e < NV; ++e) check(prev, e, prev_row0);
         }
+        half8 a[2][NRB];  // A fragments are read one k-step ahead of their MFMAs
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) a[0][rb] = a_frag(bufoff, rb, 0);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            if (kk + PF < KS) {
+            if (kk + 1 < KS) {
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) a[(kk + PF) % NA][rb] = a_frag(bufoff, rb, kk + PF);
+                for (int rb = 0; rb < NRB; ++rb) a[(kk + 1) & 1][rb] = a_frag(bufoff, rb, kk + 1);
             }
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
@@ -359,153 +322,150 @@ void ls_gemm_filter_kernel(
                     } else {
                         c = cur[rb][g2];
                     }
-                    cur[rb][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk % NA][rb], bq[g2][kk],
+                    cur[rb][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk & 1][rb], bq[g2][kk],
                                                                         c, 0, 0, 0);
                 }
             }
-#ifdef LS_GEMM_ABL_NOCHECK  // timing ablation: a branch-free sink instead of the filter
-            if (have_prev) {
-#pragma unroll
-                for (int c2 = 0; c2 < CPK; ++c2)
-                    if (kk * CPK + c2 < NV) {
-                        const int e = kk * CPK + c2;
-                        tauv[0] += prev[e / (QG * 4)][(e / 4) % QG][e % 4];
-                    }
-            }
-            if (false)
-#else
-            if (have_prev)
-#endif
-            {
+            if (!ONE_ACC && have_prev) {
 #pragma unroll
                 for (int c2 = 0; c2 < CPK; ++c2)
                     if (kk * CPK + c2 < NV) check(prev, kk * CPK + c2, prev_row0);
             }
         }
+        if (ONE_ACC && late) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) check(cur, e, cur_row0);
+        }
     };
 
-    f32x4v accA[NRB][QG], accB[NRB][QG];  // alternate between consecutive tiles
+    f32x4v accA[NRB][QG], accB[NRB][QG];  // two sets alternate between tiles (ONE_ACC: accA only)
     auto tile_row0 = [&](int i) { return (i * tile_stride) * TM + 4 * qd; };  // slice-relative
+    auto flush_last = [&](const f32x4v (&acc)[NRB][QG]) {  // the last tile still has to be filtered
+        const int row0 = tile_row0(nt - 1);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) check(acc, e, row0);
+    };
     // The sample pass visits only a few tiles, so their DMA latencies would be paid one by one:
     // when all of them fit in LDS together they are fetched up front and consumed back to back.
-    if (sample_upfront) {
-        __syncthreads();
-        run_tile(accA, accB, false, 0, 0);
-        if (nt > 1) run_tile(accB, accA, true, tile_row0(0), TILE_BYTES);
-        if (nt > 2) run_tile(accA, accB, true, tile_row0(1), 2 * TILE_BYTES);
-        const int row0 = tile_row0(nt - 1);
-        if ((nt - 1) & 1) {
+    if constexpr (SAMPLE) {
+        if (sample_upfront) {
+            __syncthreads();
+            if constexpr (ONE_ACC) {
+                for (int i = 0; i < nt; ++i)
+                    run_tile(accA, accA, i > 0, tile_row0(i - 1), tile_row0(i), i * TILE_BYTES);
+                if (!late) flush_last(accA);
+            } else {
+                run_tile(accA, accB, false, 0, 0, 0);
+                if (nt > 1) run_tile(accB, accA, true, tile_row0(0), 0, TILE_BYTES);
+                if (nt > 2) run_tile(accA, accB, true, tile_row0(1), 0, 2 * TILE_BYTES);
+                if ((nt - 1) & 1) flush_last(accB); else flush_last(accA);
+            }
 #pragma unroll
-            for (int e = 0; e < NV; ++e) check(accB, e, row0);
-        } else {
-#pragma unroll
-            for (int e = 0; e < NV; ++e) check(accA, e, row0);
+            for (int g2 = 0; g2 < QG; ++g2)
+                reinterpret_cast<uint4*>(out.sample_top)[queue_id(qj[g2], split, qd, nsplits)] =
+                    top4_keys(top[g2]);
+            return;
         }
-#pragma unroll
-        for (int g2 = 0; g2 < QG; ++g2)
-            reinterpret_cast<uint4*>(sample_top)[queue_id(qj[g2], split, qd, nsplits)] =
-                top4_keys(top[g2]);
-        return;
     }
     __syncthreads();  // the compiler drains the DMA (vmcnt(0)) before the barrier
-#ifdef LS_GEMM_ABL_NOSTAGE  // timing ablation: no tile hand-over (results are garbage)
-#define LS_STAGE(t, b) if (cap < 0) stage(t, b)
-#define LS_TILE_BARRIER() if (cap < 0) __syncthreads()
-#elif defined(LS_GEMM_ABL_NODMA)  // timing ablation: barriers but no tile traffic
-#define LS_STAGE(t, b) if (cap < 0) stage(t, b)
-#define LS_TILE_BARRIER() __syncthreads()
-#elif defined(LS_GEMM_ABL_NOBARRIER)  // timing ablation: tile traffic but no barrier (racy)
-#define LS_STAGE(t, b) stage(t, b)
-#define LS_TILE_BARRIER() if (cap < 0) __syncthreads()
-#else
-#define LS_STAGE(t, b) stage(t, b)
-#define LS_TILE_BARRIER() __syncthreads()
-#endif
-    if (NLOAD > 0) {  // loader waves fill a ring of three tiles, two ahead; this wave only computes
-        int b = 0;
-        for (int i = 0; i < nt; i += 2) {
-            run_tile(accA, accB, i > 0, tile_row0(i - 1), b * TILE_BYTES);
+    if constexpr (ONE_ACC) {
+        for (int i = 0; i < nt; ++i) {
+            if (i + 1 < nt) stage((i + 1) * tile_stride, (i + 1) & 1);
+            run_tile(accA, accA, i > 0, tile_row0(i - 1), tile_row0(i), (i & 1) * TILE_BYTES);
             __syncthreads();
-            b = b == 2 ? 0 : b + 1;
+        }
+        if (nt > 0 && !late) flush_last(accA);
+    } else {
+        for (int i = 0; i < nt; i += 2) {
+            if (i + 1 < nt) stage((i + 1) * tile_stride, 1);
+            run_tile(accA, accB, i > 0, tile_row0(i - 1), 0, 0);
+            __syncthreads();
             if (i + 1 < nt) {
-                run_tile(accB, accA, true, tile_row0(i), b * TILE_BYTES);
+                if (i + 2 < nt) stage((i + 2) * tile_stride, 0);
+                run_tile(accB, accA, true, tile_row0(i), 0, TILE_BYTES);
                 __syncthreads();
-                b = b == 2 ? 0 : b + 1;
             }
         }
-    }
-    for (int i = 0; i < (NLOAD > 0 ? 0 : nt); i += 2) {
-        if (i + 1 < nt) LS_STAGE((i + 1) * tile_stride, 1);
-        run_tile(accA, accB, i > 0, tile_row0(i - 1), 0);
-        LS_TILE_BARRIER();
-        if (i + 1 < nt) {
-            if (i + 2 < nt) LS_STAGE((i + 2) * tile_stride, 0);
-            run_tile(accB, accA, true, tile_row0(i), TILE_BYTES);
-            LS_TILE_BARRIER();
+        if (nt > 0) {
+            if ((nt - 1) & 1) flush_last(accB); else flush_last(accA);
         }
     }
-    if (nt > 0) {  // the last tile still has to be filtered
-        const int row0 = tile_row0(nt - 1);
-        if ((nt - 1) & 1) {
+    if constexpr (SAMPLE) {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) check(accB, e, row0);
-        } else {
+        for (int g2 = 0; g2 < QG; ++g2)
+            reinterpret_cast<uint4*>(out.sample_top)[queue_id(qj[g2], split, qd, nsplits)] =
+                top4_keys(top[g2]);
+    } else {
+        // ---- compact the four quarter-queues of every query into its (query, slice) record -------
+        // LDS is in-order per wave, and a lane reads back only what it wrote itself: no barrier.
 #pragma unroll
-            for (int e = 0; e < NV; ++e) check(accA, e, row0);
-        }
-    }
+        for (int g2 = 0; g2 < QG; ++g2) {
+            const int c = cnt[g2] < QL ? cnt[g2] : QL;  // entries in LDS
+            const int spilled = cnt[g2] > QL;
+            int off = 0, total = 0, smask = 0;
 #pragma unroll
-    for (int g2 = 0; g2 < QG; ++g2) {
-        const long long qid = queue_id(qj[g2], split, qd, nsplits);
-        if (SAMPLE) {
-            reinterpret_cast<uint4*>(sample_top)[qid] = top4_keys(top[g2]);
-        } else {
-            counts[qid] = (u32)(cnt[g2] < cap ? cnt[g2] : cap);
-#ifdef LS_GEMM_ABL_NOCHECK
-            if (tauv[0] == 12345.0f) counts[qid] = 7u;
-#endif
-            if (cnt[g2] > cap) overflow[qj[g2]] = 1u;
+            for (int j = 0; j < 4; ++j) {
+                const int cj = __shfl(c, li + 16 * j, 64);
+                const int sj = __shfl(spilled, li + 16 * j, 64);
+                off += j < qd ? cj : 0;
+                total += cj;
+                smask |= sj << j;
+            }
+            const long long rid = (long long)qj[g2] * nsplits + split;
+            uint2* r = out.rec + rid * LS_GEMM_REC + off;
+            for (int e = 0; e < c; ++e) r[e] = lq[g2 * QL + e];
+            if (qd == 0) out.rcnt[rid] = (u32)total | ((u32)smask << 8);
+            if (spilled) {
+                const int sc = cnt[g2] - QL;
+                out.scnt[queue_id(qj[g2], split, qd, nsplits)] = (u32)(sc < LS_GEMM_SCAP ? sc : LS_GEMM_SCAP);
+                if (sc > LS_GEMM_SCAP) out.overflow[qj[g2]] = 1u;
+            }
         }
     }
 }
 
-int ls_gemm_qg(const ls_geom& g) { return g.chunks <= 64 ? 2 : 1; }
-int ls_gemm_tile_rows(const ls_geom& g) { return g.chunks <= 64 ? LS_GEMM_TM_SHORT : 32; }
+int ls_gemm_qg(const ls_geom& g) { return gemm_qg(g.chunks); }
+int ls_gemm_tile_rows(const ls_geom& g) { return gemm_tm(g.chunks); }
 
 int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, const void* d_qh,
                           int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
-                          int64_t rows_per_split, int tile_stride, u64* d_queues, u32* d_counts,
-                          int cap, u32* d_overflow, u32* d_sample_top, hipStream_t s) {
+                          int64_t rows_per_split, int tile_stride, const ls_gemm_bufs& b,
+                          hipStream_t s) {
     const int QG = ls_gemm_qg(g);
     const int nqt = (int)(nq_pad / (LS_GEMM_WAVES * 16 * QG));
     const dim3 grid((unsigned)(nsplits * nqt));
-    // two tile buffers; the sample pass takes a third when it fits (all its tiles up front)
-    const size_t tile_bytes = (size_t)ls_gemm_tile_rows(g) * g.chunks * 16;
-    const size_t smem = tile_bytes * (((!d_tau || ls_gemm_loaders(g.chunks, false)) &&
-                                       3 * tile_bytes <= 144 * 1024) ? 3 : 2);
-#define LS_GEMM_LAUNCH(C, Q, SMP)                                                                 \
+    ls_gemm_out o;
+    o.rec = (uint2*)b.d_rec;
+    o.rcnt = b.d_rcnt;
+    o.spill = (uint2*)b.d_spill;
+    o.scnt = b.d_scnt;
+    o.overflow = b.d_overflow;
+    o.sample_top = b.d_sample_top;
+    // full pass: two tile buffers + the lane queues; sample pass: up to three tiles up front
+    const size_t tile_bytes = (size_t)gemm_tile_bytes(g.chunks);
+    size_t smem;
+    if (d_tau)
+        smem = 2 * tile_bytes + (size_t)LS_GEMM_THREADS * QG * (gemm_ql(g.chunks) > 0 ? gemm_ql(g.chunks) : 1) * 8;
+    else
+        smem = tile_bytes * (3 * tile_bytes <= LS_GEMM_LDS_BYTES ? 3 : 2);
+#define LS_GEMM_LAUNCH(C, SMP)                                                                    \
     {                                                                                             \
-        auto kern = ls_gemm_filter_kernel<C, Q, SMP>;                                             \
-        static bool attr_set = false;                                                             \
-        if (!attr_set) {                                                                          \
-            LS_HIP(hipFuncSetAttribute((const void*)kern,                                         \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));  \
-            attr_set = true;                                                                      \
-        }                                                                                         \
-        const dim3 blk(LS_GEMM_THREADS + 64 * ls_gemm_loaders(C, SMP));                           \
-        hipLaunchKernelGGL(kern, grid, blk, smem, s, (const u32x4*)d_corpus, (long long)n,        \
-                           (const u32x4*)d_qh, (int)nq, nqt, d_tau, (long long)rows_per_split,     \
-                           tile_stride, d_queues, d_counts, cap, d_overflow, d_sample_top);       \
+        auto kern = ls_gemm_filter_kernel<C, gemm_qg(C), SMP>;                                    \
+        static ls_attr_once once;                                                                 \
+        if (int rc = ls_set_max_dynamic_lds(once, (const void*)kern, LS_GEMM_LDS_BYTES)) return rc; \
+        hipLaunchKernelGGL(kern, grid, dim3(LS_GEMM_THREADS), smem, s, (const u32x4*)d_corpus,    \
+                           (long long)n, (const u32x4*)d_qh, (int)nq, nqt, d_tau,                 \
+                           (long long)rows_per_split, tile_stride, o);                            \
         LS_HIP(hipGetLastError());                                                                \
         return LS_OK;                                                                             \
     }
-#define LS_GEMM_CASE(C, Q)                     \
-    if (g.chunks == C) {                       \
-        if (d_tau) LS_GEMM_LAUNCH(C, Q, false) \
-        else LS_GEMM_LAUNCH(C, Q, true)        \
+#define LS_GEMM_CASE(C)                     \
+    if (g.chunks == C) {                    \
+        if (d_tau) LS_GEMM_LAUNCH(C, false) \
+        else LS_GEMM_LAUNCH(C, true)        \
     }
-    LS_GEMM_CASE(16, 2) LS_GEMM_CASE(32, 2) LS_GEMM_CASE(48, 2) LS_GEMM_CASE(64, 2)
-    LS_GEMM_CASE(96, 1) LS_GEMM_CASE(128, 1)
+    LS_GEMM_CASE(16) LS_GEMM_CASE(32) LS_GEMM_CASE(48) LS_GEMM_CASE(64)
+    LS_GEMM_CASE(96) LS_GEMM_CASE(128)
 #undef LS_GEMM_CASE
 #undef LS_GEMM_LAUNCH
     ls_set_error("batched path: unsupported row geometry (%d chunks)", g.chunks);
@@ -515,170 +475,183 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
 // ---- tau: j-th best sample score of each query --------------------------------------------------
 // The sample pass left, for every (workgroup, lane, query group), the 4 best sample scores that
 // lane saw (ord() of the score, 0 = none). A query owns 4 lanes in each of its nsplits
-// workgroups: 16*nsplits values, <= 4 per thread. 4 radix passes find the j-th largest.
-// Keeping only 4 per lane can only LOWER the result (if one lane held more than 4 of the best
-// j), i.e. let more rows through: tau is a speculative, verified threshold either way.
-#define LS_TAU_PER_THREAD 8
-#ifndef LS_TAU_PASSES
-#define LS_TAU_PASSES 2
-#endif
+// workgroups: 16*nsplits values. ONE WAVE per query (4 queries per workgroup): the values sit in
+// registers, each radix pass is a wave-private LDS histogram + a 64-lane suffix scan: no
+// workgroup barrier anywhere. Keeping only 4 per lane can only LOWER the result (if one lane held
+// more than 4 of the best j), i.e. let more rows through: tau is a speculative, verified
+// threshold either way.
+#define LS_TAU_PER_LANE (LS_GEMM_MAX_SPLITS * 16 / 64)
 __global__ __launch_bounds__(256) void ls_tau_kernel(const u32* __restrict__ sample_top, int nsplits,
-                                                     int nqt, int QG, int nq, int j_rank,
+                                                     int nq, int nq_pad, int j_rank,
                                                      float* __restrict__ tau) {
-    __shared__ u32 hist[4 * 256];
-    __shared__ u32 misc[4 * 8];
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    __shared__ u32 hist_all[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wv;
+    if (q >= nq_pad) return;
     if (q >= nq) {
-        if (tid == 0) tau[q] = FLT_MAX;  // padded query: nothing passes
+        if (lane == 0) tau[q] = FLT_MAX;  // padded query: nothing passes
         return;
     }
-    (void)nqt;
-    (void)QG;
-    const int total = nsplits * 4 * 4;  // values of this query, contiguous
-    u32 v[LS_TAU_PER_THREAD];
+    u32* hist = hist_all[wv];
+    const int total = nsplits * 16;  // values of this query, contiguous: [slice][quarter][4]
+    const uint4* src = reinterpret_cast<const uint4*>(sample_top) + (long long)q * nsplits * 4;
+    u32 v[LS_TAU_PER_LANE];
 #pragma unroll
-    for (int j = 0; j < LS_TAU_PER_THREAD; ++j) {
-        const int idx = tid + j * 256;
-        u32 x = 0;
-        if (idx < total) {
-            const int e = idx & 3, sq = idx >> 2, quarter = sq & 3, split = sq >> 2;
-            x = sample_top[queue_id(q, split, quarter, nsplits) * 4 + e];  // == q*total + idx
-        }
-        v[j] = x;
+    for (int j = 0; j < LS_TAU_PER_LANE / 4; ++j) {
+        const int idx4 = lane + j * 64;  // one (slice, quarter) group of 4 per load
+        const uint4 x = idx4 * 4 < total ? src[idx4] : make_uint4(0, 0, 0, 0);
+        v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
     }
-    for (int i = tid; i < 4 * 256; i += 256) hist[i] = 0;
-    __syncthreads();
     u32 pref = 0, pmask = 0, krem = (u32)j_rank;
     // Only the top 16 bits of the order key are resolved (sign, exponent, 7 mantissa bits): the
     // result is at most 0.8 % below the exact j-th sample score, i.e. still a valid (slightly
     // more permissive) speculative threshold, for half the passes.
-    for (int pass = 0; pass < LS_TAU_PASSES; ++pass) {
+    for (int pass = 0; pass < 2; ++pass) {
         const int shift = 24 - 8 * pass;
+        for (int i = lane; i < 256; i += 64) hist[i] = 0;
+        wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < LS_TAU_PER_THREAD; ++j)
-            wave_hist_add(hist + pass * 256, (v[j] >> shift) & 255u,
-                          v[j] != 0u && (v[j] & pmask) == pref, lane);
-        __syncthreads();
-        find_bin(hist + pass * 256, krem, misc + pass * 8, tid);
-        __syncthreads();
-        if (pass == 0 && misc[3] < (u32)j_rank) {  // fewer than j sample scores: no bound
-            if (tid == 0) tau[q] = -FLT_MAX;
+        for (int j = 0; j < LS_TAU_PER_LANE; ++j)
+            if (v[j] != 0u && (v[j] & pmask) == pref) atomicAdd(&hist[(v[j] >> shift) & 255u], 1u);
+        wave_lds_fence();
+        // lane l owns bins 4l..4l+3; suffix sums locate the bin of the krem-th largest value
+        const u32 h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2],
+                  h3 = hist[4 * lane + 3];
+        const u32 mine = h0 + h1 + h2 + h3;
+        u32 suf = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_down(suf, o, 64);
+            if (lane + o < 64) suf += t;
+        }
+        const u32 above = suf - mine;
+        const u32 totalv = __shfl(suf, 0, 64);
+        if (pass == 0 && totalv < (u32)j_rank) {  // fewer than j sample scores: no bound
+            if (lane == 0) tau[q] = -FLT_MAX;
             return;
         }
-        pref |= misc[pass * 8] << shift;
+        const bool owner = krem > above && krem <= above + mine;  // exactly one lane
+        u32 bin = 0, rem = 0;
+        if (owner) {
+            u32 cum = above;
+            if (cum + h3 >= krem) { bin = 4 * lane + 3; rem = krem - cum; }
+            else {
+                cum += h3;
+                if (cum + h2 >= krem) { bin = 4 * lane + 2; rem = krem - cum; }
+                else {
+                    cum += h2;
+                    if (cum + h1 >= krem) { bin = 4 * lane + 1; rem = krem - cum; }
+                    else { cum += h1; bin = 4 * lane; rem = krem - cum; }
+                }
+            }
+        }
+        const int ol = __ffsll((long long)__ballot(owner)) - 1;
+        bin = (u32)__shfl((int)bin, ol, 64);
+        krem = (u32)__shfl((int)rem, ol, 64);
+        pref |= bin << shift;
         pmask |= 255u << shift;
-        krem = misc[pass * 8 + 1];
+        wave_lds_fence();
     }
-    if (tid == 0) tau[q] = ls_unord(pref);
+    if (lane == 0) tau[q] = ls_unord(pref);
 }
 
-int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_pad, const ls_geom& g,
-                  int j_rank, float* d_tau, hipStream_t s) {
-    const int QG = ls_gemm_qg(g);
-    if ((long long)nsplits * 16 > 256LL * LS_TAU_PER_THREAD) {
-        ls_set_error("batched path: sample too large for the tau kernel");
+int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_pad, int j_rank,
+                  float* d_tau, hipStream_t s) {
+    if (nsplits > LS_GEMM_MAX_SPLITS) {
+        ls_set_error("batched path: too many slices for the tau kernel");
         return LS_ERR_INVALID_ARG;
     }
-    hipLaunchKernelGGL(ls_tau_kernel, dim3((unsigned)nq_pad), dim3(256), 0, s, d_sample_top,
-                       nsplits, (int)(nq_pad / (LS_GEMM_WAVES * 16 * QG)), QG, (int)nq, j_rank, d_tau);
+    hipLaunchKernelGGL(ls_tau_kernel, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, s,
+                       d_sample_top, nsplits, (int)nq, (int)nq_pad, j_rank, d_tau);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
 
-// ---- exact top-k of each query's queues --------------------------------------------------------------
-#define LS_BSEL_KEYS 2048
+// ---- exact top-k of each query's records -------------------------------------------------------------
+// One workgroup per query. Its nsplits record lengths are contiguous (one load per thread), a
+// block-wide prefix assigns LDS slots, then P = 256 / nsplits threads share each record's
+// entries (16-byte loads of two entries). Spilled lanes (rare) are walked afterwards.
+// LDS: keys[keys_cap] | res[res_cap] | tmp[res_cap] (u64), hist[8*256] | misc[64] (u32).
 __global__ __launch_bounds__(256) void ls_batch_select_kernel(
-    const u64* __restrict__ queues, const u32* __restrict__ counts, int cap, int nsplits, int nqt,
-    int QG, int k, long long base, long long n, long long rows_per_split,
-    u32* __restrict__ overflow, float* __restrict__ out_scores,
-    long long* __restrict__ out_indices) {
-    __shared__ u64 keys[LS_BSEL_KEYS];
-    __shared__ u64 res[256];
-    __shared__ u64 tmp[256];
-    __shared__ u32 hist[8 * 256];
-    __shared__ u32 misc[64];
-    __shared__ u32 nkeys;
-    __shared__ u32 wsum[8];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    (void)nqt;
-    (void)QG;
-    // gather: the query owns 4 queues per slice (<= 512); thread t takes queues t and t + 256:
-    // one load each for their lengths, a block-wide prefix for the slot ranges in LDS, then the
-    // (few) live entries
-    const int nqueues = nsplits * 4;
-    u32 c[2] = {0, 0};
-    const u64* qptr[2] = {nullptr, nullptr};
-    long long r_begin[2] = {0, 0};
-    // the first four entries of each queue are fetched together with its length (their address
-    // does not depend on it): one round trip instead of two for the typical <= 4-entry queue
-    uint4 ea[2], eb[2];
+    const uint2* __restrict__ rec, const u32* __restrict__ rcnt, const uint2* __restrict__ spill,
+    const u32* __restrict__ scnt, int nsplits, int k, int keys_cap, int res_cap, long long base,
+    long long n, long long rows_per_split, u32* __restrict__ overflow,
+    float* __restrict__ out_scores, long long* __restrict__ out_indices) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sel[];
+    u64* keys = reinterpret_cast<u64*>(smem_sel);
+    u64* res = keys + keys_cap;
+    u64* tmp = res + res_cap;
+    u32* hist = reinterpret_cast<u32*>(tmp + res_cap);
+    u32* misc = hist + 8 * 256;
+    u32* wsum = misc + 64;  // [4] + nkeys: inside the dynamic region (a static __shared__ in front
+    u32& nkeys = wsum[4];   // of it would shift its 16-byte alignment)
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 word = tid < nsplits ? rcnt[(long long)q * nsplits + tid] : 0u;
+    const u32 c_rec = word & 255u, smask = (word >> 8) & 15u;
+    // spilled lanes' lengths ride along in the same prefix (their queue is walked by this thread)
+    u32 c_sp[4] = {0, 0, 0, 0};
+    u32 ct = c_rec;
+    if (smask) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int qi = tid + h * 256;
-        ea[h] = eb[h] = make_uint4(0, 0, 0, 0);
-        if (qi < nqueues) {
-            const int quarter = qi & 3, split = qi >> 2;
-            r_begin[h] = (long long)split * rows_per_split;
-            const long long qid = queue_id(q, split, quarter, nsplits);
-            c[h] = counts[qid];
-            qptr[h] = queues + qid * cap;
-            ea[h] = reinterpret_cast<const uint4*>(qptr[h])[0];
-            eb[h] = reinterpret_cast<const uint4*>(qptr[h])[1];
+        for (int j = 0; j < 4; ++j)
+            if (smask >> j & 1) {
+                c_sp[j] = scnt[queue_id(q, tid, j, nsplits)];
+                ct += c_sp[j];
+            }
+    }
+    u32 inc = ct;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t2 = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t2;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    u32 off = 0;
+    for (int i = 0; i < wv; ++i) off += wsum[i];
+    if (tid == 0) nkeys = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const u32 start = off + inc - ct;  // first LDS slot of slice `tid`
+    auto put = [&](u32 slot, uint2 ent, long long rb) {
+        if (slot < (u32)keys_cap) {
+            const long long row = rb + (long long)ent.y;
+            keys[slot] = row < n ? ls_make_key(__uint_as_float(ent.x), (u32)row) : 0ull;
+        }
+    };
+    // record entries: P threads per slice, two entries per 16-byte load
+    const int P = nsplits <= 64 ? 4 : (nsplits <= 128 ? 2 : 1);
+    {
+        const int sl = tid / P, part = tid % P;
+        // the owner thread's (start, c_rec) reach its helpers through LDS (hist is free until
+        // lds_topk, which re-zeroes it behind the barrier below)
+        if (tid < nsplits) reinterpret_cast<uint2*>(hist)[tid] = make_uint2(start, c_rec);
+        __syncthreads();
+        if (sl < nsplits) {
+            const uint2 sc = reinterpret_cast<const uint2*>(hist)[sl];
+            const long long rb = (long long)sl * rows_per_split;
+            const uint4* r4 = reinterpret_cast<const uint4*>(rec + ((long long)q * nsplits + sl) * LS_GEMM_REC);
+            for (u32 e = 2 * part; e < sc.y; e += 2 * P) {
+                const uint4 x = r4[e >> 1];
+                put(sc.x + e, make_uint2(x.x, x.y), rb);
+                if (e + 1 < sc.y) put(sc.x + e + 1, make_uint2(x.z, x.w), rb);
+            }
         }
     }
-    {
-        const int lane = tid & 63, wv = tid >> 6;
-        const u32 ct = c[0] + c[1];
-        u32 inc = ct;
-        for (int o = 1; o < 64; o <<= 1) {
-            const u32 t2 = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t2;
-        }
-        if (lane == 63) wsum[wv] = inc;
-        __syncthreads();
-        u32 off = 0;
-        for (int i = 0; i < wv; ++i) off += wsum[i];
-        if (tid == 0) nkeys = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        u32 start = off + inc - ct;
+    if (smask) {  // rare: this slice has lanes that spilled past their LDS queue
+        u32 slot = start + c_rec;
+        const long long rb = (long long)tid * rows_per_split;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const u32 ch = c[h];
-            const long long rb = r_begin[h];
-            auto put = [&](u32 e, u32 bits, u32 lrow) {
-                if (e < ch && start + e < LS_BSEL_KEYS) {
-                    const long long row = rb + (long long)lrow;
-                    keys[start + e] = row < n ? ls_make_key(__uint_as_float(bits), (u32)row) : 0ull;
-                }
-            };
-            uint4 a = ea[h], b = eb[h];
-            for (u32 e0 = 0; e0 < ch; e0 += 4) {  // cap is a multiple of 4: loads stay in the queue
-                if (e0) {
-                    a = reinterpret_cast<const uint4*>(qptr[h] + e0)[0];
-                    b = reinterpret_cast<const uint4*>(qptr[h] + e0)[1];
-                }
-                put(e0, a.x, a.y);
-                put(e0 + 1, a.z, a.w);
-                put(e0 + 2, b.x, b.y);
-                put(e0 + 3, b.z, b.w);
-            }
-            start += ch;
+        for (int j = 0; j < 4; ++j) {
+            const uint2* sq = spill + queue_id(q, tid, j, nsplits) * LS_GEMM_SCAP;
+            for (u32 e = 0; e < c_sp[j]; ++e) put(slot + e, sq[e], rb);
+            slot += c_sp[j];
         }
     }
     __syncthreads();
     const int cnt = (int)nkeys;
-    if (cnt > LS_BSEL_KEYS) {  // more candidates than fit: exact fallback handles this query
+    if (cnt > keys_cap) {  // more candidates than fit: the exact scan path handles this query
         if (tid == 0) overflow[q] = 1u;
         return;
     }
-    if (overflow[q]) return;  // a queue overflowed in the GEMM pass
-    __syncthreads();
-#if defined(LS_BSEL_ABL) && LS_BSEL_ABL == 1  // timing ablation: gather only
-    if (cap > 0) return;
-#endif
+    if (overflow[q]) return;  // a spill queue overflowed in the GEMM pass
     const int nvalid = lds_topk(keys, cnt, k, res, tmp, hist, misc, tid, 256);
-#if defined(LS_BSEL_ABL) && LS_BSEL_ABL == 2  // timing ablation: no output
-    if (cap > 0) return;
-#endif
     __syncthreads();
     if (nvalid < k && tid == 0) overflow[q] = 2u;  // the speculative tau let < k rows through
     for (int i = tid; i < k; i += 256) {
@@ -688,18 +661,26 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
     }
 }
 
-int ls_launch_batch_select(const u64* d_queues, const u32* d_counts, int cap, int nsplits,
-                           int64_t nq, int64_t nq_pad, const ls_geom& g, int k, int64_t base,
-                           int64_t n, int64_t rows_per_split, u32* d_overflow, float* d_out_scores, int64_t* d_out_indices,
-                           hipStream_t s) {
-    const int QG = ls_gemm_qg(g);
-    if (k > LS_GEMM_MAX_K || nsplits * 4 > 512) {
+int ls_launch_batch_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k, int64_t base,
+                           int64_t n, int64_t rows_per_split, float* d_out_scores,
+                           int64_t* d_out_indices, hipStream_t s) {
+    if (k > LS_GEMM_MAX_K || nsplits > LS_GEMM_MAX_SPLITS) {
         ls_set_error("batched path: k > %d or too many slices", LS_GEMM_MAX_K);
         return LS_ERR_INVALID_ARG;
     }
-    hipLaunchKernelGGL(ls_batch_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, d_queues,
-                       d_counts, cap, nsplits, (int)(nq_pad / (LS_GEMM_WAVES * 16 * QG)), QG, k, (long long)base,
-                       (long long)n, (long long)rows_per_split, d_overflow, d_out_scores, (long long*)d_out_indices);
+    // candidates per query average ~2-5 k (the threshold's safety margin): room for 4 k, >= 2048
+    int keys_cap = 2048;
+    while (keys_cap < 4 * k) keys_cap <<= 1;
+    int res_cap = 256;
+    while (res_cap < k) res_cap <<= 1;
+    const size_t smem = ((size_t)keys_cap + 2 * (size_t)res_cap) * sizeof(u64) +
+                        (8 * 256 + 64 + 16) * sizeof(u32);
+    static ls_attr_once once;
+    if (int rc = ls_set_max_dynamic_lds(once, (const void*)ls_batch_select_kernel, 128 * 1024)) return rc;
+    hipLaunchKernelGGL(ls_batch_select_kernel, dim3((unsigned)nq), dim3(256), smem, s,
+                       (const uint2*)b.d_rec, b.d_rcnt, (const uint2*)b.d_spill, b.d_scnt, nsplits, k,
+                       keys_cap, res_cap, (long long)base, (long long)n, (long long)rows_per_split,
+                       b.d_overflow, d_out_scores, (long long*)d_out_indices);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }

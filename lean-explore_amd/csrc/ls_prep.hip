@@ -8,24 +8,19 @@
 //                       in fp32 or fp16, zero padded to whole 16-byte chunks.
 #include "ls_common.h"
 
-__global__ __launch_bounds__(256) void ls_prep_kernel(const float* __restrict__ qin,
-                                                      float* __restrict__ qout, int d, int d_pad,
-                                                      int normalize, int round_f16) {
-    __shared__ float red[4];
+// One wave per query: the squared norm in the library's canonical order (ls_wave_sumsq).
+__global__ __launch_bounds__(64) void ls_prep_kernel(const float* __restrict__ qin,
+                                                     float* __restrict__ qout, int d, int d_pad,
+                                                     int normalize, int round_f16) {
     const long long qi = blockIdx.x;
     const float* src = qin + qi * d;
     float* dst = qout + qi * d_pad;
     float inv = 1.0f;
     if (normalize) {
-        float ss = 0.0f;
-        for (int j = threadIdx.x; j < d; j += 256) ss = fmaf(src[j], src[j], ss);
-        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-        __syncthreads();
-        ss = (red[0] + red[1]) + (red[2] + red[3]);
+        const float ss = ls_wave_sumsq(src, d, threadIdx.x);
         if (ss > 0.0f) inv = 1.0f / sqrtf(ss);  // zero-norm rows stay untouched (fvec_renorm_L2)
     }
-    for (int j = threadIdx.x; j < d_pad; j += 256) {
+    for (int j = threadIdx.x; j < d_pad; j += 64) {
         float v = 0.0f;
         if (j < d) {
             v = normalize ? src[j] * inv : src[j];
@@ -38,7 +33,7 @@ __global__ __launch_bounds__(256) void ls_prep_kernel(const float* __restrict__ 
 int ls_launch_prep(const float* d_q_in, float* d_q_out, int64_t nq, const ls_geom& g,
                    bool normalize, bool round_f16, hipStream_t s) {
     if (nq <= 0) return LS_OK;
-    hipLaunchKernelGGL(ls_prep_kernel, dim3((unsigned)nq), dim3(256), 0, s, d_q_in, d_q_out, g.d,
+    hipLaunchKernelGGL(ls_prep_kernel, dim3((unsigned)nq), dim3(64), 0, s, d_q_in, d_q_out, g.d,
                        g.d_pad, normalize ? 1 : 0, round_f16 ? 1 : 0);
     LS_HIP(hipGetLastError());
     return LS_OK;
@@ -90,6 +85,37 @@ int ls_launch_convert(const float* d_src, void* d_dst, int64_t n, const ls_geom&
     else
         hipLaunchKernelGGL((ls_convert_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s,
                            d_src, (uint4*)d_dst, (long long)n, g.d, g.chunks);
+    LS_HIP(hipGetLastError());
+    return LS_OK;
+}
+
+// stored rows -> fp32 [n, d] (index.reconstruct_n): fp16 storage yields the rounded values
+template <bool F16>
+__global__ __launch_bounds__(256) void ls_unconvert_kernel(const unsigned char* __restrict__ src,
+                                                           float* __restrict__ dst, long long n,
+                                                           int d, int chunks) {
+    const long long total = n * d;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (long long)gridDim.x * 256) {
+        const long long r = i / d;
+        const int j = (int)(i - r * d);
+        const unsigned char* row = src + r * (long long)chunks * 16;
+        dst[i] = F16 ? (float)reinterpret_cast<const _Float16*>(row)[j]
+                     : reinterpret_cast<const float*>(row)[j];
+    }
+}
+
+int ls_launch_unconvert(const void* d_src, float* d_dst, int64_t n, const ls_geom& g,
+                        hipStream_t s) {
+    if (n <= 0) return LS_OK;
+    long long blocks = ((long long)n * g.d + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (g.elem == 2)
+        hipLaunchKernelGGL((ls_unconvert_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s,
+                           (const unsigned char*)d_src, d_dst, (long long)n, g.d, g.chunks);
+    else
+        hipLaunchKernelGGL((ls_unconvert_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s,
+                           (const unsigned char*)d_src, d_dst, (long long)n, g.d, g.chunks);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }

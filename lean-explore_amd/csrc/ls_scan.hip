@@ -212,8 +212,12 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
     QueryRegs<F16, V> qr[NQ];
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
-        const float ss = group_sum<L>(qr[qi].load(qraw + (long long)qi * d, d, sub, L));
-        const float inv = (normalize && ss > 0.0f) ? 1.0f / sqrtf(ss) : 1.0f;
+        (void)qr[qi].load(qraw + (long long)qi * d, d, sub, L);
+        float inv = 1.0f;
+        if (normalize) {  // the library's canonical summation order (ls_common.h)
+            const float ss = ls_wave_sumsq(qraw + (long long)qi * d, d, lane);
+            if (ss > 0.0f) inv = 1.0f / sqrtf(ss);
+        }
         qr[qi].scale(inv);
     }
 
@@ -285,21 +289,12 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
 static constexpr int scan_unroll(int V) { return (V >= 3) ? LS_UNROLL_V3 : 8; }  // >= 8 loads in flight
 
 int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu) {
-    static int bpc = -1;
-    if (bpc < 0) {
-        const char* e = getenv("LS_SCAN_BPC");
-        bpc = e ? atoi(e) : 2;
-        if (bpc < 1) bpc = 1;
-    }
+    constexpr int bpc = 2;  // scan workgroups per CU
     const int64_t TR = (int64_t)scan_unroll(g.V) * (LS_WAVE / g.L);
     const int64_t NT = (n + TR - 1) / TR;
-    static int tpw = -1;  // minimum tiles per wave. Small shards: fewer blocks -> fewer candidate keys
-    // for the piggy-backed finalize, which bounds the launch there (N=25k: 18.6 -> 11.7 us/step)
-    if (tpw < 0) {
-        const char* e = getenv("LS_SCAN_TPW");
-        tpw = e ? atoi(e) : 4;
-        if (tpw < 1) tpw = 1;
-    }
+    // minimum tiles per wave. Small shards: fewer blocks -> fewer candidate keys for the
+    // piggy-backed finalize, which bounds the launch there (N=25k: 18.6 -> 11.7 us/step)
+    constexpr int tpw = 4;
     int64_t b = (NT + LS_SCAN_WAVES * tpw - 1) / (LS_SCAN_WAVES * tpw);
     const int64_t cap = (int64_t)n_cu * bpc;
     if (b > cap) b = cap;
@@ -318,12 +313,8 @@ static int launch_lvq(const void* corpus, int64_t n, const ls_geom& g, const ls_
         smem = std::max(smem, ls_fin_lds_bytes(fp.keys_cap, keff));
     }
     auto kern = ls_scan_kernel<F16, L, V, U, NQ>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   LS_PIGGY_LDS_MAX));
-        attr_set = true;
-    }
+    static ls_attr_once once;
+    if (int rc = ls_set_max_dynamic_lds(once, (const void*)kern, LS_PIGGY_LDS_MAX)) return rc;
     hipLaunchKernelGGL(kern, dim3(a.blocks + a.nfin), dim3(LS_SCAN_THREADS), smem, s,
                        (const f32x4*)corpus, (long long)n, g.chunks, a.d_q, g.d,
                        a.normalize ? 1 : 0, a.reverse ? 1 : 0, a.d_S, (long long)a.s_stride,

@@ -12,12 +12,8 @@ __global__ __launch_bounds__(LS_FINAL_THREADS) void ls_finalize_kernel(ls_fin_ba
 
 int ls_launch_finalize(const ls_fin_batch& jobs, int njobs, hipStream_t s) {
     if (njobs <= 0) return LS_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LS_HIP(hipFuncSetAttribute((const void*)ls_finalize_kernel,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-    }
+    static ls_attr_once once;
+    if (int rc = ls_set_max_dynamic_lds(once, (const void*)ls_finalize_kernel, 128 * 1024)) return rc;
     size_t smem = 0;
     for (int i = 0; i < njobs; ++i) {
         const ls_fin_params& p = jobs.p[i];
@@ -75,12 +71,8 @@ int ls_launch_merge(const float* d_scores_in, const int64_t* d_indices_in, int64
         return LS_ERR_K_TOO_LARGE;
     }
     const size_t smem = ((size_t)mc + 2 * LS_RES_CAP) * sizeof(u64) + (8 * 256 + 64) * sizeof(u32);
-    static bool attr_set = false;
-    if (!attr_set) {
-        LS_HIP(hipFuncSetAttribute((const void*)ls_merge_kernel,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
-        attr_set = true;
-    }
+    static ls_attr_once once;
+    if (int rc = ls_set_max_dynamic_lds(once, (const void*)ls_merge_kernel, 112 * 1024)) return rc;
     hipLaunchKernelGGL(ls_merge_kernel, dim3((unsigned)nq), dim3(LS_MERGE_THREADS), smem, s,
                        d_scores_in, (const long long*)d_indices_in, (long long)stride_s_bytes,
                        (long long)stride_i_bytes, n_lists, (long long)nq, k, d_out_scores,

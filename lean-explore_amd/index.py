@@ -56,8 +56,10 @@ class FlatIPIndex:
         self.device = int(device)
         self._base = int(base)
         self._handle: ctypes.c_void_p | None = None
-        self._pending: list[np.ndarray] = []   # rows added since the handle was built
-        self._host_rows: list[np.ndarray] = []  # everything ever added (for re-build / save)
+        # rows added before the first search: uploaded (and released) when the handle is built.
+        # No host copy outlives that: later add() calls append in HBM (ls_add), host_corpus()
+        # reads the rows back (ls_reconstruct).
+        self._pending: list[np.ndarray] = []
         self._ntotal = 0
         self._device_built = False             # built straight from device memory
         self.is_trained = True
@@ -96,17 +98,18 @@ class FlatIPIndex:
         return ix
 
     def add(self, x: np.ndarray) -> None:
-        """index.add(x) (reference extract/index.py:116): append float32 rows."""
-        if self._device_built:
-            raise RuntimeError("cannot add to an index built from device memory")
+        """index.add(x) (reference extract/index.py:116): append float32 rows. On a built index
+        the stored rows stay in HBM and only the new ones are uploaded (ls_add)."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         if x.ndim != 2 or x.shape[1] != self.d:
             raise ValueError(f"add expects [n, {self.d}] float32")
         if x.shape[0] == 0:
             return
-        self._host_rows.append(x)
+        if self._handle is not None:
+            native.check(native.load().ls_add(self._handle, x.ctypes.data, x.shape[0]))
+        else:
+            self._pending.append(x)
         self._ntotal += x.shape[0]
-        self._drop_handle()
 
     def _drop_handle(self) -> None:
         if self._handle is not None:
@@ -117,13 +120,14 @@ class FlatIPIndex:
         if self._handle is not None:
             return self._handle
         lib = native.load()
-        if len(self._host_rows) > 1:
-            self._host_rows = [np.concatenate(self._host_rows, axis=0)]
-        corpus = self._host_rows[0] if self._host_rows else np.zeros((0, self.d), np.float32)
+        if len(self._pending) > 1:
+            self._pending = [np.concatenate(self._pending, axis=0)]
+        corpus = self._pending[0] if self._pending else np.zeros((0, self.d), np.float32)
         h = ctypes.c_void_p()
         native.check(lib.ls_create(ctypes.byref(h), corpus.ctypes.data if corpus.size else None,
                                    corpus.shape[0], self.d, self._dtype, self.device))
         self._handle = h
+        self._pending = []  # the rows live in HBM now
         if self._base:
             native.check(lib.ls_set_base(h, self._base))
         return h
@@ -142,12 +146,18 @@ class FlatIPIndex:
         return self._base
 
     def host_corpus(self) -> np.ndarray:
-        """The float32 rows this index was built from (host copy), [ntotal, d]."""
-        if self._device_built:
-            raise RuntimeError("index was built from device memory; no host copy exists")
-        if len(self._host_rows) > 1:
-            self._host_rows = [np.concatenate(self._host_rows, axis=0)]
-        return self._host_rows[0] if self._host_rows else np.zeros((0, self.d), np.float32)
+        """The stored rows as float32 [ntotal, d], read back from HBM (index.reconstruct_n);
+        an fp16 index returns the rounded values. Before the first search the rows have not been
+        uploaded yet and are returned as added."""
+        if self._handle is None and not self._device_built:
+            if len(self._pending) > 1:
+                self._pending = [np.concatenate(self._pending, axis=0)]
+            return self._pending[0] if self._pending else np.zeros((0, self.d), np.float32)
+        h = self._ensure_built()
+        out = np.empty((self._ntotal, self.d), dtype=np.float32)
+        if self._ntotal:
+            native.check(native.load().ls_reconstruct(h, 0, self._ntotal, out.ctypes.data))
+        return out
 
     # ------------------------------------------------------------------ search
     def search(self, x: np.ndarray, k: int, *, normalize: bool = False
@@ -180,7 +190,10 @@ class FlatIPIndex:
 
         q: float32 CUDA tensor [nq, d]. Work is queued on ``stream`` (default: torch's current
         stream). Returns (scores float32 [nq, k], indices int64 [nq, k]) CUDA tensors.
-        ``asynchronous``: queue and return, results ordered on the stream.
+        ``asynchronous``: queue and return, results ordered on the stream. For batched calls
+        (nq > 16 on an fp16 index) call :meth:`check` before trusting them: it repairs the rare
+        query the speculative threshold short-changed, re-writing its rows of the output tensors
+        (keep those alive until then; ``q`` may be reused at once in stream order).
         ``pipeline``: queue on the index's internal lanes so consecutive calls overlap; results
         are valid only after :meth:`check`.
         """
@@ -203,6 +216,17 @@ class FlatIPIndex:
                                                     out_scores.data_ptr(), out_indices.data_ptr(),
                                                     s.cuda_stream))
         return out_scores, out_indices
+
+    def export_flags(self, dst, stream=None) -> None:
+        """Copy the per-query verification flags (uint32/int32 CUDA tensor [nq]) of the most
+        recent search queued on this index, in stream order (see ls_export_flags)."""
+        import torch
+
+        if not (dst.is_cuda and dst.dim() == 1 and dst.element_size() == 4 and dst.is_contiguous()):
+            raise ValueError("export_flags expects a contiguous 32-bit CUDA tensor [nq]")
+        s = stream if stream is not None else torch.cuda.current_stream(dst.device)
+        native.check(native.load().ls_export_flags(self._ensure_built(), dst.data_ptr(),
+                                                   dst.shape[0], s.cuda_stream))
 
     def check(self, stream=None) -> None:
         """Synchronise and validate async searches (see ls_check)."""

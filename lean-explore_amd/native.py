@@ -40,6 +40,8 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 SYMBOLS: dict[str, tuple] = {
     "ls_create": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _i64, _i32, _i32, _i32]),
     "ls_create_from_device": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _i64, _i32, _i32, _i32]),
+    "ls_add": (ctypes.c_int, [_vp, _vp, _i64]),
+    "ls_reconstruct": (ctypes.c_int, [_vp, _i64, _i64, _vp]),
     "ls_destroy": (None, [_vp]),
     "ls_ntotal": (_i64, [_vp]),
     "ls_dim": (_i32, [_vp]),
@@ -49,6 +51,7 @@ SYMBOLS: dict[str, tuple] = {
     "ls_search": (ctypes.c_int, [_vp, _vp, _i64, _i32, _u32, _vp, _vp]),
     "ls_search_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _u32, _vp, _vp, _vp]),
     "ls_check": (ctypes.c_int, [_vp, _vp]),
+    "ls_export_flags": (ctypes.c_int, [_vp, _vp, _i64, _vp]),
     "ls_normalize_l2": (ctypes.c_int, [_vp, _i64, _i32, _i32]),
     "ls_merge_topk": (ctypes.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
     "ls_merge_topk_strided": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),

@@ -52,6 +52,7 @@ class ShardedFlatIPIndex:
         # collective on a one-GPU box)
         self.force_exchange = False
         self._pipe = None
+        self._unfinished: list = []  # batched exchanges whose flags have not been looked at yet
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -79,12 +80,11 @@ class ShardedFlatIPIndex:
 
     # ------------------------------------------------------------------ HIP defaults
     def _hip_local_search(self, q, k, normalize, out_scores=None, out_indices=None):
-        # The per-query scan path is exact in stream order, so it can stay asynchronous. The
-        # batched MFMA path may flag queries for repair (ls_check): the local result must be
-        # final BEFORE it is exchanged, so larger batches run synchronously (sync + repair).
-        asynchronous = q.shape[0] <= 16 or self.local.storage_dtype != "f16"
+        # Always queued asynchronously. The per-query scan path is exact in stream order; the
+        # batched MFMA path may flag queries for repair, and those flags travel WITH the results
+        # (see search_device): no host synchronisation before the exchange.
         return self.local.search_device(q, k, out_scores, out_indices, normalize=normalize,
-                                        asynchronous=asynchronous)
+                                        asynchronous=True)
 
     def _hip_merge(self, all_scores, all_rows, k, list_stride_bytes=None):
         import torch
@@ -109,35 +109,74 @@ class ShardedFlatIPIndex:
     # ------------------------------------------------------------------ search
     def search_device(self, q, k: int, *, normalize: bool = False):
         """q: float32 tensor [nq, d] (same on every rank). Returns (scores, rows) [nq, k]
-        tensors, identical on every rank. All work is queued on the current stream."""
+        tensors, identical on every rank. All work is queued on the current stream; for batched
+        calls (nq > 16, fp16 shards) the result is final after :meth:`finish`."""
         import torch
         import torch.distributed as dist
 
         if self.world == 1 and not self.force_exchange:
             return self._local_search(q, k, normalize)
+        if len(self._unfinished) >= 8:  # bounded look-ahead (the library itself allows 16)
+            self.finish()
         nq = q.shape[0]
-        # one packed block per rank: [scores f32 nq*k | pad to 8 B | rows i64 nq*k] -> ONE all-gather
+        hip = self._local_search == self._hip_local_search
+        # one packed block per rank: [scores f32 nq*k | pad to 8 B | rows i64 nq*k | flags u32 nq]
+        # -> ONE all-gather. The flags are the shard's per-query "provisional" marks.
         sbytes = (nq * k * 4 + 7) & ~7
-        block = sbytes + nq * k * 8
+        fbytes = nq * 4 if hip else 0
+        block = (sbytes + nq * k * 8 + fbytes + 7) & ~7
         packed = torch.empty(block, dtype=torch.uint8, device=q.device)
         s_loc = packed[: nq * k * 4].view(torch.float32).view(nq, k)
-        i_loc = packed[sbytes:].view(torch.int64).view(nq, k)
-        if self._local_search == self._hip_local_search:
+        i_loc = packed[sbytes: sbytes + nq * k * 8].view(torch.int64).view(nq, k)
+        if hip:
             self._hip_local_search(q, k, normalize, s_loc, i_loc)
+            self.local.export_flags(packed[sbytes + nq * k * 8: sbytes + nq * k * 8 + fbytes]
+                                    .view(torch.int32))
         else:  # injected (CPU tests): copy its result into the packed block
             s_tmp, i_tmp = self._local_search(q, k, normalize)
             s_loc.copy_(s_tmp)
             i_loc.copy_(i_tmp)
         gathered = torch.empty(self.world * block, dtype=torch.uint8, device=q.device)
         dist.all_gather_into_tensor(gathered, packed, group=self.group)
-        all_s = gathered.view(self.world, block)[:, : nq * k * 4]
-        all_i = gathered.view(self.world, block)[:, sbytes:]
         if self._merge == self._hip_merge:
             # strided views are never materialised: the kernel walks the packed blocks
-            return self._merge_packed(gathered, sbytes, block, nq, k)
-        s_all = all_s.contiguous().view(torch.float32).view(self.world, nq, k)
-        i_all = all_i.contiguous().view(torch.int64).view(self.world, nq, k)
-        return self._merge(s_all, i_all, k)
+            out = self._merge_packed(gathered, sbytes, block, nq, k)
+        else:
+            g2 = gathered.view(self.world, block)
+            s_all = g2[:, : nq * k * 4].contiguous().view(torch.float32).view(self.world, nq, k)
+            i_all = g2[:, sbytes: sbytes + nq * k * 8].contiguous().view(torch.int64) \
+                .view(self.world, nq, k)
+            out = self._merge(s_all, i_all, k)
+        if hip:  # `packed` holds the local results: it must outlive the ls_check that may repair them
+            self._unfinished.append((nq, k, out, packed, gathered, sbytes, block, fbytes))
+        return out
+
+    def finish(self):
+        """Make the results of the search_device calls since the last finish() final. Every rank
+        reads the SAME gathered flags, so all ranks agree, without another collective, on whether
+        any shard had a provisional query; if so (rare) the flagged shard repairs it (ls_check)
+        and that batch's exchange + merge is redone into the same output tensors."""
+        import torch
+        import torch.distributed as dist
+
+        todo, self._unfinished = self._unfinished, []
+        if not todo:
+            self.local.check()
+            return
+        marks = [t[4].view(self.world, t[6])[:, t[5] + t[0] * t[1] * 8: t[5] + t[0] * t[1] * 8 + t[7]]
+                 .any() for t in todo]
+        redo = torch.stack(marks).cpu().tolist()  # synchronises the stream
+        self.local.check()  # repairs this shard's flagged rows of the `packed` blocks in place
+        for again, (nq, k, out, packed, gathered, sbytes, block, fbytes) in zip(redo, todo):
+            if not again:
+                continue
+            packed[sbytes + nq * k * 8:].zero_()
+            dist.all_gather_into_tensor(gathered, packed, group=self.group)
+            s2, i2 = self._merge_packed(gathered, sbytes, block, nq, k)
+            out[0].copy_(s2)
+            out[1].copy_(i2)
+        if any(redo):
+            torch.cuda.synchronize()
 
     def _merge_packed(self, gathered, sbytes, block, nq, k):
         import torch
@@ -281,5 +320,5 @@ class ShardedFlatIPIndex:
         x = np.ascontiguousarray(x, dtype=np.float32)
         dev = torch.device("cuda", self.local.device)
         s, i = self.search_device(torch.from_numpy(x).to(dev), int(k), normalize=normalize)
-        self.local.check()
+        self.finish()
         return s.cpu().numpy(), i.cpu().numpy()

@@ -24,8 +24,9 @@
  * k = 1 -> label 0) and the structural asserts at :164-183 (ntotal, d); tests/test_oracle.py
  * checks this file against those. FAISS's own summation order and tie behaviour cannot be
  * observed here (no faiss), so they are fixed by definition:
- *   summation  : plain left-to-right fp32, one rounding per multiply and one per add
- *                (compiled with -ffp-contract=off so no FMA contraction sneaks in)
+ *   summation  : scores: plain left-to-right fp32, one rounding per multiply and one per add
+ *                (compiled with -ffp-contract=off so no FMA contraction sneaks in);
+ *                squared norm of normalize_L2: see oracle_normalize_l2 below
  *   total order: score descending, then row index ascending
  *   not returned: rows whose score is NaN or <= -FLT_MAX (a FAISS heap never admits them:
  *                 its test is `score > heap_top` with heap_top initialised to -FLT_MAX)
@@ -105,12 +106,21 @@ void oracle_round_f16(float* x, int64_t count) {
 }
 
 /* faiss.normalize_L2 (engine.py:242): x_i *= 1/sqrt(sum x^2); zero-norm rows untouched.
- * The squared norm is a plain left-to-right fp32 sum. */
+ * FAISS computes the squared norm with SIMD partial sums in an order that cannot be observed
+ * here, so the order is fixed by definition, the same one every HIP kernel of the build uses
+ * (ls_wave_sumsq, lean-explore_amd/csrc/ls_common.h): 64 interleaved partial sums
+ * p[l] = fma(x[j], x[j], p[l]) over j = l, l+64, ... in increasing j, combined by the balanced
+ * xor tree with strides 32, 16, 8, 4, 2, 1. Then ONE correctly rounded 1/sqrt and one multiply
+ * per element: a normalised query is bit-identical between this file and the HIP path. */
 void oracle_normalize_l2(float* x, int64_t nq, int32_t d) {
     for (int64_t i = 0; i < nq; ++i) {
         float* r = x + i * (int64_t)d;
-        float nr = 0.0f;
-        for (int32_t j = 0; j < d; ++j) nr += r[j] * r[j];
+        float p[64];
+        for (int l = 0; l < 64; ++l) p[l] = 0.0f;
+        for (int32_t j = 0; j < d; ++j) p[j & 63] = fmaf(r[j], r[j], p[j & 63]);
+        for (int o = 32; o >= 1; o >>= 1)
+            for (int l = 0; l < o; ++l) p[l] = p[l] + p[l ^ o];
+        const float nr = p[0];
         if (nr > 0.0f) {
             float inv = 1.0f / sqrtf(nr);
             for (int32_t j = 0; j < d; ++j) r[j] *= inv;

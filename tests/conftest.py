@@ -1,3 +1,4 @@
+import os
 import sys
 from pathlib import Path
 
@@ -10,6 +11,18 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """On a host with no ROCm device node at all (a CPU-only container) the gpu tests are skipped
+    instead of failing one by one. On a GPU box nothing is ever skipped: if /dev/kfd exists but no
+    device is usable the tests must fail loudly."""
+    if os.path.exists("/dev/kfd"):
+        return
+    skip = pytest.mark.skip(reason="no ROCm device node (/dev/kfd): CPU-only host")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -1,0 +1,72 @@
+"""bench.py's launch contract: `--gpus N` must really run N ranks (self-spawned under
+torch.distributed.run when no launcher set WORLD_SIZE) or refuse to print a line; the default
+single-GPU line must carry both halves of BASELINE's metric plus the host-API block."""
+
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def run_bench(args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, env=env, timeout=timeout,
+                       capture_output=True, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_gpus_2_self_spawns_two_ranks():
+    """One GPU here: the two ranks share it over gloo (LS_BENCH_SHARE_GPU, a rehearsal of the
+    N > 1 code path: row shards, pipelined packed all-gather, strided merge, max-over-ranks)."""
+    p, out = run_bench(["--gpus", "2", "--workload", "c1", "--steps", "48", "--warmup", "8",
+                        "--secondary", "none", "--no-host-api", "--no-cpu-baseline"],
+                       {"LS_BENCH_SHARE_GPU": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out is not None and out["n_gpus"] == 2 and out["rccl_ranks_seen"] == 2
+    assert out["recall_at_k"] == 1.0 and "rehearsal" in out
+    assert out["config"]["parallelism"] == "row-shard x2" and out["config"]["rows_per_gpu"] == 5000
+
+
+def test_gpus_2_batched_exchange_rehearsal():
+    """The batched (MFMA) path sharded two ways: async local search, flags shipped with the
+    results, finish() after the timed region."""
+    p, out = run_bench(["--gpus", "2", "--workload", "c3", "--steps", "6", "--warmup", "2",
+                        "--secondary", "none", "--no-host-api", "--no-cpu-baseline"],
+                       {"LS_BENCH_SHARE_GPU": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["n_gpus"] == 2 and out["recall_at_k"] == 1.0
+
+
+def test_refuses_rank_count_it_cannot_run():
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than requested ranks")
+    p, out = run_bench(["--gpus", "2", "--workload", "c1", "--steps", "4", "--warmup", "1",
+                        "--secondary", "none", "--no-host-api", "--no-cpu-baseline"])
+    assert p.returncode != 0 and out is None
+    p, out = run_bench(["--gpus", "1", "--workload", "c1", "--steps", "4", "--warmup", "1"],
+                       {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and out is None
+
+
+def test_default_line_carries_both_metric_halves_and_host_api():
+    p, out = run_bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["n_gpus"] == 1 and out["config"]["workload"].startswith("c2:")
+    assert out["recall_at_k"] == 1.0 and 0.3 < out["roofline"]["frac"] <= 1.0
+    c3 = out["secondary"]["c3"]
+    assert c3["recall_at_k"] == 1.0 and c3["roofline"]["bound"] == "mfma"
+    assert 0.0 < c3["roofline"]["frac_whole_batch"] <= c3["roofline"]["frac"] <= 1.0
+    for w in ("c2", "c2p"):
+        assert out["host_api"][w]["us_per_call_mean"] > 0

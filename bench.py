@@ -315,12 +315,26 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         rep = oracle.compare_topk(s[:nv].cpu().numpy(), i[:nv].cpu().numpy(), Dr, Ir, S)
         return rep["recall"]
 
-    # untimed pre-warm: a 20-step driver run is ~1 ms of GPU time, shorter than the clock ramp
-    t_pw = time.perf_counter()
-    while time.perf_counter() - t_pw < PREWARM_S:
+    # untimed pre-warm: a 20-step driver run is ~1 ms of GPU time, shorter than the clock ramp.
+    # Every rank must run the SAME number of steps (they contain collectives): one group is
+    # timed, the group count is agreed on by a max-reduction.
+    def group():
         for _ in range(8):
             step()
         drain()
+
+    group()
+    env.barrier()
+    t_pw = time.perf_counter()
+    group()
+    t_group = max(time.perf_counter() - t_pw, 1e-5)
+    n_groups = int(min(400, max(1, PREWARM_S / t_group)))
+    if world > 1:
+        t = torch.tensor([n_groups], dtype=torch.int64, device="cpu" if env.share_gpu else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n_groups = int(t.item())
+    for _ in range(n_groups):
+        group()
     for _ in range(warmup):
         step()
     env.barrier()

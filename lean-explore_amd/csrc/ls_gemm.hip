@@ -135,6 +135,16 @@ __device__ __forceinline__ uint4 top4_keys(const float (&t)[4]) {  // 0 = "no sa
                       t[2] == -FLT_MAX ? 0u : ls_ord(t[2]), t[3] == -FLT_MAX ? 0u : ls_ord(t[3]));
 }
 
+// LDS store the compiler does not see as one: with a tile DMA (global_load_lds) in flight hipcc
+// puts `s_waitcnt vmcnt(0)` in front of every ordinary LDS store (the DMA is a pending LDS write
+// it cannot prove disjoint), which would park the wave behind the next tile's HBM fetch on every
+// queue append. LDS operations of one wave execute in order, so the flush's later reads of the
+// same queue need no wait either.
+__device__ __forceinline__ void lds_store_b64_nowait(unsigned lds_addr, unsigned lo, unsigned hi) {
+    const u64 v = ((u64)hi << 32) | lo;
+    asm volatile("ds_write_b64 %0, %1" : : "v"(lds_addr), "v"(v) : "memory");
+}
+
 struct ls_gemm_out {
     uint2* rec;        // [nq_pad][nsplits][LS_GEMM_REC] (score bits, slice-relative row)
     u32* rcnt;         // [nq_pad][nsplits] entries in the record | spill mask << 8
@@ -242,6 +252,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // This lane's candidate queues, one per query group: entry = {score bits, row relative to the
     // slice}. Entries 0..QL-1 in LDS (behind the two tile buffers), the rest in the HBM spill queue.
     uint2* lq = reinterpret_cast<uint2*>(smem + 2 * TILE_BYTES) + (size_t)tid * QG * (QL > 0 ? QL : 1);
+    const unsigned lq_addr = (unsigned)(uintptr_t)(lds_ptr_t)lq;  // LDS byte address of the queue
     int cnt[QG];
     float top[QG][4];
 #pragma unroll
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             const int c = cnt[g2];
             const uint2 ent = make_uint2(__float_as_uint(s), (u32)lrow);
             if (c < QL) {
-                lq[g2 * QL + c] = ent;
+                lds_store_b64_nowait(lq_addr + (unsigned)(g2 * QL + c) * 8u, ent.x, ent.y);
             } else {
                 const int slot = c - QL < LS_GEMM_SCAP ? c - QL : LS_GEMM_SCAP - 1;
                 out.spill[queue_id(qj[g2], split, qd, nsplits) * LS_GEMM_SCAP + slot] = ent;

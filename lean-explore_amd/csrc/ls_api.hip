@@ -51,14 +51,14 @@ struct ls_index {
     } sets[LS_NSETS];
     uint64_t set_rr = 0;
     int32_t last_set = 0;
-    // batched (MFMA) path scratch, allocated on first use. ONE set per handle: calls on
-    // different streams are fenced by `bc_done` (recorded behind the last kernel of a call, waited
-    // for by the next call's stream), so they never overlap on it.
+    // batched (MFMA) path scratch, allocated on first use. ONE set per handle. A handle that only
+    // ever sees one stream pays nothing for that; the first call on a second stream synchronises
+    // the previous one and switches the handle to multi-stream mode, where `bc_done` is recorded
+    // behind the last kernel of every call and waited for by the next call's stream (an event
+    // record costs a few us of GPU time per batch: a barrier packet with a release).
     void* d_qh = nullptr;      size_t qh_cap = 0;       // bytes: fp16 queries [nq_pad, d_pad]
-    unsigned char* d_rec = nullptr;   size_t rec_cap = 0;    // bytes: (query, slice) records
-    u32* d_rcnt = nullptr;     size_t rcnt_cap = 0;
-    unsigned char* d_spill = nullptr; size_t spill_cap = 0;  // bytes: per-lane HBM spill queues
-    u32* d_scnt = nullptr;     size_t scnt_cap = 0;
+    u64* d_queues = nullptr;   size_t queues_cap = 0;   // private candidate queues
+    u32* d_counts = nullptr;   size_t counts_cap = 0;
     float* d_tau = nullptr;    size_t tau_cap = 0;
     u32* d_overflow = nullptr; size_t overflow_cap = 0;
     u32* d_sample_top = nullptr; size_t sample_top_cap = 0;  // 4 best sample scores per lane
@@ -66,6 +66,7 @@ struct ls_index {
     hipEvent_t bc_done = nullptr;
     hipStream_t bc_last_stream = nullptr;
     bool bc_used = false;
+    bool bc_multi_stream = false;
     // async batched calls not yet checked: each keeps its own flag slice of d_overflow AND its own
     // copy of the raw queries (d_qkeep), so that several batches can be in flight before one
     // ls_check repairs whatever was flagged, whatever the caller did to its query buffer meanwhile
@@ -284,10 +285,8 @@ void ls_destroy(ls_index* ix) {
     (void)hipFree(ix->d_counters);
     (void)hipFree(ix->d_qpad);
     (void)hipFree(ix->d_qh);
-    (void)hipFree(ix->d_rec);
-    (void)hipFree(ix->d_rcnt);
-    (void)hipFree(ix->d_spill);
-    (void)hipFree(ix->d_scnt);
+    (void)hipFree(ix->d_queues);
+    (void)hipFree(ix->d_counts);
     (void)hipFree(ix->d_qkeep);
     if (ix->bc_done) (void)hipEventDestroy(ix->bc_done);
     (void)hipFree(ix->d_tau);
@@ -561,8 +560,15 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         if (rc != LS_OK) return rc;
     }
     // One scratch set per handle: a call on another stream waits for the previous call's kernels.
-    if (!ix->bc_done) LS_HIP(hipEventCreateWithFlags(&ix->bc_done, hipEventDisableTiming));
-    if (ix->bc_used && ix->bc_last_stream != s) LS_HIP(hipStreamWaitEvent(s, ix->bc_done, 0));
+    if (ix->bc_used && ix->bc_last_stream != s) {
+        if (!ix->bc_multi_stream) {
+            LS_HIP(hipStreamSynchronize(ix->bc_last_stream));  // once: no event was recorded yet
+            LS_HIP(hipEventCreateWithFlags(&ix->bc_done, hipEventDisableTiming));
+            ix->bc_multi_stream = true;
+        } else {
+            LS_HIP(hipStreamWaitEvent(s, ix->bc_done, 0));
+        }
+    }
     const int nqt = (int)(nq_pad / QT);
     // corpus slices: one 8-wave workgroup per CU in total, a multiple of the 8 XCDs
     int nsplits = (LS_GEMM_WG_PER_CU * ix->n_cu / nqt) / 8 * 8;
@@ -584,10 +590,8 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     c = ix->qh_cap;
     if ((rc = grow((unsigned char**)&ix->d_qh, &c, (size_t)nq_pad * g.d_pad * 2)) != LS_OK) return rc;
     ix->qh_cap = c;
-    if ((rc = grow(&ix->d_rec, &ix->rec_cap, nrec * LS_GEMM_REC * 8)) != LS_OK) return rc;
-    if ((rc = grow(&ix->d_rcnt, &ix->rcnt_cap, nrec)) != LS_OK) return rc;
-    if ((rc = grow(&ix->d_spill, &ix->spill_cap, nrec * 4 * LS_GEMM_SCAP * 8)) != LS_OK) return rc;
-    if ((rc = grow(&ix->d_scnt, &ix->scnt_cap, nrec * 4)) != LS_OK) return rc;
+    if ((rc = grow(&ix->d_queues, &ix->queues_cap, nrec * 4 * LS_GEMM_QCAP)) != LS_OK) return rc;
+    if ((rc = grow(&ix->d_counts, &ix->counts_cap, nrec * 4)) != LS_OK) return rc;
     if ((rc = grow(&ix->d_tau, &ix->tau_cap, (size_t)nq_pad)) != LS_OK) return rc;
     if (ix->bc_pending.empty()) {
         if (nq_pad > ix->bc_slot_stride) ix->bc_slot_stride = nq_pad;
@@ -607,10 +611,8 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
                           (size_t)ix->bc_slot_stride * LS_BC_SLOTS)) != LS_OK)
         return rc;
     ls_gemm_bufs bufs;
-    bufs.d_rec = ix->d_rec;
-    bufs.d_rcnt = ix->d_rcnt;
-    bufs.d_spill = ix->d_spill;
-    bufs.d_scnt = ix->d_scnt;
+    bufs.d_queues = ix->d_queues;
+    bufs.d_counts = ix->d_counts;
     bufs.d_overflow = d_flags;
     bufs.d_sample_top = ix->d_sample_top;
 
@@ -662,7 +664,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     }
     rc = ls_launch_batch_select(bufs, nsplits, nq, k, ix->base, ix->n, rps, d_out_s, d_out_i, s);
     if (rc != LS_OK) return rc;
-    LS_HIP(hipEventRecord(ix->bc_done, s));
+    if (ix->bc_multi_stream) LS_HIP(hipEventRecord(ix->bc_done, s));
     ix->bc_used = true;
     ix->bc_last_stream = s;
     ix->n_batched_launches = 5;
@@ -917,7 +919,10 @@ int ls_export_flags(ls_index* ix, void* d_dst, int64_t nq, void* stream) {
     LS_HIP(hipSetDevice(ix->device));
     hipStream_t s = (hipStream_t)stream;
     if (ix->d_last_flags && ix->last_flags_n == nq) {
-        if (ix->bc_last_stream != s) LS_HIP(hipStreamWaitEvent(s, ix->bc_done, 0));
+        if (ix->bc_last_stream != s) {  // flags are written on the search's stream
+            if (ix->bc_multi_stream) LS_HIP(hipStreamWaitEvent(s, ix->bc_done, 0));
+            else LS_HIP(hipStreamSynchronize(ix->bc_last_stream));
+        }
         LS_HIP(hipMemcpyAsync(d_dst, ix->d_last_flags, sizeof(u32) * (size_t)nq,
                               hipMemcpyDeviceToDevice, s));
     } else {

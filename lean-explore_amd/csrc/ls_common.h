@@ -41,9 +41,16 @@ typedef unsigned int u32;
 #define LS_GEMM_MIN_ROWS 32768       // ... and shards at least this big,
 #define LS_GEMM_MIN_ROWS_BIGNQ 8192  // or this big when the batch has >= LS_GEMM_BIGNQ queries
 #define LS_GEMM_BIGNQ 128            // (small shards of a many-GPU run: ~60 us fixed vs nq/8 scans)
-#define LS_GEMM_QL 7                 // candidate-queue entries per (lane, query) kept in LDS
-#define LS_GEMM_REC (4 * LS_GEMM_QL) // entries of one compacted (query, slice) record in HBM
-#define LS_GEMM_SCAP 32              // entries of a lane's HBM spill queue (past the LDS part)
+#define LS_GEMM_QCAP 32              // entries per private candidate queue (a multiple of 4)
+#ifndef LS_GEMM_QG2_MAX_CHUNKS
+#define LS_GEMM_QG2_MAX_CHUNKS 96    // stored rows up to this many chunks: 2 query groups per wave
+#endif
+#ifndef LS_GEMM_STAGGER
+#define LS_GEMM_STAGGER 0            // one accumulator set: the SIMD's two waves filter at opposite ends
+#endif
+#ifndef LS_GEMM_RING3
+#define LS_GEMM_RING3 1              // three tile buffers, DMA two tiles ahead (when they fit in LDS)
+#endif
 #define LS_GEMM_SAMPLE_ROWS 128      // sample pass: rows per workgroup
 #define LS_GEMM_MAX_SPLITS 256       // corpus slices (the select kernel gives each one a thread)
 
@@ -179,10 +186,8 @@ int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const ls_s
 int ls_launch_finalize(const struct ls_fin_batch& jobs, int njobs, hipStream_t s);
 // batched MFMA path (ls_gemm.hip)
 struct ls_gemm_bufs {
-    void* d_rec;        // uint2 [nq_pad][nsplits][LS_GEMM_REC]
-    u32* d_rcnt;        // [nq_pad][nsplits]
-    void* d_spill;      // uint2 [nq_pad][nsplits][4][LS_GEMM_SCAP]
-    u32* d_scnt;        // [nq_pad][nsplits][4]
+    void* d_queues;     // uint2 [nq_pad][nsplits][4][LS_GEMM_QCAP]: private candidate queues
+    u32* d_counts;      // [nq_pad][nsplits][4]
     u32* d_overflow;    // [nq_pad] repair flags of this call
     u32* d_sample_top;  // [nq_pad][nsplits][4][4]
 };

@@ -4,29 +4,31 @@
 // (reference src/lean_explore/search/engine.py:250; the reference itself only ever sends nq=1).
 //
 // Why fused: the score matrix is nq*N fp32 = 819 MB for config 3; writing and re-reading it
-// would cost more HBM time than the whole MFMA budget, so scores never leave the CU.
+// would cost more HBM time than the whole MFMA budget, so scores never leave registers.
 //
 // ls_gemm_filter_kernel — one workgroup = 8 waves x (16*QG queries) x one corpus slice
 //   - v_mfma_f32_16x16x32_f16. A wave owns QG = 2 groups of 16 queries (1 only for stored rows of
 //     2 KiB): their fp16 fragments stay in VGPRs for the whole slice, so B costs no LDS or HBM
 //     traffic in the loop. For 1.5 KiB rows (config 4) that is 192 of the wave's 256 registers;
-//     the kernel then keeps ONE accumulator set and the two waves of a SIMD filter at opposite
-//     ends of a tile, so one of them always feeds the matrix pipe (see run_tile).
+//     the kernel then keeps ONE accumulator set (ONE_ACC).
 //   - A operand (corpus): tiles of TM rows (64, or 32 for long rows) stream HBM/L2 -> LDS by DMA
-//     (global_load_lds, 16 B/lane, double buffered) and are shared by the 8 waves. LDS rows are
-//     XOR-swizzled on the SOURCE address (chunk ^ (row & 15)): conflict-free ds_read_b128.
+//     (global_load_lds, 16 B/lane) into a ring of three buffers, TWO tiles ahead of the MFMAs:
+//     the hand-over waits with a counted vmcnt for the NEXT tile only (loads return in order, so
+//     "at most LOADS outstanding" proves the older tile has landed whatever stores sit between)
+//     and crosses a bare s_barrier; a whole tile time of HBM latency stays hidden.
+//     LDS rows are XOR-swizzled on the SOURCE address (chunk ^ (row & 15)): conflict-free
+//     ds_read_b128.
 //   - epilogue: lane (query, quarter) holds 4 row scores per accumulator; a score >= tau[query]
-//     is appended to the lane's private queue. The first QL entries of a queue live in the LDS
-//     the tiles leave free (a ds_write_b64, no HBM traffic, no atomics); the rare lane that sees
-//     more spills to a private HBM queue. When the slice is done the four quarter-queues of a
-//     query are compacted into ONE contiguous record per (query, slice) in HBM: the select kernel
-//     reads 1-2 lines per slice instead of walking 4 scattered queues.
+//     is appended to the lane's private queue in HBM (no atomics) as a raw (score, slice-relative
+//     row) pair. The append is the hot slow path — every instruction in it costs ~1 us per batch
+//     (measured: an LDS-resident queue with an overflow test ran 10 us slower) — so it is a
+//     clamped slot, one address add and one store.
 //   - workgroups that share a corpus slice sit on the same XCD (block % 8) so the slice is
 //     fetched from HBM once and served to the other query tiles from that XCD's L2.
 //
 // Phases (ls_api.hip orchestrates): sample pass (a few tiles of every slice; each lane keeps its 4
 // best sample scores in registers) -> tau kernel (j-th best sample score per query) -> full pass
-// with tau -> select kernel (exact top-k of each query's records, verifies >= k candidates). A
+// with tau -> select kernel (exact top-k of each query's queues, verifies >= k candidates). A
 // flagged query (queue overflow / too few candidates) is re-run by the exact per-query scan
 // path, so the result is always exact.
 #include "ls_select_dev.h"
@@ -40,14 +42,12 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 #define LS_GEMM_LDS_BYTES (160 * 1024)  // the whole LDS of a CU: one workgroup per CU
 
 // ---- static geometry of one instantiation ------------------------------------------------------
-__host__ __device__ constexpr int gemm_qg(int chunks) { return chunks <= 96 ? 2 : 1; }
-__host__ __device__ constexpr int gemm_tm(int chunks) { return chunks <= 64 ? LS_GEMM_TM_SHORT : 32; }
+__host__ __device__ constexpr int gemm_qg(int chunks) { return chunks <= LS_GEMM_QG2_MAX_CHUNKS ? 2 : 1; }
+__host__ __device__ constexpr int gemm_tm(int chunks) { return chunks <= 48 ? LS_GEMM_TM_SHORT : 32; }
 __host__ __device__ constexpr int gemm_tile_bytes(int chunks) { return gemm_tm(chunks) * chunks * 16; }
-// LDS queue entries per (lane, query group): what two tile buffers leave free, at most LS_GEMM_QL
-__host__ __device__ constexpr int gemm_ql(int chunks) {
-    const int left = LS_GEMM_LDS_BYTES - 2 * gemm_tile_bytes(chunks);
-    const int per = left / (LS_GEMM_THREADS * gemm_qg(chunks) * 8);
-    return per < 0 ? 0 : (per > LS_GEMM_QL ? LS_GEMM_QL : per);
+// tile buffers: a ring of three (two tiles of DMA look-ahead) when they fit, else two
+__host__ __device__ constexpr int gemm_nbuf(int chunks) {
+    return (LS_GEMM_RING3 && 3 * gemm_tile_bytes(chunks) <= LS_GEMM_LDS_BYTES) ? 3 : 2;
 }
 
 // ---- queries -> fp16 MFMA B fragments, normalised if asked, zero padded ---------------------------
@@ -135,24 +135,20 @@ __device__ __forceinline__ uint4 top4_keys(const float (&t)[4]) {  // 0 = "no sa
                       t[2] == -FLT_MAX ? 0u : ls_ord(t[2]), t[3] == -FLT_MAX ? 0u : ls_ord(t[3]));
 }
 
-// LDS store the compiler does not see as one: with a tile DMA (global_load_lds) in flight hipcc
-// puts `s_waitcnt vmcnt(0)` in front of every ordinary LDS store (the DMA is a pending LDS write
-// it cannot prove disjoint), which would park the wave behind the next tile's HBM fetch on every
-// queue append. LDS operations of one wave execute in order, so the flush's later reads of the
-// same queue need no wait either.
-__device__ __forceinline__ void lds_store_b64_nowait(unsigned lds_addr, unsigned lo, unsigned hi) {
-    const u64 v = ((u64)hi << 32) | lo;
-    asm volatile("ds_write_b64 %0, %1" : : "v"(lds_addr), "v"(v) : "memory");
-}
-
 struct ls_gemm_out {
-    uint2* rec;        // [nq_pad][nsplits][LS_GEMM_REC] (score bits, slice-relative row)
-    u32* rcnt;         // [nq_pad][nsplits] entries in the record | spill mask << 8
-    uint2* spill;      // [nq_pad][nsplits][4][LS_GEMM_SCAP] private HBM queues past the LDS part
-    u32* scnt;         // [nq_pad][nsplits][4] entries a spilling lane wrote
+    uint2* queues;     // [nq_pad][nsplits][4][LS_GEMM_QCAP] (score bits, slice-relative row)
+    u32* counts;       // [nq_pad][nsplits][4]
     u32* overflow;     // [nq_pad] per-query repair flag
     u32* sample_top;   // [nq_pad][nsplits][4][4] (sample pass)
 };
+
+// "at most n vector-memory operations outstanding" (gfx9 encoding: vmcnt in bits 3:0 and 15:14;
+// expcnt and lgkmcnt fields left at "no wait")
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
 
 template <int CHUNKS, int QG, bool SAMPLE>
 __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_gemm_filter_kernel(
@@ -164,17 +160,17 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     constexpr int QPW = 16 * QG;           // queries per wave
     constexpr int NV = NRB * QG * 4;       // filter values per lane per tile
     // B fragments of QG groups take KS*QG*4 registers. When that leaves too little for two
-    // accumulator sets, one set is kept and a chain is filtered right before it restarts.
+    // accumulator sets, one set is kept and filtered between a tile's k-loop and the next one's.
     constexpr bool ONE_ACC = KS * QG * 4 >= 128;
     constexpr int CPK = (NV + KS - 1) / KS;  // two sets: checks interleaved per k-step
     constexpr int ROW_BYTES = CHUNKS * 16;
     constexpr int TILE_CHUNKS = TM * CHUNKS;
     constexpr int TILE_BYTES = TILE_CHUNKS * 16;
     constexpr int LOADS = TILE_CHUNKS / LS_GEMM_THREADS;  // 16-byte DMA loads per thread per tile
-    constexpr int QL = SAMPLE ? 0 : gemm_ql(CHUNKS);
+    constexpr int NBUF = gemm_nbuf(CHUNKS);
+    constexpr int cap = LS_GEMM_QCAP;
     static_assert(TILE_CHUNKS % LS_GEMM_THREADS == 0, "tile must split evenly over the threads");
-    static_assert(QL * 4 <= LS_GEMM_REC, "a record holds the four LDS quarter-queues");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // tiles | lane queues
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // the tile ring
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar DMA addressing
@@ -188,12 +184,11 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     const int ntiles_all = r_begin < r_end ? (int)((r_end - r_begin + TM - 1) / TM) : 0;
     const int nt = (ntiles_all + tile_stride - 1) / tile_stride;  // tiles this launch visits
 
-    // ---- corpus tiles: HBM/L2 -> LDS by DMA (global_load_lds, 16 B per lane), double buffered --
+    // ---- corpus tiles: HBM/L2 -> LDS by DMA (global_load_lds, 16 B per lane) ------------------
     // Wave w, load j fills the 64 consecutive LDS chunks starting at (w*LOADS + j)*64: chunk Lc
     // is tile row r = Lc / CHUNKS, slot sl = Lc % CHUNKS and receives SOURCE chunk sl ^ (r & 15)
     // (the DMA destination is lane-linear, so the swizzle goes on the source address). The HBM
-    // copy is padded with zero rows past n (ls_api.hip): no clamping. A tile takes ~3 us to
-    // consume, longer than the DMA's flight, so one tile of look-ahead suffices.
+    // copy is padded with zero rows past n (ls_api.hip): no clamping.
     // Register-starved instantiations (ONE_ACC) recompute the per-lane source offsets for every
     // tile (a handful of VALU ops behind an opaque copy of the lane id): hoisted out of the tile
     // loop they would be spilled and every reload would wait on the memory pipe.
@@ -206,7 +201,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             goff[j] = r * CHUNKS + (sl ^ (r & 15));
         }
     }
-    auto stage = [&](int ti, int buf) {
+    auto stage = [&](int ti, int bufoff) {  // ti: tile index inside the slice; bufoff: LDS bytes
         const u32x4* base = corpus + (r_begin + (long long)ti * TM) * CHUNKS;
         int lane_v = lane;
         if constexpr (ONE_ACC) asm volatile("" : "+v"(lane_v));
@@ -220,9 +215,20 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             } else {
                 off = goff[j];
             }
-            unsigned char* dst = smem + buf * TILE_BYTES + (wave * LOADS + j) * 1024;
+            unsigned char* dst = smem + bufoff + (wave * LOADS + j) * 1024;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + off), (lds_ptr_t)dst, 16, 0, 0);
         }
+    };
+    // Hand-over between tiles: this wave's pieces of the NEXT tile have landed (`newer` = a
+    // younger tile's LOADS pieces may still be in flight: loads return in order, so "<= LOADS
+    // outstanding" means every older load is done, whatever stores were issued in between), then
+    // the workgroup barrier: every wave's pieces are in LDS and every wave is done reading the
+    // buffer that is refilled next. A bare s_barrier: __syncthreads() would drain vmcnt to 0.
+    auto hand_over = [&](bool newer) {
+        asm volatile("" ::: "memory");
+        if (newer) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     };
 
     // The first tile(s) are requested BEFORE the query fragments: the HBM round trip of tile 0
@@ -231,8 +237,10 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     const bool sample_upfront = SAMPLE && nt > 0 && nt <= NB_ALL && nt <= 3;
     if (nt > 0) stage(0, 0);
     if (sample_upfront) {
-        if (nt > 1) stage(tile_stride, 1);
-        if (nt > 2) stage(2 * tile_stride, 2);
+        if (nt > 1) stage(tile_stride, TILE_BYTES);
+        if (nt > 2) stage(2 * tile_stride, 2 * TILE_BYTES);
+    } else if (NBUF == 3 && nt > 1) {
+        stage(tile_stride, TILE_BYTES);
     }
 
     // B fragments: group qg holds query qt*8*QPW + wave*QPW + qg*16 + li; k-step kk -> chunk 4kk+qd
@@ -249,14 +257,14 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
         tauv[g2] = SAMPLE ? 0.0f : tau[qj[g2]];
     }
 
-    // This lane's candidate queues, one per query group: entry = {score bits, row relative to the
-    // slice}. Entries 0..QL-1 in LDS (behind the two tile buffers), the rest in the HBM spill queue.
-    uint2* lq = reinterpret_cast<uint2*>(smem + 2 * TILE_BYTES) + (size_t)tid * QG * (QL > 0 ? QL : 1);
-    const unsigned lq_addr = (unsigned)(uintptr_t)(lds_ptr_t)lq;  // LDS byte address of the queue
+    // private queues of this lane (one per query group), contiguous per lane
+    // entry = {score bits, row relative to the slice}; the select kernel turns it into a key
+    uint2* myq[QG];
     int cnt[QG];
     float top[QG][4];
 #pragma unroll
     for (int g2 = 0; g2 < QG; ++g2) {
+        myq[g2] = out.queues + queue_id(qj[g2], split, qd, nsplits) * cap;
         cnt[g2] = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) top[g2][e] = -FLT_MAX;
@@ -276,22 +284,16 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // ---- one score of a finished tile -------------------------------------------------------------
     // The append is the hot slow path (a wave enters it for ~1 check in 5): no key building, no
     // bounds logic here. Padded queries carry tau = FLT_MAX and never pass; zero-pad rows past n
-    // are dropped by the select kernel; a full spill queue keeps overwriting its last slot while
-    // the count runs on, which is how the overflow is seen at the end.
+    // are dropped by the select kernel; a full queue keeps overwriting its last slot while the
+    // count runs on, which is how the overflow is seen at the end.
     auto check1 = [&](float s, int g2, int lrow) {
         if (SAMPLE) {
             // NaN never enters (fmaxf/fminf drop it); padded queries and zero-pad rows are masked
             top4_insert(top[g2], (qj[g2] < nq && r_begin + lrow < r_end) ? s : -FLT_MAX);
         } else if (s >= tauv[g2]) {
-            const int c = cnt[g2];
-            const uint2 ent = make_uint2(__float_as_uint(s), (u32)lrow);
-            if (c < QL) {
-                lds_store_b64_nowait(lq_addr + (unsigned)(g2 * QL + c) * 8u, ent.x, ent.y);
-            } else {
-                const int slot = c - QL < LS_GEMM_SCAP ? c - QL : LS_GEMM_SCAP - 1;
-                out.spill[queue_id(qj[g2], split, qd, nsplits) * LS_GEMM_SCAP + slot] = ent;
-            }
-            cnt[g2] = c + 1;
+            const int slot = cnt[g2] < cap ? cnt[g2] : cap - 1;
+            myq[g2][slot] = make_uint2(__float_as_uint(s), (u32)lrow);
+            ++cnt[g2];
         }
     };
     auto check = [&](const f32x4v (&acc)[NRB][QG], int e, int lrow0) {  // e -> (block, group, reg)
@@ -302,12 +304,10 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // One tile: NRB*QG independent accumulator chains advance together, one k-step at a time.
     // Two sets: the PREVIOUS tile's accumulators are filtered CPK elements per k-step, in the
     // shadow of the matrix pipe. One set (ONE_ACC): the filter cannot hide inside its own wave's
-    // MFMA stream (every check is a branch the MFMAs are not scheduled across), so it hides under
-    // the OTHER wave of the SIMD instead: waves 0-3 filter a tile right after the hand-over
-    // barrier, before they overwrite the accumulators ("early"), waves 4-7 right after their
-    // k-loop, before the barrier ("late"); waves w and w+4 share a SIMD, so one of the pair is
-    // always feeding the matrix pipe while the other one filters.
-    const bool late = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
+    // MFMA stream (every check is a branch the MFMAs are not scheduled across); it runs before
+    // the k-loop overwrites the accumulators ("early") or, with LS_GEMM_STAGGER, for waves 4-7
+    // right after their own k-loop ("late": waves w and w+4 share a SIMD).
+    const bool late = LS_GEMM_STAGGER && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
     auto run_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], bool have_prev,
                         int prev_row0, int cur_row0, int bufoff) {
         if (ONE_ACC && !late && have_prev) {
@@ -378,59 +378,43 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             return;
         }
     }
-    __syncthreads();  // the compiler drains the DMA (vmcnt(0)) before the barrier
+    // ---- the tile loop. Ring of NBUF buffers; tile i sits in buffer i % NBUF. With three
+    // buffers tile i+2 is requested at the top of tile i (its buffer was last read during tile
+    // i-1, which every wave has left through the barrier); with two, tile i+1.
+    hand_over(NBUF == 3 && nt > 1);
+    constexpr int AHEAD = NBUF - 1;
+    int b_cur = 0, b_new = AHEAD * TILE_BYTES;  // LDS byte offsets of tile i and of tile i + AHEAD
+    auto advance = [&](int& b) { b = b + TILE_BYTES == NBUF * TILE_BYTES ? 0 : b + TILE_BYTES; };
+    auto one_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], int i) {
+        const bool more = i + AHEAD < nt;
+        if (more) stage((i + AHEAD) * tile_stride, b_new);
+        run_tile(cur, prev, i > 0, tile_row0(i - 1), tile_row0(i), b_cur);
+        // tile i+1 must be complete before anyone reads it. NBUF == 3: only when a younger tile
+        // was requested in this iteration may LOADS pieces stay in flight.
+        hand_over(NBUF == 3 && more);
+        advance(b_cur);
+        advance(b_new);
+    };
     if constexpr (ONE_ACC) {
-        for (int i = 0; i < nt; ++i) {
-            if (i + 1 < nt) stage((i + 1) * tile_stride, (i + 1) & 1);
-            run_tile(accA, accA, i > 0, tile_row0(i - 1), tile_row0(i), (i & 1) * TILE_BYTES);
-            __syncthreads();
-        }
+        for (int i = 0; i < nt; ++i) one_tile(accA, accA, i);
         if (nt > 0 && !late) flush_last(accA);
     } else {
         for (int i = 0; i < nt; i += 2) {
-            if (i + 1 < nt) stage((i + 1) * tile_stride, 1);
-            run_tile(accA, accB, i > 0, tile_row0(i - 1), 0, 0);
-            __syncthreads();
-            if (i + 1 < nt) {
-                if (i + 2 < nt) stage((i + 2) * tile_stride, 0);
-                run_tile(accB, accA, true, tile_row0(i), 0, TILE_BYTES);
-                __syncthreads();
-            }
+            one_tile(accA, accB, i);
+            if (i + 1 < nt) one_tile(accB, accA, i + 1);
         }
         if (nt > 0) {
             if ((nt - 1) & 1) flush_last(accB); else flush_last(accA);
         }
     }
-    if constexpr (SAMPLE) {
 #pragma unroll
-        for (int g2 = 0; g2 < QG; ++g2)
-            reinterpret_cast<uint4*>(out.sample_top)[queue_id(qj[g2], split, qd, nsplits)] =
-                top4_keys(top[g2]);
-    } else {
-        // ---- compact the four quarter-queues of every query into its (query, slice) record -------
-        // LDS is in-order per wave, and a lane reads back only what it wrote itself: no barrier.
-#pragma unroll
-        for (int g2 = 0; g2 < QG; ++g2) {
-            const int c = cnt[g2] < QL ? cnt[g2] : QL;  // entries in LDS
-            const int spilled = cnt[g2] > QL;
-            int off = 0, total = 0, smask = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int cj = __shfl(c, li + 16 * j, 64);
-                const int sj = __shfl(spilled, li + 16 * j, 64);
-                off += j < qd ? cj : 0;
-                total += cj;
-                smask |= sj << j;
-            }
-            const long long rid = (long long)qj[g2] * nsplits + split;
-            uint2* r = out.rec + rid * LS_GEMM_REC + off;
-            for (int e = 0; e < c; ++e) r[e] = lq[g2 * QL + e];
-            if (qd == 0) out.rcnt[rid] = (u32)total | ((u32)smask << 8);
-            if (spilled) {
-                const int sc = cnt[g2] - QL;
-                out.scnt[queue_id(qj[g2], split, qd, nsplits)] = (u32)(sc < LS_GEMM_SCAP ? sc : LS_GEMM_SCAP);
-                if (sc > LS_GEMM_SCAP) out.overflow[qj[g2]] = 1u;
-            }
+    for (int g2 = 0; g2 < QG; ++g2) {
+        const long long qid = queue_id(qj[g2], split, qd, nsplits);
+        if (SAMPLE) {
+            reinterpret_cast<uint4*>(out.sample_top)[qid] = top4_keys(top[g2]);
+        } else {
+            out.counts[qid] = (u32)(cnt[g2] < cap ? cnt[g2] : cap);
+            if (cnt[g2] > cap) out.overflow[qj[g2]] = 1u;
         }
     }
 }
@@ -446,19 +430,14 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
     const int nqt = (int)(nq_pad / (LS_GEMM_WAVES * 16 * QG));
     const dim3 grid((unsigned)(nsplits * nqt));
     ls_gemm_out o;
-    o.rec = (uint2*)b.d_rec;
-    o.rcnt = b.d_rcnt;
-    o.spill = (uint2*)b.d_spill;
-    o.scnt = b.d_scnt;
+    o.queues = (uint2*)b.d_queues;
+    o.counts = b.d_counts;
     o.overflow = b.d_overflow;
     o.sample_top = b.d_sample_top;
-    // full pass: two tile buffers + the lane queues; sample pass: up to three tiles up front
+    // full pass: the tile ring; sample pass: up to three tiles up front
     const size_t tile_bytes = (size_t)gemm_tile_bytes(g.chunks);
-    size_t smem;
-    if (d_tau)
-        smem = 2 * tile_bytes + (size_t)LS_GEMM_THREADS * QG * (gemm_ql(g.chunks) > 0 ? gemm_ql(g.chunks) : 1) * 8;
-    else
-        smem = tile_bytes * (3 * tile_bytes <= LS_GEMM_LDS_BYTES ? 3 : 2);
+    const size_t smem = d_tau ? tile_bytes * gemm_nbuf(g.chunks)
+                              : tile_bytes * (3 * tile_bytes <= LS_GEMM_LDS_BYTES ? 3 : 2);
 #define LS_GEMM_LAUNCH(C, SMP)                                                                    \
     {                                                                                             \
         auto kern = ls_gemm_filter_kernel<C, gemm_qg(C), SMP>;                                    \
@@ -486,83 +465,53 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
 // ---- tau: j-th best sample score of each query --------------------------------------------------
 // The sample pass left, for every (workgroup, lane, query group), the 4 best sample scores that
 // lane saw (ord() of the score, 0 = none). A query owns 4 lanes in each of its nsplits
-// workgroups: 16*nsplits values. ONE WAVE per query (4 queries per workgroup): the values sit in
-// registers, each radix pass is a wave-private LDS histogram + a 64-lane suffix scan: no
-// workgroup barrier anywhere. Keeping only 4 per lane can only LOWER the result (if one lane held
-// more than 4 of the best j), i.e. let more rows through: tau is a speculative, verified
-// threshold either way.
-#define LS_TAU_PER_LANE (LS_GEMM_MAX_SPLITS * 16 / 64)
+// workgroups: 16*nsplits values, contiguous. One 256-thread workgroup per query (this kernel is
+// latency-bound and far from filling the chip: four waves sharing a query's values measured
+// 5.7 us against 9.3 us for one wave per query); 2 radix passes find the j-th largest.
+// Keeping only 4 per lane can only LOWER the result (if one lane held more than 4 of the best
+// j), i.e. let more rows through: tau is a speculative, verified threshold either way.
+#define LS_TAU_PER_THREAD (LS_GEMM_MAX_SPLITS * 16 / 256)
 __global__ __launch_bounds__(256) void ls_tau_kernel(const u32* __restrict__ sample_top, int nsplits,
-                                                     int nq, int nq_pad, int j_rank,
-                                                     float* __restrict__ tau) {
-    __shared__ u32 hist_all[4][256];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int q = blockIdx.x * 4 + wv;
-    if (q >= nq_pad) return;
+                                                     int nq, int j_rank, float* __restrict__ tau) {
+    __shared__ u32 hist[2 * 256];
+    __shared__ u32 misc[2 * 8];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     if (q >= nq) {
-        if (lane == 0) tau[q] = FLT_MAX;  // padded query: nothing passes
+        if (tid == 0) tau[q] = FLT_MAX;  // padded query: nothing passes
         return;
     }
-    u32* hist = hist_all[wv];
-    const int total = nsplits * 16;  // values of this query, contiguous: [slice][quarter][4]
-    const uint4* src = reinterpret_cast<const uint4*>(sample_top) + (long long)q * nsplits * 4;
-    u32 v[LS_TAU_PER_LANE];
+    const int total = nsplits * 16;  // values of this query: [slice][quarter][4]
+    u32 v[LS_TAU_PER_THREAD];
 #pragma unroll
-    for (int j = 0; j < LS_TAU_PER_LANE / 4; ++j) {
-        const int idx4 = lane + j * 64;  // one (slice, quarter) group of 4 per load
-        const uint4 x = idx4 * 4 < total ? src[idx4] : make_uint4(0, 0, 0, 0);
-        v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
+    for (int j = 0; j < LS_TAU_PER_THREAD; ++j) {
+        const int idx = tid + j * 256;
+        v[j] = idx < total ? sample_top[(long long)q * total + idx] : 0u;
     }
+    for (int i = tid; i < 2 * 256; i += 256) hist[i] = 0;
+    __syncthreads();
     u32 pref = 0, pmask = 0, krem = (u32)j_rank;
     // Only the top 16 bits of the order key are resolved (sign, exponent, 7 mantissa bits): the
     // result is at most 0.8 % below the exact j-th sample score, i.e. still a valid (slightly
     // more permissive) speculative threshold, for half the passes.
     for (int pass = 0; pass < 2; ++pass) {
         const int shift = 24 - 8 * pass;
-        for (int i = lane; i < 256; i += 64) hist[i] = 0;
-        wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < LS_TAU_PER_LANE; ++j)
-            if (v[j] != 0u && (v[j] & pmask) == pref) atomicAdd(&hist[(v[j] >> shift) & 255u], 1u);
-        wave_lds_fence();
-        // lane l owns bins 4l..4l+3; suffix sums locate the bin of the krem-th largest value
-        const u32 h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2],
-                  h3 = hist[4 * lane + 3];
-        const u32 mine = h0 + h1 + h2 + h3;
-        u32 suf = mine;
-        for (int o = 1; o < 64; o <<= 1) {
-            const u32 t = __shfl_down(suf, o, 64);
-            if (lane + o < 64) suf += t;
-        }
-        const u32 above = suf - mine;
-        const u32 totalv = __shfl(suf, 0, 64);
-        if (pass == 0 && totalv < (u32)j_rank) {  // fewer than j sample scores: no bound
-            if (lane == 0) tau[q] = -FLT_MAX;
+        for (int j = 0; j < LS_TAU_PER_THREAD; ++j)
+            if (j * 256 < total)  // uniform: later slots hold no value
+                wave_hist_add(hist + pass * 256, (v[j] >> shift) & 255u,
+                              v[j] != 0u && (v[j] & pmask) == pref, lane);
+        __syncthreads();
+        find_bin(hist + pass * 256, krem, misc + pass * 8, tid);
+        __syncthreads();
+        if (pass == 0 && misc[3] < (u32)j_rank) {  // fewer than j sample scores: no bound
+            if (tid == 0) tau[q] = -FLT_MAX;
             return;
         }
-        const bool owner = krem > above && krem <= above + mine;  // exactly one lane
-        u32 bin = 0, rem = 0;
-        if (owner) {
-            u32 cum = above;
-            if (cum + h3 >= krem) { bin = 4 * lane + 3; rem = krem - cum; }
-            else {
-                cum += h3;
-                if (cum + h2 >= krem) { bin = 4 * lane + 2; rem = krem - cum; }
-                else {
-                    cum += h2;
-                    if (cum + h1 >= krem) { bin = 4 * lane + 1; rem = krem - cum; }
-                    else { cum += h1; bin = 4 * lane; rem = krem - cum; }
-                }
-            }
-        }
-        const int ol = __ffsll((long long)__ballot(owner)) - 1;
-        bin = (u32)__shfl((int)bin, ol, 64);
-        krem = (u32)__shfl((int)rem, ol, 64);
-        pref |= bin << shift;
+        pref |= misc[pass * 8] << shift;
         pmask |= 255u << shift;
-        wave_lds_fence();
+        krem = misc[pass * 8 + 1];
     }
-    if (lane == 0) tau[q] = ls_unord(pref);
+    if (tid == 0) tau[q] = ls_unord(pref);
 }
 
 int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_pad, int j_rank,
@@ -571,88 +520,89 @@ int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_p
         ls_set_error("batched path: too many slices for the tau kernel");
         return LS_ERR_INVALID_ARG;
     }
-    hipLaunchKernelGGL(ls_tau_kernel, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, s,
-                       d_sample_top, nsplits, (int)nq, (int)nq_pad, j_rank, d_tau);
+    hipLaunchKernelGGL(ls_tau_kernel, dim3((unsigned)nq_pad), dim3(256), 0, s, d_sample_top,
+                       nsplits, (int)nq, j_rank, d_tau);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
 
-// ---- exact top-k of each query's records -------------------------------------------------------------
-// One workgroup per query. Its nsplits record lengths are contiguous (one load per thread), a
-// block-wide prefix assigns LDS slots, then P = 256 / nsplits threads share each record's
-// entries (16-byte loads of two entries). Spilled lanes (rare) are walked afterwards.
-// LDS: keys[keys_cap] | res[res_cap] | tmp[res_cap] (u64), hist[8*256] | misc[64] (u32).
+// ---- exact top-k of each query's queues --------------------------------------------------------------
+// One workgroup per query. The query owns 4 queues per slice; thread t takes queues t, t + 256,
+// ...: one load each for their lengths, a block-wide prefix for the slot ranges in LDS, then the
+// (few) live entries. LDS: keys[keys_cap] | res[res_cap] | tmp[res_cap] (u64), hist[8*256] |
+// misc[64] | 16 words (u32) — all dynamic (a static __shared__ would shift its alignment).
+#define LS_BSEL_QPT (LS_GEMM_MAX_SPLITS * 4 / 256)  // queues per thread
 __global__ __launch_bounds__(256) void ls_batch_select_kernel(
-    const uint2* __restrict__ rec, const u32* __restrict__ rcnt, const uint2* __restrict__ spill,
-    const u32* __restrict__ scnt, int nsplits, int k, int keys_cap, int res_cap, long long base,
-    long long n, long long rows_per_split, u32* __restrict__ overflow,
-    float* __restrict__ out_scores, long long* __restrict__ out_indices) {
+    const uint2* __restrict__ queues, const u32* __restrict__ counts, int nsplits, int k,
+    int keys_cap, int res_cap, long long base, long long n, long long rows_per_split,
+    u32* __restrict__ overflow, float* __restrict__ out_scores,
+    long long* __restrict__ out_indices) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sel[];
     u64* keys = reinterpret_cast<u64*>(smem_sel);
     u64* res = keys + keys_cap;
     u64* tmp = res + res_cap;
     u32* hist = reinterpret_cast<u32*>(tmp + res_cap);
     u32* misc = hist + 8 * 256;
-    u32* wsum = misc + 64;  // [4] + nkeys: inside the dynamic region (a static __shared__ in front
-    u32& nkeys = wsum[4];   // of it would shift its 16-byte alignment)
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 word = tid < nsplits ? rcnt[(long long)q * nsplits + tid] : 0u;
-    const u32 c_rec = word & 255u, smask = (word >> 8) & 15u;
-    // spilled lanes' lengths ride along in the same prefix (their queue is walked by this thread)
-    u32 c_sp[4] = {0, 0, 0, 0};
-    u32 ct = c_rec;
-    if (smask) {
+    u32* wsum = misc + 64;
+    u32& nkeys = wsum[4];
+    constexpr int cap = LS_GEMM_QCAP;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int nqueues = nsplits * 4;
+    u32 c[LS_BSEL_QPT];
+    // the first four entries of each queue are fetched together with its length (their address
+    // does not depend on it): one round trip instead of two for the typical <= 4-entry queue
+    uint4 ea[LS_BSEL_QPT], eb[LS_BSEL_QPT];
+    const uint2* qbase = queues + (long long)q * nqueues * cap;  // queue qi starts at qbase + qi*cap
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (smask >> j & 1) {
-                c_sp[j] = scnt[queue_id(q, tid, j, nsplits)];
-                ct += c_sp[j];
-            }
-    }
-    u32 inc = ct;
-    for (int o = 1; o < 64; o <<= 1) {
-        const u32 t2 = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t2;
-    }
-    if (lane == 63) wsum[wv] = inc;
-    __syncthreads();
-    u32 off = 0;
-    for (int i = 0; i < wv; ++i) off += wsum[i];
-    if (tid == 0) nkeys = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    const u32 start = off + inc - ct;  // first LDS slot of slice `tid`
-    auto put = [&](u32 slot, uint2 ent, long long rb) {
-        if (slot < (u32)keys_cap) {
-            const long long row = rb + (long long)ent.y;
-            keys[slot] = row < n ? ls_make_key(__uint_as_float(ent.x), (u32)row) : 0ull;
+    for (int h = 0; h < LS_BSEL_QPT; ++h) {
+        const int qi = tid + h * 256;  // == split * 4 + quarter
+        c[h] = 0;
+        ea[h] = eb[h] = make_uint4(0, 0, 0, 0);
+        if (qi < nqueues) {
+            c[h] = counts[(long long)q * nqueues + qi];
+            ea[h] = reinterpret_cast<const uint4*>(qbase + (long long)qi * cap)[0];
+            eb[h] = reinterpret_cast<const uint4*>(qbase + (long long)qi * cap)[1];
         }
-    };
-    // record entries: P threads per slice, two entries per 16-byte load
-    const int P = nsplits <= 64 ? 4 : (nsplits <= 128 ? 2 : 1);
+    }
     {
-        const int sl = tid / P, part = tid % P;
-        // the owner thread's (start, c_rec) reach its helpers through LDS (hist is free until
-        // lds_topk, which re-zeroes it behind the barrier below)
-        if (tid < nsplits) reinterpret_cast<uint2*>(hist)[tid] = make_uint2(start, c_rec);
-        __syncthreads();
-        if (sl < nsplits) {
-            const uint2 sc = reinterpret_cast<const uint2*>(hist)[sl];
-            const long long rb = (long long)sl * rows_per_split;
-            const uint4* r4 = reinterpret_cast<const uint4*>(rec + ((long long)q * nsplits + sl) * LS_GEMM_REC);
-            for (u32 e = 2 * part; e < sc.y; e += 2 * P) {
-                const uint4 x = r4[e >> 1];
-                put(sc.x + e, make_uint2(x.x, x.y), rb);
-                if (e + 1 < sc.y) put(sc.x + e + 1, make_uint2(x.z, x.w), rb);
-            }
-        }
-    }
-    if (smask) {  // rare: this slice has lanes that spilled past their LDS queue
-        u32 slot = start + c_rec;
-        const long long rb = (long long)tid * rows_per_split;
+        const int lane = tid & 63, wv = tid >> 6;
+        u32 ct = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint2* sq = spill + queue_id(q, tid, j, nsplits) * LS_GEMM_SCAP;
-            for (u32 e = 0; e < c_sp[j]; ++e) put(slot + e, sq[e], rb);
-            slot += c_sp[j];
+        for (int h = 0; h < LS_BSEL_QPT; ++h) ct += c[h];
+        u32 inc = ct;
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t2 = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t2;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        u32 off = 0;
+        for (int i = 0; i < wv; ++i) off += wsum[i];
+        if (tid == 0) nkeys = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        u32 start = off + inc - ct;
+#pragma unroll
+        for (int h = 0; h < LS_BSEL_QPT; ++h) {
+            const u32 ch = c[h];
+            const int qi = tid + h * 256;
+            const long long rb = (long long)(qi >> 2) * rows_per_split;
+            auto put = [&](u32 e, u32 bits, u32 lrow) {
+                if (e < ch && start + e < (u32)keys_cap) {
+                    const long long row = rb + (long long)lrow;
+                    keys[start + e] = row < n ? ls_make_key(__uint_as_float(bits), (u32)row) : 0ull;
+                }
+            };
+            uint4 a = ea[h], b = eb[h];
+            for (u32 e0 = 0; e0 < ch; e0 += 4) {  // cap is a multiple of 4: loads stay in the queue
+                if (e0) {
+                    a = reinterpret_cast<const uint4*>(qbase + (long long)qi * cap + e0)[0];
+                    b = reinterpret_cast<const uint4*>(qbase + (long long)qi * cap + e0)[1];
+                }
+                put(e0, a.x, a.y);
+                put(e0 + 1, a.z, a.w);
+                put(e0 + 2, b.x, b.y);
+                put(e0 + 3, b.z, b.w);
+            }
+            start += ch;
         }
     }
     __syncthreads();
@@ -661,7 +611,8 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
         if (tid == 0) overflow[q] = 1u;
         return;
     }
-    if (overflow[q]) return;  // a spill queue overflowed in the GEMM pass
+    if (overflow[q]) return;  // a queue overflowed in the GEMM pass
+    __syncthreads();
     const int nvalid = lds_topk(keys, cnt, k, res, tmp, hist, misc, tid, 256);
     __syncthreads();
     if (nvalid < k && tid == 0) overflow[q] = 2u;  // the speculative tau let < k rows through
@@ -689,9 +640,9 @@ int ls_launch_batch_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k
     static ls_attr_once once;
     if (int rc = ls_set_max_dynamic_lds(once, (const void*)ls_batch_select_kernel, 128 * 1024)) return rc;
     hipLaunchKernelGGL(ls_batch_select_kernel, dim3((unsigned)nq), dim3(256), smem, s,
-                       (const uint2*)b.d_rec, b.d_rcnt, (const uint2*)b.d_spill, b.d_scnt, nsplits, k,
-                       keys_cap, res_cap, (long long)base, (long long)n, (long long)rows_per_split,
-                       b.d_overflow, d_out_scores, (long long*)d_out_indices);
+                       (const uint2*)b.d_queues, b.d_counts, nsplits, k, keys_cap, res_cap,
+                       (long long)base, (long long)n, (long long)rows_per_split, b.d_overflow,
+                       d_out_scores, (long long*)d_out_indices);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }

@@ -113,3 +113,28 @@ def test_rerank_mixing_weights(tmp_path):
              for i, t in enumerate(["sum of zero", "unrelated words", "zero zero sum and"])]
     b = eng._compute_bm25_on_informalizations("sum and zero", [(d_, 0.0) for d_ in decls])
     assert b[2] > b[0] > b[1]
+
+
+def test_engine_loads_bm25_indices_from_base_path(tmp_path):
+    """Like the reference (engine.py:175-190), SearchEngine(base_path=...) picks up the BM25 name
+    indices saved under the reference's file names without being handed a retriever."""
+    from lean_explore_amd.bm25 import NameRetriever
+
+    n, d = 1500, 128
+    corpus = H.gauss(31, n, d)
+    names = [f"Mathlib.lemma_{i}_add_comm" if i % 2 else f"Mathlib.thm{i}.mul_zero" for i in range(n)]
+    rows = [(7000 + i, names[i], "Mathlib.Mod", None, "src", "link", None, f"text {i}",
+             loader.embedding_to_blob(corpus[i].tolist())) for i in range(n)]
+    _make_db(tmp_path / "lean_explore.db", rows)
+    ids, loaded = loader.load_corpus_from_sqlite(tmp_path / "lean_explore.db")
+    loader.save_ids_map(tmp_path / "informalization_faiss_ids_map.json", ids)
+    ix = faiss_compat.IndexFlatIP(d)
+    ix.add(loaded)
+    faiss_compat.write_index(ix, tmp_path / "informalization_faiss.index")
+    built = NameRetriever.from_names(ids, names)
+    built.save(tmp_path)
+    eng = S.SearchEngine(base_path=tmp_path, embedding_client=FakeEmbed(corpus[10]))
+    lex = eng._retrieve_bm25_candidates("thm400 mul_zero", 1000)
+    assert lex == built("thm400 mul_zero", 1000) and 7400 in lex
+    res = run(eng.search("thm400 mul_zero", limit=5, rerank_top=0))
+    assert len(res) == 5

@@ -442,3 +442,49 @@ def test_no_device_memory_leak_over_index_lifetimes():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (8 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_normalized_query_is_bit_identical_to_the_oracle(dtype):
+    """ls_normalize_l2, the fused LS_FLAG_NORMALIZE of the scan path and of the batched path all
+    sum the squared norm in the library's one documented order (ls_wave_sumsq), which
+    oracle_normalize_l2 mirrors: same bits, hence the same fp16 rounding and 1e-5 scores."""
+    from lean_explore_amd.index import normalize_L2
+
+    for d in (36, 100, 384, 768, 1000, 1024):
+        x = (H.gauss(d, 5, d, normalize=False) * 3.7).astype(np.float32)
+        want = oracle.c_normalize_l2(x)
+        got = x.copy()
+        normalize_L2(got)
+        assert np.array_equal(got, want), d
+    c = H.gauss(3, 50_000, 384)
+    q = (H.gauss(4, 40, 384, normalize=False) * 2.5).astype(np.float32)
+    ix = FlatIPIndex.from_array(c, dtype=dtype)
+    for nq in (1, 8, 40):  # scan path singles / groups, and (f16) the batched path
+        D, I = ix.search(q[:nq], 50, normalize=True)
+        Dr, Ir = oracle.c_search(c, q[:nq], 50, normalize=True, f16=(dtype == "f16"))
+        _, _, S = oracle.np_search(c, oracle.c_normalize_l2(q[:nq]), 50, f16=(dtype == "f16"))
+        rep = oracle.compare_topk(D, I, Dr, Ir, S, score_tol=1e-5, tie_eps=2e-6)
+        assert rep["recall"] == 1.0, (nq, rep)
+    ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_add_appends_in_hbm_and_reconstruct_round_trips(dtype):
+    """index.add on a built index (ls_add: device-to-device carry-over) and reconstruct."""
+    c = H.gauss(7, 30_000, 200)  # d = 200: padded rows, the conversion kernels run
+    ix = FlatIPIndex(200, dtype=dtype)
+    ix.add(c[:10_000])
+    q = H.gauss(8, 3, 200)
+    D0, I0 = ix.search(q, 20)  # builds the handle
+    ix.add(c[10_000:25_000])   # ls_add
+    ix.add(c[25_000:])
+    assert ix.ntotal == 30_000
+    D, I = ix.search(q, 20)
+    Dr, Ir = oracle.c_search(c, q, 20, f16=(dtype == "f16"))
+    _, _, S = oracle.np_search(c, q, 20, f16=(dtype == "f16"))
+    assert oracle.compare_topk(D, I, Dr, Ir, S)["recall"] == 1.0
+    back = ix.host_corpus()
+    want = c if dtype == "f32" else c.astype(np.float16).astype(np.float32)
+    assert np.array_equal(back, want)
+    ix.close()

@@ -5,7 +5,10 @@
 // point returns LS_ERR_NO_DEVICE.
 #include "ls_common.h"
 
+#include <immintrin.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -47,8 +50,9 @@ struct ls_index {
         float* d_S = nullptr;        // n floats
         u64* d_cand = nullptr;       // max_blocks * LS_KP_MAX
         u64* d_bound = nullptr;      // max_blocks
-
     } sets[LS_NSETS];
+    hipStream_t last_scan_stream = nullptr;
+    bool scan_used = false;
     uint64_t set_rr = 0;
     int32_t last_set = 0;
     // batched (MFMA) path scratch, allocated on first use. ONE set per handle. A handle that only
@@ -99,6 +103,9 @@ struct ls_index {
     int32_t max_blocks = 0;
     float* d_out_s = nullptr;  int64_t* d_out_i = nullptr;  size_t out_cap = 0;  // nq*k
     u32* d_counters = nullptr;                        // [0] finalize slow-path count
+    u32* h_done = nullptr;     // pinned [LS_SCAN_MAX_NQ]: completion words of the host API
+    u32 done_seq = 0;
+    u32* done_base = nullptr;  // set by ls_search around its scan-path call, else null
     float* h_q = nullptr;      size_t h_q_cap = 0;    // pinned
     float* h_out_s = nullptr;  int64_t* h_out_i = nullptr;  size_t h_out_cap = 0;
 
@@ -294,6 +301,7 @@ void ls_destroy(ls_index* ix) {
     (void)hipFree(ix->d_sample_top);
     if (ix->h_overflow) (void)hipHostFree(ix->h_overflow);
     if (ix->h_q) (void)hipHostFree(ix->h_q);
+    if (ix->h_done) (void)hipHostFree(ix->h_done);
     if (ix->h_out_s) (void)hipHostFree(ix->h_out_s);
     if (ix->h_out_i) (void)hipHostFree(ix->h_out_i);
     for (hipEvent_t e : ix->prof_ev) (void)hipEventDestroy(e);
@@ -408,6 +416,12 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
     // while group i's scan fills B). The last group's finalizes are "pending": they ride on the
     // next call's first scan (LS_FLAG_PIPELINE) or are launched on their own right away.
     const bool pipeline = (flags & LS_FLAG_PIPELINE) != 0;
+    // The two scratch generations are ordered by stream order only: a call on another stream
+    // first waits (on the host) for whatever the previous stream still runs on them.
+    if (ix->scan_used && ix->last_scan_stream != s && !(ix->n_pending && ix->pending_stream != s))
+        LS_HIP(hipStreamSynchronize(ix->last_scan_stream));
+    ix->scan_used = true;
+    ix->last_scan_stream = s;
     if (ix->n_pending && (ix->pending_stream != s || !ix->opt_overlap)) {
         hipStream_t old = ix->pending_stream;
         rc = flush_pending(ix);
@@ -495,6 +509,8 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             p.out_scores = d_out_s + (q0 + i) * k;
             p.out_indices = (long long*)(d_out_i + (q0 + i) * k);
             p.counters = ix->d_counters;
+            p.done = ix->done_base ? ix->done_base + (q0 + i) : nullptr;
+            p.done_val = ix->done_seq;
         }
         ix->last_set = gen;
         q0 += real;
@@ -749,18 +765,48 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
     // (measured in tools/hostapi_time.py).
     const bool in_direct = nq <= LS_SCAN_MAX_NQ;    // big batches: one bulk copy is better
     const bool out_direct = on <= (size_t)(1 << 16);
+    // Small scan-path calls: the finalize workgroup of every query publishes a completion word
+    // in pinned host memory once its (pinned) output rows are visible; the host spins on those
+    // words instead of sleeping in hipStreamSynchronize (whose wake-up costs more than the
+    // 47 us scan's launch). Falls back to the stream sync after 2 ms.
+    const bool spin = in_direct && out_direct && !batched_eligible(ix, nq, k) && ix->n > 0;
+    if (spin && !ix->h_done) {
+        LS_HIP(hipHostMalloc((void**)&ix->h_done, sizeof(u32) * LS_SCAN_MAX_NQ, hipHostMallocDefault));
+        memset(ix->h_done, 0, sizeof(u32) * LS_SCAN_MAX_NQ);
+    }
     memcpy(ix->h_q, q, qn * sizeof(float));
     if (!in_direct)
         LS_HIP(hipMemcpyAsync(ix->d_qraw, ix->h_q, qn * sizeof(float), hipMemcpyHostToDevice, s));
+    if (spin) {
+        if (++ix->done_seq == 0) ix->done_seq = 1;
+        ix->done_base = ix->h_done;
+    }
     rc = search_on_stream(ix, in_direct ? ix->h_q : ix->d_qraw, nq, k, flags & LS_FLAG_NORMALIZE,
                           out_direct ? ix->h_out_s : ix->d_out_s,
                           out_direct ? ix->h_out_i : ix->d_out_i, s, true);
+    ix->done_base = nullptr;
     if (rc != LS_OK) return rc;
     if (!out_direct) {
         LS_HIP(hipMemcpyAsync(ix->h_out_s, ix->d_out_s, on * sizeof(float), hipMemcpyDeviceToHost, s));
         LS_HIP(hipMemcpyAsync(ix->h_out_i, ix->d_out_i, on * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     }
-    LS_HIP(hipStreamSynchronize(s));
+    bool done = false;
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned it = 0;; ++it) {
+            int64_t i = 0;
+            while (i < nq && __atomic_load_n(&ix->h_done[i], __ATOMIC_ACQUIRE) == ix->done_seq) ++i;
+            if (i == nq) {
+                done = true;
+                break;
+            }
+            _mm_pause();
+            if ((it & 1023) == 1023 &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+                break;
+        }
+    }
+    if (!done) LS_HIP(hipStreamSynchronize(s));
     memcpy(out_scores, ix->h_out_s, on * sizeof(float));
     memcpy(out_indices, ix->h_out_i, on * sizeof(int64_t));
     return LS_OK;

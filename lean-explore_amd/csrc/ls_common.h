@@ -141,6 +141,8 @@ struct ls_fin_params {
     float* out_scores;     // [k]
     long long* out_indices;  // [k]
     u32* counters;         // [0] left the fast path, [1] took the general path
+    u32* done;             // optional: pinned host word that receives done_val once the outputs
+    u32 done_val;          //           are visible to the host (the host API spins on it)
 };
 #define LS_SCAN_NQ_MAX 8
 struct ls_fin_batch {

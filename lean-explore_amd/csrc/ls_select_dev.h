@@ -485,6 +485,18 @@ static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem
         p.out_scores[i] = ls_key_score(key);
         p.out_indices[i] = ls_key_index(key, p.base);
     }
+    if (p.done) {
+        // completion word for the host API: every wave drains its output stores, the workgroup
+        // meets, then ONE lane releases at system scope and publishes (cdna_hip_programming.md
+        // Guideline 16, with the host as the consumer)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(p.done, p.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     LS_STAMP(5);
 #ifdef LS_FIN_TIMING
     if (tid == 0 && p.counters)

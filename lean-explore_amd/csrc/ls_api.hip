@@ -19,7 +19,6 @@
 
 #define LS_NSETS 2
 #define LS_BC_SLOTS 16
-#define LS_CORPUS_PAD_ROWS 128
 #define LS_PROF_MAX 4096
 
 static thread_local char g_err[512] = "";
@@ -521,10 +520,12 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
 
 // ---- batched MFMA path (ls_gemm.hip) ---------------------------------------------------------------
 static bool batched_eligible(const ls_index* ix, int64_t nq, int32_t k) {
-    return ix->opt_gemm && ix->dtype == LS_DTYPE_F16 && nq > LS_SCAN_MAX_NQ &&
-           k <= LS_GEMM_MAX_K && ix->g.chunks <= LS_GEMM_MAX_CHUNKS &&
-           (ix->n >= LS_GEMM_MIN_ROWS ||
-            (ix->n >= LS_GEMM_MIN_ROWS_BIGNQ && nq >= LS_GEMM_BIGNQ));
+    if (!ix->opt_gemm || k > LS_GEMM_MAX_K) return false;
+    const bool big = ix->n >= LS_GEMM_MIN_ROWS ||
+                     (ix->n >= LS_GEMM_MIN_ROWS_BIGNQ && nq >= LS_GEMM_BIGNQ);
+    if (ix->dtype == LS_DTYPE_F16)
+        return nq > LS_SCAN_MAX_NQ && ix->g.chunks <= LS_GEMM_MAX_CHUNKS && big;
+    return nq >= LS_GEMM32_MIN_NQ && big;  // fp32: exact f32 MFMA (ls_gemm32.hip), any row length
 }
 
 // Re-run the queries of the pending batched calls whose candidate queues overflowed (or were
@@ -564,9 +565,10 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     int rc = flush_pending(ix);
     if (rc != LS_OK) return rc;
     const ls_geom& g = ix->g;
+    const bool f32 = ix->dtype == LS_DTYPE_F32;
     const int QG = ls_gemm_qg(g);
-    const int QT = LS_GEMM_WAVES * 16 * QG;  // queries per workgroup
-    const int TM = ls_gemm_tile_rows(g);
+    const int QT = f32 ? 64 : LS_GEMM_WAVES * 16 * QG;  // queries per workgroup
+    const int TM = f32 ? 64 : ls_gemm_tile_rows(g);
     const int64_t nq_pad = (nq + QT - 1) / QT * QT;
     const int64_t qkeep_need = nq * g.d;
     if ((int)ix->bc_pending.size() >= LS_BC_SLOTS ||
@@ -586,9 +588,11 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         }
     }
     const int nqt = (int)(nq_pad / QT);
-    // corpus slices: one 8-wave workgroup per CU in total, a multiple of the 8 XCDs
+    // corpus slices: one 8-wave workgroup per CU in total, a multiple of the 8 XCDs. The fp32
+    // kernel is light on registers (two workgroups share a CU) and each workgroup walks two slices.
     int nsplits = (LS_GEMM_WG_PER_CU * ix->n_cu / nqt) / 8 * 8;
-    nsplits = std::max(8, std::min(nsplits, LS_GEMM_MAX_SPLITS));
+    nsplits = std::max(8, std::min(nsplits, 256));
+    if (f32) nsplits = 2 * std::max(8, std::min(LS_GEMM_MAX_SPLITS / 2, (2 * ix->n_cu / nqt) / 8 * 8));
     int64_t rps = (ix->n + nsplits - 1) / nsplits;
     rps = (rps + TM - 1) / TM * TM;
     const int tiles_per_split = (int)(rps / TM);
@@ -604,7 +608,8 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
 
     size_t c;
     c = ix->qh_cap;
-    if ((rc = grow((unsigned char**)&ix->d_qh, &c, (size_t)nq_pad * g.d_pad * 2)) != LS_OK) return rc;
+    if ((rc = grow((unsigned char**)&ix->d_qh, &c, (size_t)nq_pad * g.d_pad * (f32 ? 4 : 2))) != LS_OK)
+        return rc;
     ix->qh_cap = c;
     if ((rc = grow(&ix->d_queues, &ix->queues_cap, nrec * 4 * LS_GEMM_QCAP)) != LS_OK) return rc;
     if ((rc = grow(&ix->d_counts, &ix->counts_cap, nrec * 4)) != LS_OK) return rc;
@@ -642,12 +647,19 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         }
         pe = &ix->prof_ev[2 * ix->prof_n];
     }
-    rc = ls_launch_prep_f16(d_q, ix->d_qh, d_qkeep, nq, nq_pad, g,
-                            (flags & LS_FLAG_NORMALIZE) != 0, d_flags, s);
+    auto pass = [&](const float* tau, int stride) {  // sample pass (tau == null) or full pass
+        return f32 ? ls_launch_gemm32_filter(ix->d_corpus, ix->n, g, (const float*)ix->d_qh, nq,
+                                             nq_pad, tau, nsplits, rps, stride, bufs, s)
+                   : ls_launch_gemm_filter(ix->d_corpus, ix->n, g, ix->d_qh, nq, nq_pad, tau,
+                                           nsplits, rps, stride, bufs, s);
+    };
+    rc = f32 ? ls_launch_prep_f32(d_q, (float*)ix->d_qh, d_qkeep, nq, nq_pad, g,
+                                  (flags & LS_FLAG_NORMALIZE) != 0, d_flags, s)
+             : ls_launch_prep_f16(d_q, ix->d_qh, d_qkeep, nq, nq_pad, g,
+                                  (flags & LS_FLAG_NORMALIZE) != 0, d_flags, s);
     if (rc != LS_OK) return rc;
     // sample pass: a few tiles of every slice, spread over the slice
-    rc = ls_launch_gemm_filter(ix->d_corpus, ix->n, g, ix->d_qh, nq, nq_pad, nullptr, nsplits, rps,
-                               sample_stride, bufs, s);
+    rc = pass(nullptr, sample_stride);
     if (rc != LS_OK) return rc;
     // Speculative threshold. The k-th best SAMPLE score is a certified lower bound of the final
     // k-th best but passes ~k*N/M0 rows per query. The j-th best sample score (j < k) passes only
@@ -671,8 +683,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     if (rc != LS_OK) return rc;
     // full pass
     if (prof) LS_HIP(hipEventRecord(pe[0], s));
-    rc = ls_launch_gemm_filter(ix->d_corpus, ix->n, g, ix->d_qh, nq, nq_pad, ix->d_tau, nsplits,
-                               rps, 1, bufs, s);
+    rc = pass(ix->d_tau, 1);
     if (rc != LS_OK) return rc;
     if (prof) {
         LS_HIP(hipEventRecord(pe[1], s));

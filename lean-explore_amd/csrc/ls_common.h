@@ -21,6 +21,7 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 #define LS_WAVE 64
+#define LS_CORPUS_PAD_ROWS 128       // zero rows kept behind the stored corpus (whole-tile reads)
 #define LS_SCAN_THREADS 256          // 4 waves per scan workgroup
 #define LS_SCAN_WAVES (LS_SCAN_THREADS / LS_WAVE)
 #define LS_KP_MAX 16                 // per-workgroup emitted candidates (k') + 1 bound
@@ -52,7 +53,8 @@ typedef unsigned int u32;
 #define LS_GEMM_RING3 1              // three tile buffers, DMA two tiles ahead (when they fit in LDS)
 #endif
 #define LS_GEMM_SAMPLE_ROWS 128      // sample pass: rows per workgroup
-#define LS_GEMM_MAX_SPLITS 256       // corpus slices (the select kernel gives each one a thread)
+#define LS_GEMM_MAX_SPLITS 512       // corpus slices (4 queues each; the select kernel walks 8 per thread)
+#define LS_GEMM32_MIN_NQ 24           // fp32 index: batches at least this big take the f32 MFMA path
 
 __host__ __device__ __forceinline__ u32 ls_ord(float f) {
     f = f + 0.0f;  // folds -0.0 into +0.0
@@ -206,6 +208,13 @@ int ls_gemm_tile_rows(const ls_geom& g);  // corpus rows per LDS tile (64, or 32
 int ls_launch_batch_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k, int64_t base,
                            int64_t n, int64_t rows_per_split, float* d_out_scores,
                            int64_t* d_out_indices, hipStream_t s);
+// fp32 batched path (ls_gemm32.hip): exact f32 MFMA, shares tau / select with the fp16 path
+int ls_launch_prep_f32(const float* d_q, float* d_qp, float* d_qkeep, int64_t nq, int64_t nq_pad,
+                       const ls_geom& g, bool normalize, u32* d_overflow, hipStream_t s);
+int ls_launch_gemm32_filter(const void* d_corpus, int64_t n, const ls_geom& g, const float* d_qp,
+                            int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
+                            int64_t rows_per_split, int tile_stride, const ls_gemm_bufs& b,
+                            hipStream_t s);
 // merge of per-shard lists
 int ls_launch_merge(const float* d_scores_in, const int64_t* d_indices_in, int64_t stride_s_bytes,
                     int64_t stride_i_bytes, int32_t n_lists, int64_t nq, int32_t k,

@@ -214,9 +214,16 @@ __device__ __forceinline__ void wave_hist_add(u32* hist, u32 digit, bool active,
 }
 
 // Exact top-k of the non-zero keys in keys[0..cnt) (LDS, left untouched) -> res[0..kk) sorted
-// descending, kk = min(k, #non-zero). tmp: LDS scratch of LS_RES_CAP keys. k <= LS_RES_CAP.
-// hist: 8 * 256 counters (one histogram per radix pass, zeroed here), misc: 8 * 8 words.
+// descending, kk = min(k, #non-zero). tmp: LDS scratch of >= 256 keys. k <= LS_RES_CAP.
+// hist: 8 * 256 counters (one histogram per radix pass), misc: 8 * 8 words.
 // The caller must have synchronised the workgroup after writing keys.
+//
+// Candidate keys of one query share their leading score bits (they all passed one threshold), so
+// a fixed MSB-first digit schedule wastes its first passes on digits that separate nothing. One
+// reduction pass finds the highest bit in which the score halves differ (and the number of
+// non-zero keys); the 8-bit radix passes start there: typically 3 instead of 4, and the
+// selected bin thins out at once. Survivors are compacted with one wave-aggregated LDS atomic
+// per wave and step instead of one per key.
 #ifdef LS_FIN_TIMING  // developer instrumentation: phase stamps (100 MHz ticks) of one finalize
 __device__ unsigned long long g_fin_stamp[8];
 #define LS_STAMP(i) do { if (tid == 0) g_fin_stamp[i] = wall_clock64(); } while (0)
@@ -227,32 +234,67 @@ static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* t
                         int tid, int nt) {
     if (k > cnt) k = cnt;
     if (k <= 0) return 0;
-    const int lane = tid & 63;
+    const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
     const int cnt_pad = (cnt + 63) & ~63;  // whole waves take part in the ballots
+    // ---- range of the score halves + number of non-zero keys (one pass, no atomics) ---------
+    u32 vmax = 0, vmin = 0xffffffffu, nnz = 0;
+    for (int i = tid; i < cnt; i += nt) {
+        const u64 key = keys[i];
+        if (key != 0ull) {
+            const u32 hi = (u32)(key >> 32);
+            vmax = hi > vmax ? hi : vmax;
+            vmin = hi < vmin ? hi : vmin;
+            ++nnz;
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        const u32 a = (u32)__shfl_xor((int)vmax, o, 64), b = (u32)__shfl_xor((int)vmin, o, 64);
+        vmax = a > vmax ? a : vmax;
+        vmin = b < vmin ? b : vmin;
+        nnz += (u32)__shfl_xor((int)nnz, o, 64);
+    }
+    // hist is free until the first pass: [0..nw) max, [16..16+nw) min, [32..32+nw) counts
+    if (lane == 0) {
+        hist[wv] = vmax;
+        hist[16 + wv] = vmin;
+        hist[32 + wv] = nnz;
+    }
+    __syncthreads();
+    vmax = 0; vmin = 0xffffffffu; nnz = 0;
+    for (int w = 0; w < nw; ++w) {
+        vmax = hist[w] > vmax ? hist[w] : vmax;
+        vmin = hist[16 + w] < vmin ? hist[16 + w] : vmin;
+        nnz += hist[32 + w];
+    }
+    __syncthreads();
+    int kk = (u32)k < nnz ? k : (int)nnz;  // min(k, #non-zero keys)
+    if (kk == 0) return 0;
+    const u32 diff = vmax ^ vmin;
+    const int hb = diff ? 31 - __clz((int)diff) : -1;  // highest bit that separates any two scores
+    const int npass = (hb + 8) / 8;                      // 0 when every score is the same
     for (int i = tid; i < 8 * 256; i += nt) hist[i] = 0;
     if (tid == 0) misc[7 * 8 + 7] = 0;  // survivor counter
     __syncthreads();
-    u32 pref = 0, pmask = 0;
-    u32 krem = (u32)k, neq = 0;
-    int kk = k;
-    for (int pass = 0; pass < 4; ++pass) {  // score half
-        const int shift = 24 - 8 * pass;
+    u32 pref = hb >= 0 ? (vmax >> (hb + 1) << (hb + 1)) : vmax;  // the bits all scores share
+    if (hb == 31) pref = 0;
+    u32 pmask = hb >= 0 ? (hb == 31 ? 0u : ~((2u << hb) - 1u)) : 0xffffffffu;
+    u32 krem = (u32)kk, neq = nnz;
+    for (int pass = 0; pass < npass; ++pass) {  // score half, 8 bits at a time from bit hb down
+        const int top = hb - 8 * pass;           // highest bit of this digit
+        const int shift = top >= 7 ? top - 7 : 0;
+        const u32 dmask = top >= 7 ? 255u : ((2u << top) - 1u);
         u32* h = hist + pass * 256;
         u32* ms = misc + pass * 8;
         for (int i = tid; i < cnt_pad; i += nt) {
             const u64 key = i < cnt ? keys[i] : 0ull;
             const u32 hi = (u32)(key >> 32);
-            wave_hist_add(h, (hi >> shift) & 255u, key != 0ull && (hi & pmask) == pref, lane);
+            wave_hist_add(h, (hi >> shift) & dmask, key != 0ull && (hi & pmask) == pref, lane);
         }
         __syncthreads();
         find_bin(h, krem, ms, tid);
         __syncthreads();
-        if (pass == 0) {
-            kk = (int)ms[4];  // min(k, #non-zero keys)
-            if (kk == 0) return 0;
-        }
         pref |= ms[0] << shift;
-        pmask |= 255u << shift;
+        pmask |= dmask << shift;
         krem = ms[1];
         neq = ms[2];
         // every key of the selected bin is needed: the prefix alone (low bits 0) already is a
@@ -286,9 +328,16 @@ static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* t
     }
     const u64 T = ((u64)T_hi << 32) | (u64)T_lo;  // exactly kk non-zero keys are >= T
     u64* dst = (kk <= 256) ? tmp : res;
-    for (int i = tid; i < cnt; i += nt) {
-        const u64 key = keys[i];
-        if (key != 0ull && key >= T) dst[atomicAdd(&misc[7 * 8 + 7], 1u)] = key;
+    for (int i = tid; i < cnt_pad; i += nt) {  // one LDS atomic per wave and step
+        const u64 key = i < cnt ? keys[i] : 0ull;
+        const bool keep = key != 0ull && key >= T;
+        const u64 bal = __ballot(keep);
+        if (bal) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&misc[7 * 8 + 7], (u32)__popcll(bal));
+            base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+            if (keep) dst[base + __popcll(bal & ((1ull << lane) - 1ull))] = key;
+        }
     }
     __syncthreads();
     LS_STAMP(3);

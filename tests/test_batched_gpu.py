@@ -225,3 +225,74 @@ def test_async_repair_uses_the_librarys_query_copy():
     _, _, S = oracle.np_search(c, q, 100, f16=True)
     assert oracle.compare_topk(s.cpu().numpy(), i.cpu().numpy(), Dr, Ir, S)["recall"] == 1.0
     ix.close()
+
+
+# ---------------------------------------------------------------- fp32 index: exact f32 MFMA path
+def check_batched_f32(c, q, k, normalize=False, base=0):
+    ix = FlatIPIndex.from_array(c, dtype="f32", base=base)
+    D, I = ix.search(q, k, normalize=normalize)
+    assert ix.debug_counter(9) == 5, "fp32 batches of >= 24 queries take the f32 MFMA path"
+    qn = oracle.c_normalize_l2(q) if normalize else q
+    Dr, Ir = oracle.c_search(c, qn, k, base=base)
+    _, _, S = oracle.np_search(c, qn, k)
+    rep = oracle.compare_topk(D, I, Dr, Ir, S, score_tol=1e-5, base=base, tie_eps=2e-6)
+    assert rep["recall"] == 1.0, rep
+    fb = ix.debug_counter(8)
+    ix.close()
+    return rep, fb
+
+
+@pytest.mark.parametrize("nq,k,d", [(24, 10, 384), (64, 100, 1024), (200, 50, 100), (65, 1000, 768),
+                                    (130, 128, 36), (300, 64, 512)])
+def test_f32_batched_shapes(nq, k, d):
+    c = H.gauss(71, 40_000, d)
+    q = H.gauss(72, nq, d)
+    check_batched_f32(c, q, k, normalize=True, base=7_000_000)
+    check_batched_f32(c, oracle.c_normalize_l2(q), k)
+
+
+def test_f32_batched_integer_corpus_bit_exact():
+    c = H.int_corpus(73, 100_000, 384)
+    q = H.int_corpus(74, 96, 384)
+    ix = FlatIPIndex.from_array(c, dtype="f32")
+    D, I = ix.search(q, 64)
+    assert ix.debug_counter(9) == 5
+    Dr, Ir = oracle.c_search(c, q, 64)
+    assert np.array_equal(D, Dr) and np.array_equal(I, Ir)
+    print("f32 int corpus fallbacks (ties overflow the queues):", ix.debug_counter(8))
+    ix.close()
+
+
+@pytest.mark.parametrize("nq", [64, 1024])
+def test_f32_batched_reference_call_shape(nq):
+    """The reference's storage dtype and k (models/search_db.py:24-35, engine.py:538) batched:
+    N=200k, d=1024 fp32, k=1000."""
+    c = H.gauss(41, 200_000, 1024)
+    q = H.gauss(42, nq, 1024)
+    ix = FlatIPIndex.from_array(c, dtype="f32")
+    D, I = ix.search(q, 1000)
+    assert ix.debug_counter(9) == 5
+    nchk = 32
+    Dr, Ir = oracle.c_search(c, q[:nchk], 1000)
+    _, _, S = oracle.np_search(c, q[:nchk], 1000)
+    rep = oracle.compare_topk(D[:nchk], I[:nchk], Dr, Ir, S)
+    assert rep["recall"] == 1.0, rep
+    if nq > nchk:  # the tail of the batch against the scan path of the same index
+        ix.debug_option(4, 0)
+        Ds, Is = ix.search(q[-40:], 1000)
+        assert np.allclose(Ds, D[-40:], atol=2e-6)
+        assert (np.sort(Is, axis=1) == np.sort(I[-40:], axis=1)).mean() > 0.999
+    print("f32 k1000", nq, rep, "fallbacks", ix.debug_counter(8))
+    ix.close()
+
+
+def test_f32_batched_ragged_small_and_clustered():
+    # ragged slices (n not a multiple of anything), a planted cluster that overflows queues
+    c = H.gauss(75, 33_333, 200)
+    q = H.gauss(76, 70, 200)
+    rng = np.random.default_rng(6)
+    for r in range(9_000, 9_250):
+        v = q[3] + 0.05 * rng.standard_normal(200).astype(np.float32)
+        c[r] = v / np.linalg.norm(v)
+    rep, fb = check_batched_f32(c, q, 100)
+    print("f32 clustered", rep, "fallbacks", fb)

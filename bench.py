@@ -10,6 +10,7 @@ Workloads (BASELINE.json configs):
   c2  (default) N=200k d=384 fp32, nq=1,    k=50    HBM-bound     <- the headline metric
   c3            N=200k d=384 fp16, nq=1024, k=100   MFMA-bound    <- the metric's "batch=1024" half
   c2p           N=200k d=1024 fp32, nq=1,   k=1000  the reference's real call shape
+  c2m           N=1M   d=384 fp32, nq=1,    k=50    c2 with a 1.5 GB corpus (no cache assistance)
   c1            N=10k  d=384 fp32, nq=1,    k=50    the reference's CPU-runnable case
   c4            N=12.5M rows PER GPU (100M at 8 GPUs), d=768 fp16, nq=256, k=100; rows are
                 generated on the device per shard (seed 1234+rank); weak scaling
@@ -47,6 +48,7 @@ WORKLOADS = {
     "c1": (10_000, 384, "f32", 1, 50),
     "c2": (200_000, 384, "f32", 1, 50),
     "c2p": (200_000, 1024, "f32", 1, 1000),
+    "c2m": (1_000_000, 384, "f32", 1, 50),      # c2's shape past the 256 MiB Infinity Cache
     "c3": (200_000, 384, "f16", 1024, 100),
     "c4": (12_500_000, 768, "f16", 256, 100),  # rows PER GPU
 }

@@ -46,11 +46,8 @@ typedef unsigned int u32;
 #ifndef LS_GEMM_QG2_MAX_CHUNKS
 #define LS_GEMM_QG2_MAX_CHUNKS 96    // stored rows up to this many chunks: 2 query groups per wave
 #endif
-#ifndef LS_GEMM_STAGGER
-#define LS_GEMM_STAGGER 0            // one accumulator set: the SIMD's two waves filter at opposite ends
-#endif
 #ifndef LS_GEMM_RING3
-#define LS_GEMM_RING3 1              // three tile buffers, DMA two tiles ahead (when they fit in LDS)
+#define LS_GEMM_RING3 0              // 1: three tile buffers, DMA two tiles ahead (measured 1-2 % slower than two)
 #endif
 #define LS_GEMM_SAMPLE_ROWS 128      // sample pass: rows per workgroup
 #define LS_GEMM_MAX_SPLITS 512       // corpus slices (4 queues each; the select kernel walks 8 per thread)

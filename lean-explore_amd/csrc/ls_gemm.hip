@@ -189,11 +189,18 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // is tile row r = Lc / CHUNKS, slot sl = Lc % CHUNKS and receives SOURCE chunk sl ^ (r & 15)
     // (the DMA destination is lane-linear, so the swizzle goes on the source address). The HBM
     // copy is padded with zero rows past n (ls_api.hip): no clamping.
-    // Register-starved instantiations (ONE_ACC) recompute the per-lane source offsets for every
-    // tile (a handful of VALU ops behind an opaque copy of the lane id): hoisted out of the tile
-    // loop they would be spilled and every reload would wait on the memory pipe.
-    int goff[ONE_ACC ? 1 : LOADS];
-    if constexpr (!ONE_ACC) {
+    // 1.5 KiB rows (config 4) are 1.5 DMA pieces each and the kernel has no registers to keep six
+    // per-lane offsets: the tile is stored with logical rows r and r + 16 ADJACENT in LDS
+    // (physical row 2*(r & 15) + (r >> 4)); wave w then stages {w, w+16} and {w+8, w+24} as two
+    // runs of three whole pieces, and since both rows of a run share the swizzle key r & 15 every
+    // source offset is  run base (scalar) + (lane ^ key) + constant : ~12 VALU per tile instead
+    // of ~55 for the generic divide-by-row-length form. PAIRED changes a_frag's row stride too.
+    constexpr bool PAIRED = CHUNKS == 96 && TM == 32 && LS_GEMM_WAVES == 8;
+    // Other register-starved instantiations (ONE_ACC) recompute the generic per-lane offsets for
+    // every tile behind an opaque copy of the lane id: hoisted out of the tile loop they would be
+    // spilled and every reload would wait on the memory pipe.
+    int goff[(ONE_ACC || PAIRED) ? 1 : LOADS];
+    if constexpr (!ONE_ACC && !PAIRED) {
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) {
             const int Lc = (wave * LOADS + j) * 64 + lane;
@@ -204,7 +211,22 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     auto stage = [&](int ti, int bufoff) {  // ti: tile index inside the slice; bufoff: LDS bytes
         const u32x4* base = corpus + (r_begin + (long long)ti * TM) * CHUNKS;
         int lane_v = lane;
-        if constexpr (ONE_ACC) asm volatile("" : "+v"(lane_v));
+        if constexpr (ONE_ACC || PAIRED) asm volatile("" : "+v"(lane_v));
+        if constexpr (PAIRED) {
+#pragma unroll
+            for (int run = 0; run < 2; ++run) {
+                const int r0 = wave + 8 * run;            // logical rows r0 and r0 + 16, key r0
+                const int t = lane_v ^ r0;
+                const u32x4* rowp = base + r0 * CHUNKS;  // wave-uniform
+                unsigned char* dst = smem + bufoff + (2 * r0) * ROW_BYTES;
+                const int mid = lane_v < 32 ? 64 + t : 16 * CHUNKS + t - 32;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + t), (lds_ptr_t)dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + mid), (lds_ptr_t)(dst + 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + 16 * CHUNKS + 32 + t),
+                                                 (lds_ptr_t)(dst + 2048), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) {
             int off;
@@ -274,10 +296,11 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // (4kk + qd) & 15 takes 4 values per lane: 4 precomputed byte offsets + immediates.
     int lo4[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) lo4[m] = li * ROW_BYTES + (((4 * m + qd) ^ li) * 16);
+    for (int m = 0; m < 4; ++m)
+        lo4[m] = li * (PAIRED ? 2 : 1) * ROW_BYTES + (((4 * m + qd) ^ li) * 16);
     auto a_frag = [&](int bufoff, int rb, int kk) -> half8 {  // bufoff: byte offset of the tile
         const u32x4 v = *reinterpret_cast<const u32x4*>(smem + lo4[kk & 3] + bufoff +
-                                                        rb * 16 * ROW_BYTES + (kk >> 2) * 256);
+                                                        rb * (PAIRED ? 1 : 16) * ROW_BYTES + (kk >> 2) * 256);
         return __builtin_bit_cast(half8, v);
     };
 
@@ -305,9 +328,8 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // Two sets: the PREVIOUS tile's accumulators are filtered CPK elements per k-step, in the
     // shadow of the matrix pipe. One set (ONE_ACC): the filter cannot hide inside its own wave's
     // MFMA stream (every check is a branch the MFMAs are not scheduled across); it runs before
-    // the k-loop overwrites the accumulators ("early") or, with LS_GEMM_STAGGER, for waves 4-7
-    // right after their own k-loop ("late": waves w and w+4 share a SIMD).
-    const bool late = LS_GEMM_STAGGER && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
+    // the k-loop overwrites the accumulators.
+    constexpr bool late = false;  // (a per-SIMD stagger - waves 4-7 filtering after their k-loop - measured 1-2 % slower)
     auto run_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], bool have_prev,
                         int prev_row0, int cur_row0, int bufoff) {
         if (ONE_ACC && !late && have_prev) {
@@ -470,7 +492,7 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
 // 5.7 us against 9.3 us for one wave per query); 2 radix passes find the j-th largest.
 // Keeping only 4 per lane can only LOWER the result (if one lane held more than 4 of the best
 // j), i.e. let more rows through: tau is a speculative, verified threshold either way.
-#define LS_TAU_PER_THREAD (LS_GEMM_MAX_SPLITS * 16 / 256)
+template <int LS_TAU_PER_THREAD>  // values per thread: 16 * nsplits / 256, rounded up to 4, 8, 16, 32
 __global__ __launch_bounds__(256) void ls_tau_kernel(const u32* __restrict__ sample_top, int nsplits,
                                                      int nq, int j_rank, float* __restrict__ tau) {
     __shared__ u32 hist[2 * 256];
@@ -520,18 +542,26 @@ int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_p
         ls_set_error("batched path: too many slices for the tau kernel");
         return LS_ERR_INVALID_ARG;
     }
-    hipLaunchKernelGGL(ls_tau_kernel, dim3((unsigned)nq_pad), dim3(256), 0, s, d_sample_top,
-                       nsplits, (int)nq, j_rank, d_tau);
+#define LS_TAU_LAUNCH(P)                                                                       \
+    hipLaunchKernelGGL(ls_tau_kernel<P>, dim3((unsigned)nq_pad), dim3(256), 0, s, d_sample_top, \
+                       nsplits, (int)nq, j_rank, d_tau)
+    if (nsplits <= 64) LS_TAU_LAUNCH(4);
+    else if (nsplits <= 128) LS_TAU_LAUNCH(8);
+    else if (nsplits <= 256) LS_TAU_LAUNCH(16);
+    else LS_TAU_LAUNCH(32);
+#undef LS_TAU_LAUNCH
     LS_HIP(hipGetLastError());
     return LS_OK;
 }
 
 // ---- exact top-k of each query's queues --------------------------------------------------------------
-// One workgroup per query. The query owns 4 queues per slice; thread t takes queues t, t + 256,
+// One 256-thread workgroup per query (one WAVE per query with the keys in registers and no
+// barrier at all measured 19.7 us against 18.4 us: a lone wave has nothing to hide its LDS
+// latencies behind). The query owns 4 queues per slice; thread t takes queues t, t + 256,
 // ...: one load each for their lengths, a block-wide prefix for the slot ranges in LDS, then the
 // (few) live entries. LDS: keys[keys_cap] | res[res_cap] | tmp[res_cap] (u64), hist[8*256] |
 // misc[64] | 16 words (u32) — all dynamic (a static __shared__ would shift its alignment).
-#define LS_BSEL_QPT (LS_GEMM_MAX_SPLITS * 4 / 256)  // queues per thread
+template <int LS_BSEL_QPT>  // queues per thread: 4 * nsplits / 256, rounded up to 1, 2, 4, 8
 __global__ __launch_bounds__(256) void ls_batch_select_kernel(
     const uint2* __restrict__ queues, const u32* __restrict__ counts, int nsplits, int k,
     int keys_cap, int res_cap, long long base, long long n, long long rows_per_split,
@@ -637,12 +667,22 @@ int ls_launch_batch_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k
     while (res_cap < k) res_cap <<= 1;
     const size_t smem = ((size_t)keys_cap + 2 * (size_t)res_cap) * sizeof(u64) +
                         (8 * 256 + 64 + 16) * sizeof(u32);
-    static ls_attr_once once;
-    if (int rc = ls_set_max_dynamic_lds(once, (const void*)ls_batch_select_kernel, 128 * 1024)) return rc;
-    hipLaunchKernelGGL(ls_batch_select_kernel, dim3((unsigned)nq), dim3(256), smem, s,
-                       (const uint2*)b.d_queues, b.d_counts, nsplits, k, keys_cap, res_cap,
-                       (long long)base, (long long)n, (long long)rows_per_split, b.d_overflow,
-                       d_out_scores, (long long*)d_out_indices);
+#define LS_BSEL_LAUNCH(P)                                                                      \
+    {                                                                                          \
+        static ls_attr_once once;                                                              \
+        if (int rc = ls_set_max_dynamic_lds(once, (const void*)ls_batch_select_kernel<P>,     \
+                                            128 * 1024))                                       \
+            return rc;                                                                         \
+        hipLaunchKernelGGL(ls_batch_select_kernel<P>, dim3((unsigned)nq), dim3(256), smem, s, \
+                           (const uint2*)b.d_queues, b.d_counts, nsplits, k, keys_cap, res_cap, \
+                           (long long)base, (long long)n, (long long)rows_per_split,          \
+                           b.d_overflow, d_out_scores, (long long*)d_out_indices);            \
+    }
+    if (nsplits <= 64) LS_BSEL_LAUNCH(1)
+    else if (nsplits <= 128) LS_BSEL_LAUNCH(2)
+    else if (nsplits <= 256) LS_BSEL_LAUNCH(4)
+    else LS_BSEL_LAUNCH(8)
+#undef LS_BSEL_LAUNCH
     LS_HIP(hipGetLastError());
     return LS_OK;
 }

@@ -52,7 +52,7 @@ if stats:
     # keep this library's kernels only (the torch kernels that build the synthetic corpus are noise)
     with open(stats[0]) as fh:
         rows = list(csv.DictReader(fh))
-    keep = [r for r in rows if "ls_" in r["Name"]]
+    keep = [r for r in rows if "ls_" in r["Name"] or "bm25_" in r["Name"]]
     with open(dst / f"{tag}_{wl}_kernel_stats.csv", "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
         w.writeheader()

@@ -162,7 +162,7 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * group on the next scan launch (default on); option 4: allow the batched MFMA path (default on);
  * option 5: speculative, verified sample threshold on the batched path (default on; off = the
  * certified k-th sample score); option 6: several queries per corpus pass on the scan path
- * (default on).
+ * (default on); option 7: force the number of scan workgroups per launch (0 = automatic).
  * counter 9: kernel launches of the most recent batched call.
  * counter 0: searches whose finalize step left the fast path (rescue or general); counter 1:
  * those that took the general path; counter 8: queries of batched calls that were repaired by

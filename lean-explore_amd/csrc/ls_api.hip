@@ -110,6 +110,7 @@ struct ls_index {
 
     // options / instrumentation
     int32_t opt_kprime = 0;  // 0 = automatic
+    int32_t opt_blocks = 0;  // 0 = automatic (scan workgroups per launch)
     int32_t opt_force_slow = 0;
     int32_t opt_overlap = 1;    // finalize of group i-1 rides on the scan launch of group i
     int32_t opt_alternate = 0;  // alternate sweep direction between consecutive scans
@@ -216,7 +217,8 @@ static int alloc_rows(ls_index* ix, int64_t new_n) {
     }
     if (ix->d_corpus) LS_HIP(hipFree(ix->d_corpus));
     ix->d_corpus = d_new;
-    ix->max_blocks = ls_scan_blocks(new_n > 0 ? new_n : 1, ix->g, ix->n_cu);
+    // room for the tuning hook (debug option 7) to force up to 4 workgroups per CU
+    ix->max_blocks = std::max(ls_scan_blocks(new_n > 0 ? new_n : 1, ix->g, ix->n_cu), 4 * ix->n_cu);
     ix->s_stride = ((new_n > 0 ? new_n : 1) + 63) / 64 * 64;
     for (auto& st : ix->sets) {  // room for LS_SCAN_NQ_MAX queries per generation
         if (st.d_S) LS_HIP(hipFree(st.d_S));
@@ -405,7 +407,8 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
     int rc = LS_OK;
     const bool normalize = (flags & LS_FLAG_NORMALIZE) != 0;
     const int64_t keff = std::min<int64_t>(k, ix->n);
-    const int blocks = ls_scan_blocks(ix->n > 0 ? ix->n : 1, g, ix->n_cu);
+    const int blocks = ix->opt_blocks > 0 ? std::min(ix->opt_blocks, ix->max_blocks)
+                                          : ls_scan_blocks(ix->n > 0 ? ix->n : 1, g, ix->n_cu);
     const int kprime = pick_kprime(ix, blocks, (int)std::max<int64_t>(keff, 1));
     // Everything is queued on the caller's stream. Queries go out in groups of 8, 4 or 1 that
     // share one pass over the corpus:
@@ -1058,6 +1061,10 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
     std::lock_guard<std::mutex> lk(ix->mu);
     if (which == 0) {  // force k' (0 = automatic)
         ix->opt_kprime = value;
+        return LS_OK;
+    }
+    if (which == 7) {  // force the number of scan workgroups per launch (0 = automatic)
+        ix->opt_blocks = value;
         return LS_OK;
     }
     if (which == 6) {  // several queries per corpus pass on the scan path (default on)

@@ -297,7 +297,26 @@ int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu) {
     constexpr int tpw = 4;
     int64_t b = (NT + LS_SCAN_WAVES * tpw - 1) / (LS_SCAN_WAVES * tpw);
     const int64_t cap = (int64_t)n_cu * bpc;
-    if (b > cap) b = cap;
+    if (b > cap) {
+        // Big shards: tiles are dealt round-robin to 4*b waves, so the launch ends with a partial
+        // round in which only frac(NT / 4b) of the waves still have a tile - too few to keep HBM
+        // busy. Measured on config 2 (25 000 tiles): 512 workgroups (12.2 rounds) 47.55 us,
+        // 448 (13.95 rounds) 47.03 us; config 2' 123.2 vs 120.4 us (tools/scan_blocks_sweep.py).
+        // Pick the count in [1.5, 2] workgroups per CU (multiples of the 8 XCDs) whose last round
+        // is the fullest.
+        int64_t best = cap;
+        double best_fill = -1.0;
+        for (int64_t c = cap; c >= cap * 3 / 4; c -= 8) {
+            const double rounds = (double)NT / (double)(c * LS_SCAN_WAVES);
+            double fill = rounds - (double)(int64_t)rounds;
+            if (fill == 0.0) fill = 1.0;
+            if (fill > best_fill + 0.02) {  // near-ties go to the larger count
+                best_fill = fill;
+                best = c;
+            }
+        }
+        b = best;
+    }
     if (b < 1) b = 1;
     return (int)b;
 }

@@ -326,13 +326,49 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
 
     // One tile: NRB*QG independent accumulator chains advance together, one k-step at a time.
     // Two sets: the PREVIOUS tile's accumulators are filtered CPK elements per k-step, in the
-    // shadow of the matrix pipe. One set (ONE_ACC): the filter cannot hide inside its own wave's
-    // MFMA stream (every check is a branch the MFMAs are not scheduled across); it runs before
-    // the k-loop overwrites the accumulators.
-    constexpr bool late = false;  // (a per-SIMD stagger - waves 4-7 filtering after their k-loop - measured 1-2 % slower)
+    // shadow of the matrix pipe.
+    // One set, two query groups (SEQ_RB, config 4's geometry): the tile's two row blocks run one
+    // after the other; while block rb's two chains advance, the 8 scores of the block that
+    // finished just before (block rb-1 of this tile, or the last block of the previous tile,
+    // still sitting in its registers) are filtered, one every KS/8 k-steps. The filter hides in
+    // the MFMA stream again without a second accumulator set.
+    // One set, one query group (2 KiB rows): a single chain per row block would stall on its own
+    // MFMA latency, so all blocks advance together and the filter runs before the k-loop.
+    constexpr bool SEQ_RB = ONE_ACC && QG == 2 && LS_GEMM_SEQ_RB;
     auto run_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], bool have_prev,
                         int prev_row0, int cur_row0, int bufoff) {
-        if (ONE_ACC && !late && have_prev) {
+        if constexpr (SEQ_RB) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const int pb = rb == 0 ? NRB - 1 : rb - 1;  // block whose scores are filtered now
+                const bool have = rb == 0 ? have_prev : true;
+                const int prow0 = (rb == 0 ? prev_row0 : cur_row0) + pb * 16;
+                half8 a[2];
+                a[0] = a_frag(bufoff, rb, 0);
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    if (kk + 1 < KS) a[(kk + 1) & 1] = a_frag(bufoff, rb, kk + 1);
+#pragma unroll
+                    for (int g2 = 0; g2 < QG; ++g2) {
+                        f32x4v c;
+                        if (kk == 0) {
+                            c[0] = 0.0f; c[1] = 0.0f; c[2] = 0.0f; c[3] = 0.0f;
+                        } else {
+                            c = cur[rb][g2];
+                        }
+                        cur[rb][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk & 1], bq[g2][kk], c,
+                                                                            0, 0, 0);
+                    }
+                    if (have) {
+#pragma unroll
+                        for (int e = 0; e < QG * 4; ++e)
+                            if ((e * KS) / (QG * 4) == kk) check1(cur[pb][e / 4][e % 4], e / 4, prow0 + e % 4);
+                    }
+                }
+            }
+            return;
+        }
+        if (ONE_ACC && have_prev) {
 #pragma unroll
             for (int e = 0; e < NV; ++e) check(prev, e, prev_row0);
         }
@@ -365,10 +401,6 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                     if (kk * CPK + c2 < NV) check(prev, kk * CPK + c2, prev_row0);
             }
         }
-        if (ONE_ACC && late) {
-#pragma unroll
-            for (int e = 0; e < NV; ++e) check(cur, e, cur_row0);
-        }
     };
 
     f32x4v accA[NRB][QG], accB[NRB][QG];  // two sets alternate between tiles (ONE_ACC: accA only)
@@ -376,7 +408,8 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     auto flush_last = [&](const f32x4v (&acc)[NRB][QG]) {  // the last tile still has to be filtered
         const int row0 = tile_row0(nt - 1);
 #pragma unroll
-        for (int e = 0; e < NV; ++e) check(acc, e, row0);
+        for (int e = 0; e < NV; ++e)
+            if (!SEQ_RB || e / (QG * 4) == NRB - 1) check(acc, e, row0);  // SEQ_RB: last block only
     };
     // The sample pass visits only a few tiles, so their DMA latencies would be paid one by one:
     // when all of them fit in LDS together they are fetched up front and consumed back to back.
@@ -386,7 +419,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             if constexpr (ONE_ACC) {
                 for (int i = 0; i < nt; ++i)
                     run_tile(accA, accA, i > 0, tile_row0(i - 1), tile_row0(i), i * TILE_BYTES);
-                if (!late) flush_last(accA);
+                flush_last(accA);
             } else {
                 run_tile(accA, accB, false, 0, 0, 0);
                 if (nt > 1) run_tile(accB, accA, true, tile_row0(0), 0, TILE_BYTES);
@@ -419,7 +452,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     };
     if constexpr (ONE_ACC) {
         for (int i = 0; i < nt; ++i) one_tile(accA, accA, i);
-        if (nt > 0 && !late) flush_last(accA);
+        if (nt > 0) flush_last(accA);
     } else {
         for (int i = 0; i < nt; i += 2) {
             one_tile(accA, accB, i);

@@ -20,6 +20,7 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--warmup", type=int, default=20)
 ap.add_argument("--c4-rows", type=int, default=0)
+ap.add_argument("--extra", default="", help="extra bench.py arguments, e.g. --no-verify")
 args = ap.parse_args()
 libs = args.libs.split(",")
 res = {l: [] for l in libs}
@@ -33,6 +34,7 @@ for r in range(args.rounds):
                "--no-cpu-baseline"]
         if args.c4_rows:
             cmd += ["--c4-rows", str(args.c4_rows)]
+        cmd += args.extra.split()
         p = subprocess.run(cmd, env=env, capture_output=True, text=True)
         line = [x for x in p.stdout.splitlines() if x.startswith("{")]
         if not line:

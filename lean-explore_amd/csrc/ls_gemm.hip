@@ -208,27 +208,22 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             goff[j] = r * CHUNKS + (sl ^ (r & 15));
         }
     }
-    auto stage = [&](int ti, int bufoff) {  // ti: tile index inside the slice; bufoff: LDS bytes
+    // piece j (0 .. LOADS-1) of tile ti -> the tile buffer at LDS byte offset bufoff
+    auto stage_piece = [&](int ti, int bufoff, int j) {
         const u32x4* base = corpus + (r_begin + (long long)ti * TM) * CHUNKS;
         int lane_v = lane;
         if constexpr (ONE_ACC || PAIRED) asm volatile("" : "+v"(lane_v));
         if constexpr (PAIRED) {
-#pragma unroll
-            for (int run = 0; run < 2; ++run) {
-                const int r0 = wave + 8 * run;            // logical rows r0 and r0 + 16, key r0
-                const int t = lane_v ^ r0;
-                const u32x4* rowp = base + r0 * CHUNKS;  // wave-uniform
-                unsigned char* dst = smem + bufoff + (2 * r0) * ROW_BYTES;
-                const int mid = lane_v < 32 ? 64 + t : 16 * CHUNKS + t - 32;
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + t), (lds_ptr_t)dst, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + mid), (lds_ptr_t)(dst + 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + 16 * CHUNKS + 32 + t),
-                                                 (lds_ptr_t)(dst + 2048), 16, 0, 0);
-            }
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < LOADS; ++j) {
+            const int run = j / 3, which = j % 3;
+            const int r0 = wave + 8 * run;            // logical rows r0 and r0 + 16, key r0
+            const int t = lane_v ^ r0;
+            const u32x4* rowp = base + r0 * CHUNKS;  // wave-uniform
+            unsigned char* dst = smem + bufoff + (2 * r0) * ROW_BYTES + which * 1024;
+            const int off = which == 0 ? t
+                          : which == 1 ? (lane_v < 32 ? 64 + t : 16 * CHUNKS + t - 32)
+                                       : 16 * CHUNKS + 32 + t;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + off), (lds_ptr_t)dst, 16, 0, 0);
+        } else {
             int off;
             if constexpr (ONE_ACC) {
                 const int Lc = (wave * LOADS + j) * 64 + lane_v;
@@ -240,6 +235,10 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             unsigned char* dst = smem + bufoff + (wave * LOADS + j) * 1024;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + off), (lds_ptr_t)dst, 16, 0, 0);
         }
+    };
+    auto stage = [&](int ti, int bufoff) {  // all pieces of tile ti, back to back
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) stage_piece(ti, bufoff, j);
     };
     // Hand-over between tiles: this wave's pieces of the NEXT tile have landed (`newer` = a
     // younger tile's LOADS pieces may still be in flight: loads return in order, so "<= LOADS
@@ -335,8 +334,12 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // One set, one query group (2 KiB rows): a single chain per row block would stall on its own
     // MFMA latency, so all blocks advance together and the filter runs before the k-loop.
     constexpr bool SEQ_RB = ONE_ACC && QG == 2 && LS_GEMM_SEQ_RB;
+    // SEQ_RB also spreads the DMA pieces of the tile that is fetched next over the first row
+    // block's k-steps (one piece every other k-step) instead of issuing all of them right behind
+    // the barrier, where both waves of a SIMD would do so at once with the matrix pipe idle.
     auto run_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], bool have_prev,
-                        int prev_row0, int cur_row0, int bufoff) {
+                        int prev_row0, int cur_row0, int bufoff, bool stage_more = false,
+                        int stage_ti = 0, int stage_buf = 0) {
         if constexpr (SEQ_RB) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
@@ -364,6 +367,8 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                         for (int e = 0; e < QG * 4; ++e)
                             if ((e * KS) / (QG * 4) == kk) check1(cur[pb][e / 4][e % 4], e / 4, prow0 + e % 4);
                     }
+                    if (LS_GEMM_SPREAD_DMA && rb == 0 && (kk & 1) && kk / 2 < LOADS && stage_more)
+                        stage_piece(stage_ti, stage_buf, kk / 2);
                 }
             }
             return;
@@ -442,8 +447,10 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     auto advance = [&](int& b) { b = b + TILE_BYTES == NBUF * TILE_BYTES ? 0 : b + TILE_BYTES; };
     auto one_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], int i) {
         const bool more = i + AHEAD < nt;
-        if (more) stage((i + AHEAD) * tile_stride, b_new);
-        run_tile(cur, prev, i > 0, tile_row0(i - 1), tile_row0(i), b_cur);
+        constexpr bool spread = SEQ_RB && LS_GEMM_SPREAD_DMA && 2 * LOADS <= KS;
+        if (more && !spread) stage((i + AHEAD) * tile_stride, b_new);
+        run_tile(cur, prev, i > 0, tile_row0(i - 1), tile_row0(i), b_cur, more && spread,
+                 (i + AHEAD) * tile_stride, b_new);
         // tile i+1 must be complete before anyone reads it. NBUF == 3: only when a younger tile
         // was requested in this iteration may LOADS pieces stay in flight.
         hand_over(NBUF == 3 && more);

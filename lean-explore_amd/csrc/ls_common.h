@@ -46,12 +46,6 @@ typedef unsigned int u32;
 #ifndef LS_GEMM_QG2_MAX_CHUNKS
 #define LS_GEMM_QG2_MAX_CHUNKS 96    // stored rows up to this many chunks: 2 query groups per wave
 #endif
-#ifndef LS_GEMM_SEQ_RB
-#define LS_GEMM_SEQ_RB 1             // one accumulator set: row blocks in sequence, filter hidden in the next block's MFMAs
-#endif
-#ifndef LS_GEMM_SPREAD_DMA
-#define LS_GEMM_SPREAD_DMA 1         // SEQ_RB: the next tile's DMA pieces are issued between the first block's k-steps
-#endif
 #ifndef LS_GEMM_RING3
 #define LS_GEMM_RING3 0              // 1: three tile buffers, DMA two tiles ahead (measured 1-2 % slower than two)
 #endif

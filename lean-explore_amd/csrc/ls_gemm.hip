@@ -251,6 +251,20 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    // The hand-over in front of the first tile drains everything (vmcnt(0)). Tried and removed:
+    // waiting only for the DMA ("at most QG*KS+QG younger loads outstanding") so that the first
+    // tile starts while the query fragments stream in. It gained 0.3 % and was WRONG once the
+    // compiler sank some fragment loads below the wait (they come from const __restrict__ memory,
+    // an asm memory clobber does not pin them): fewer younger loads than counted, the wait passes
+    // with DMA pieces still in flight, the first tile is read stale (caught by tests/test_fuzz_gpu.py
+    // on two of three seeds). A counted vmcnt is only sound where this file issues every
+    // vector-memory operation in between itself.
+    auto first_hand_over = [&]() {
+        asm volatile("" ::: "memory");
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
 
     // The first tile(s) are requested BEFORE the query fragments: the HBM round trip of tile 0
     // then overlaps the (L2-resident) query loads instead of queueing behind them.
@@ -264,20 +278,22 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
         stage(tile_stride, TILE_BYTES);
     }
 
-    // B fragments: group qg holds query qt*8*QPW + wave*QPW + qg*16 + li; k-step kk -> chunk 4kk+qd
+    // B fragments: group qg holds query qt*8*QPW + wave*QPW + qg*16 + li; k-step kk -> chunk 4kk+qd.
     half8 bq[QG][KS];
     int qj[QG];
     float tauv[QG];
+    const u32x4* qfrag[QG];
 #pragma unroll
     for (int g2 = 0; g2 < QG; ++g2) {
         qj[g2] = (qt * LS_GEMM_WAVES + wave) * QPW + g2 * 16 + li;
         // fragment-ordered by ls_prep_f16_kernel: each load below is one contiguous KiB per wave
-        const u32x4* qfrag = qh + ((((long long)(qt * LS_GEMM_WAVES + wave) * QG + g2) * KS) << 6) + lane;
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) bq[g2][kk] = __builtin_bit_cast(half8, qfrag[kk << 6]);
+        qfrag[g2] = qh + ((((long long)(qt * LS_GEMM_WAVES + wave) * QG + g2) * KS) << 6) + lane;
         tauv[g2] = SAMPLE ? 0.0f : tau[qj[g2]];
     }
-
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int g2 = 0; g2 < QG; ++g2) bq[g2][kk] = __builtin_bit_cast(half8, qfrag[g2][kk << 6]);
     // private queues of this lane (one per query group), contiguous per lane
     // entry = {score bits, row relative to the slice}; the select kernel turns it into a key
     uint2* myq[QG];
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // the MFMA stream again without a second accumulator set.
     // One set, one query group (2 KiB rows): a single chain per row block would stall on its own
     // MFMA latency, so all blocks advance together and the filter runs before the k-loop.
-    constexpr bool SEQ_RB = ONE_ACC && QG == 2 && LS_GEMM_SEQ_RB;
+    constexpr bool SEQ_RB = ONE_ACC && QG == 2;
     // SEQ_RB also spreads the DMA pieces of the tile that is fetched next over the first row
     // block's k-steps (one piece every other k-step) instead of issuing all of them right behind
     // the barrier, where both waves of a SIMD would do so at once with the matrix pipe idle.
@@ -367,7 +383,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                         for (int e = 0; e < QG * 4; ++e)
                             if ((e * KS) / (QG * 4) == kk) check1(cur[pb][e / 4][e % 4], e / 4, prow0 + e % 4);
                     }
-                    if (LS_GEMM_SPREAD_DMA && rb == 0 && (kk & 1) && kk / 2 < LOADS && stage_more)
+                    if (rb == 0 && (kk & 1) && kk / 2 < LOADS && stage_more)
                         stage_piece(stage_ti, stage_buf, kk / 2);
                 }
             }
@@ -405,6 +421,8 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                 for (int c2 = 0; c2 < CPK; ++c2)
                     if (kk * CPK + c2 < NV) check(prev, kk * CPK + c2, prev_row0);
             }
+            if (!SEQ_RB && kk < LOADS && stage_more)
+                stage_piece(stage_ti, stage_buf, kk);
         }
     };
 
@@ -420,7 +438,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // when all of them fit in LDS together they are fetched up front and consumed back to back.
     if constexpr (SAMPLE) {
         if (sample_upfront) {
-            __syncthreads();
+            first_hand_over();
             if constexpr (ONE_ACC) {
                 for (int i = 0; i < nt; ++i)
                     run_tile(accA, accA, i > 0, tile_row0(i - 1), tile_row0(i), i * TILE_BYTES);
@@ -441,13 +459,15 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // ---- the tile loop. Ring of NBUF buffers; tile i sits in buffer i % NBUF. With three
     // buffers tile i+2 is requested at the top of tile i (its buffer was last read during tile
     // i-1, which every wave has left through the barrier); with two, tile i+1.
-    hand_over(NBUF == 3 && nt > 1);
+    first_hand_over();
     constexpr int AHEAD = NBUF - 1;
     int b_cur = 0, b_new = AHEAD * TILE_BYTES;  // LDS byte offsets of tile i and of tile i + AHEAD
     auto advance = [&](int& b) { b = b + TILE_BYTES == NBUF * TILE_BYTES ? 0 : b + TILE_BYTES; };
     auto one_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], int i) {
         const bool more = i + AHEAD < nt;
-        constexpr bool spread = SEQ_RB && LS_GEMM_SPREAD_DMA && 2 * LOADS <= KS;
+        // the next tile's DMA pieces are issued between this tile's k-steps (run_tile), not in
+        // one burst behind the barrier
+        constexpr bool spread = (SEQ_RB && 2 * LOADS <= KS) || (!SEQ_RB && !SAMPLE && LOADS <= KS);
         if (more && !spread) stage((i + AHEAD) * tile_stride, b_new);
         run_tile(cur, prev, i > 0, tile_row0(i - 1), tile_row0(i), b_cur, more && spread,
                  (i + AHEAD) * tile_stride, b_new);

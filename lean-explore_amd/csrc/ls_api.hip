@@ -603,10 +603,39 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     // LS_GEMM_SAMPLE_ROWS rows; ~1/48 for slices of more than 1536 tiles, where the sample pass
     // itself is what costs): the expected number of rows passing tau, ~j*N/M0, then does not
     // grow with N
-    const int frac = tiles_per_split > 1536 ? 48 : 24;
-    const int sample_tiles = std::max(std::max(1, LS_GEMM_SAMPLE_ROWS / TM),
-                                      (tiles_per_split + frac - 1) / frac);
-    const int sample_stride = std::max(1, (tiles_per_split + sample_tiles - 1) / sample_tiles);
+    // The fraction thins out on long slices (about 16 tiles per slice up to 1/96 of the rows:
+    // config 4's 12.5 M-row shard spent 7 % of its batch in a 1/24 sample): a thinner sample
+    // passes more rows per query (~j*N/M0 +- that over sqrt(j)), which the select kernel's key
+    // buffer must hold; the fraction is halved until the +5 sigma count fits LS_BSEL_MAX_KEYS.
+    int frac = std::max(24, std::min(96, tiles_per_split / 16));
+    int sample_tiles, sample_stride, jrank, keys_need;
+    for (;; frac /= 2) {
+        sample_tiles = std::max(std::max(1, LS_GEMM_SAMPLE_ROWS / TM),
+                                (tiles_per_split + frac - 1) / frac);
+        sample_stride = std::max(1, (tiles_per_split + sample_tiles - 1) / sample_tiles);
+        // Speculative threshold. The k-th best SAMPLE score is a certified lower bound of the
+        // final k-th best but passes ~k*N/M0 rows per query. The j-th best sample score (j < k)
+        // passes only ~j*N/M0 rows; it is not certified, so the select kernel verifies that at
+        // least k rows passed and flags the query for the exact scan path otherwise. j is the
+        // smallest rank whose expected pass count exceeds k by 4.5 standard deviations (relative
+        // sd of an order statistic ~ 1/sqrt(j)): a flag is a ~1e-5 event per query on
+        // exchangeable rows.
+        jrank = k;
+        const int visited = (tiles_per_split + sample_stride - 1) / sample_stride;
+        const double m0 = (double)nsplits * visited * TM;
+        const double r = (double)ix->n / std::max(1.0, m0);
+        if (ix->opt_spec_tau) {
+            for (int j = 1; j <= k; ++j) {
+                if ((double)j * r * (1.0 - 4.5 / __builtin_sqrt((double)j)) >= (double)k) {
+                    jrank = j;
+                    break;
+                }
+            }
+        }
+        const double expect = (double)jrank * r * (1.0 + 5.0 / __builtin_sqrt((double)jrank));
+        keys_need = (int)std::min(expect, 1e9);
+        if (keys_need <= LS_BSEL_MAX_KEYS || frac <= 24) break;
+    }
     const size_t nrec = (size_t)nq_pad * nsplits;
 
     size_t c;
@@ -664,24 +693,6 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     // sample pass: a few tiles of every slice, spread over the slice
     rc = pass(nullptr, sample_stride);
     if (rc != LS_OK) return rc;
-    // Speculative threshold. The k-th best SAMPLE score is a certified lower bound of the final
-    // k-th best but passes ~k*N/M0 rows per query. The j-th best sample score (j < k) passes only
-    // ~j*N/M0 rows; it is not certified, so the select kernel verifies that at least k rows
-    // passed and flags the query for the exact scan path otherwise. j is the smallest rank whose
-    // expected pass count exceeds k by 4.5 standard deviations (relative sd of an order
-    // statistic ~ 1/sqrt(j)): a flag is a ~1e-5 event per query on exchangeable rows.
-    int jrank = k;
-    if (ix->opt_spec_tau) {
-        const int visited = (tiles_per_split + sample_stride - 1) / sample_stride;
-        const double m0 = (double)nsplits * visited * TM;
-        const double r = (double)ix->n / std::max(1.0, m0);
-        for (int j = 1; j <= k; ++j) {
-            if ((double)j * r * (1.0 - 4.5 / __builtin_sqrt((double)j)) >= (double)k) {
-                jrank = j;
-                break;
-            }
-        }
-    }
     rc = ls_launch_tau(ix->d_sample_top, nsplits, nq, nq_pad, jrank, ix->d_tau, s);
     if (rc != LS_OK) return rc;
     // full pass
@@ -692,7 +703,8 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         LS_HIP(hipEventRecord(pe[1], s));
         ix->prof_n++;
     }
-    rc = ls_launch_batch_select(bufs, nsplits, nq, k, ix->base, ix->n, rps, d_out_s, d_out_i, s);
+    rc = ls_launch_batch_select(bufs, nsplits, nq, k, keys_need, ix->base, ix->n, rps, d_out_s, d_out_i,
+                                s);
     if (rc != LS_OK) return rc;
     if (ix->bc_multi_stream) LS_HIP(hipEventRecord(ix->bc_done, s));
     ix->bc_used = true;

@@ -36,7 +36,7 @@ typedef unsigned int u32;
 #ifndef LS_GEMM_TM_SHORT
 #define LS_GEMM_TM_SHORT 64          // corpus rows per LDS tile for stored rows <= 1 KiB
 #endif
-#define LS_GEMM_WG_PER_CU (8 / LS_GEMM_WAVES)
+#define LS_GEMM_WG_PER_CU 1          // the tile ring takes most of the LDS: one workgroup per CU
 #define LS_GEMM_MAX_K 1024           // batched path handles k <= this (the reference uses 1000)
 #define LS_GEMM_MAX_CHUNKS 128       // ... and stored rows <= 2 KiB (d <= 1024 fp16)
 #define LS_GEMM_MIN_ROWS 32768       // ... and shards at least this big,
@@ -45,6 +45,12 @@ typedef unsigned int u32;
 #define LS_GEMM_QCAP 32              // entries per private candidate queue (a multiple of 4)
 #ifndef LS_GEMM_QG2_MAX_CHUNKS
 #define LS_GEMM_QG2_MAX_CHUNKS 96    // stored rows up to this many chunks: 2 query groups per wave
+#endif
+#ifndef LS_GEMM_PF
+#define LS_GEMM_PF 3                 // row-blocks-in-sequence loop: A-fragment look-ahead in k-steps
+#endif
+#ifndef LS_GEMM_STRAIGHT
+#define LS_GEMM_STRAIGHT 1           // tile loop without previous-/next-tile branches
 #endif
 #ifndef LS_GEMM_RING3
 #define LS_GEMM_RING3 0              // 1: three tile buffers, DMA two tiles ahead (measured 1-2 % slower than two)
@@ -202,7 +208,9 @@ int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_p
                   float* d_tau, hipStream_t s);
 int ls_gemm_qg(const ls_geom& g);         // query groups of 16 per wave (2, or 1 for 2 KiB rows)
 int ls_gemm_tile_rows(const ls_geom& g);  // corpus rows per LDS tile (64, or 32 for long rows)
-int ls_launch_batch_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k, int64_t base,
+#define LS_BSEL_MAX_KEYS 8192         // candidate keys per query the select kernel can hold in LDS
+int ls_launch_batch_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k, int keys_need,
+                           int64_t base,
                            int64_t n, int64_t rows_per_split, float* d_out_scores,
                            int64_t* d_out_indices, hipStream_t s);
 // fp32 batched path (ls_gemm32.hip): exact f32 MFMA, shares tau / select with the fp16 path

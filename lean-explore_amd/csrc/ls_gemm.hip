@@ -195,7 +195,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // runs of three whole pieces, and since both rows of a run share the swizzle key r & 15 every
     // source offset is  run base (scalar) + (lane ^ key) + constant : ~12 VALU per tile instead
     // of ~55 for the generic divide-by-row-length form. PAIRED changes a_frag's row stride too.
-    constexpr bool PAIRED = CHUNKS == 96 && TM == 32 && LS_GEMM_WAVES == 8;
+    constexpr bool PAIRED = CHUNKS == 96 && TM == 32 && 16 % LS_GEMM_WAVES == 0;
     // Other register-starved instantiations (ONE_ACC) recompute the generic per-lane offsets for
     // every tile behind an opaque copy of the lane id: hoisted out of the tile loop they would be
     // spilled and every reload would wait on the memory pipe.
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
         if constexpr (ONE_ACC || PAIRED) asm volatile("" : "+v"(lane_v));
         if constexpr (PAIRED) {
             const int run = j / 3, which = j % 3;
-            const int r0 = wave + 8 * run;            // logical rows r0 and r0 + 16, key r0
+            const int r0 = wave + LS_GEMM_WAVES * run;  // logical rows r0 and r0 + 16, key r0
             const int t = lane_v ^ r0;
             const u32x4* rowp = base + r0 * CHUNKS;  // wave-uniform
             unsigned char* dst = smem + bufoff + (2 * r0) * ROW_BYTES + which * 1024;
@@ -330,7 +330,8 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             top4_insert(top[g2], (qj[g2] < nq && r_begin + lrow < r_end) ? s : -FLT_MAX);
         } else if (s >= tauv[g2]) {
             const int slot = cnt[g2] < cap ? cnt[g2] : cap - 1;
-            myq[g2][slot] = make_uint2(__float_as_uint(s), (u32)lrow);
+            uint2* qp = ONE_ACC ? out.queues + queue_id(qj[g2], split, qd, nsplits) * cap : myq[g2];
+            qp[slot] = make_uint2(__float_as_uint(s), (u32)lrow);
             ++cnt[g2];
         }
     };
@@ -362,11 +363,13 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                 const int pb = rb == 0 ? NRB - 1 : rb - 1;  // block whose scores are filtered now
                 const bool have = rb == 0 ? have_prev : true;
                 const int prow0 = (rb == 0 ? prev_row0 : cur_row0) + pb * 16;
-                half8 a[2];
-                a[0] = a_frag(bufoff, rb, 0);
+                constexpr int PF = LS_GEMM_PF, NA = PF + 1;  // A fragments are read PF k-steps ahead
+                half8 a[NA];
+#pragma unroll
+                for (int p0 = 0; p0 < PF; ++p0) a[p0] = a_frag(bufoff, rb, p0);
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk) {
-                    if (kk + 1 < KS) a[(kk + 1) & 1] = a_frag(bufoff, rb, kk + 1);
+                    if (kk + PF < KS) a[(kk + PF) % NA] = a_frag(bufoff, rb, kk + PF);
 #pragma unroll
                     for (int g2 = 0; g2 < QG; ++g2) {
                         f32x4v c;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                         } else {
                             c = cur[rb][g2];
                         }
-                        cur[rb][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk & 1], bq[g2][kk], c,
+                        cur[rb][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk % NA], bq[g2][kk], c,
                                                                             0, 0, 0);
                     }
                     if (have) {
@@ -383,8 +386,9 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                         for (int e = 0; e < QG * 4; ++e)
                             if ((e * KS) / (QG * 4) == kk) check1(cur[pb][e / 4][e % 4], e / 4, prow0 + e % 4);
                     }
-                    if (rb == 0 && (kk & 1) && kk / 2 < LOADS && stage_more)
-                        stage_piece(stage_ti, stage_buf, kk / 2);
+                    constexpr int SD = 2 * LOADS <= KS ? 2 : 1;  // a piece every SD-th k-step
+                    if (rb == 0 && kk % SD == SD - 1 && kk / SD < LOADS && stage_more)
+                        stage_piece(stage_ti, stage_buf, kk / SD);
                 }
             }
             return;
@@ -427,6 +431,20 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     };
 
     f32x4v accA[NRB][QG], accB[NRB][QG];  // two sets alternate between tiles (ONE_ACC: accA only)
+#if LS_GEMM_STRAIGHT
+    // The tile loop carries no "is there a previous tile" / "is there a next tile" branches (they
+    // cut the loop body into basic blocks the scheduler cannot move MFMAs across): the
+    // accumulators start at -inf, which passes no threshold (tau >= -FLT_MAX) and leaves a
+    // top-4 list unchanged, so the first tile may filter them like a real previous tile; and
+    // the full pass always requests the next tile, past the slice end too (the next slice's
+    // rows or the zero pad rows, LS_CORPUS_PAD_ROWS >= 2 tiles: fetched, never read).
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int g2 = 0; g2 < QG; ++g2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accA[rb][g2][e] = accB[rb][g2][e] = -INFINITY;
+#endif
     auto tile_row0 = [&](int i) { return (i * tile_stride) * TM + 4 * qd; };  // slice-relative
     auto flush_last = [&](const f32x4v (&acc)[NRB][QG]) {  // the last tile still has to be filtered
         const int row0 = tile_row0(nt - 1);
@@ -464,12 +482,13 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     int b_cur = 0, b_new = AHEAD * TILE_BYTES;  // LDS byte offsets of tile i and of tile i + AHEAD
     auto advance = [&](int& b) { b = b + TILE_BYTES == NBUF * TILE_BYTES ? 0 : b + TILE_BYTES; };
     auto one_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], int i) {
-        const bool more = i + AHEAD < nt;
+        constexpr bool always = LS_GEMM_STRAIGHT && !SAMPLE && (AHEAD + 1) * TM <= LS_CORPUS_PAD_ROWS;
+        const bool more = always ? true : i + AHEAD < nt;
         // the next tile's DMA pieces are issued between this tile's k-steps (run_tile), not in
         // one burst behind the barrier
-        constexpr bool spread = (SEQ_RB && 2 * LOADS <= KS) || (!SEQ_RB && !SAMPLE && LOADS <= KS);
+        constexpr bool spread = (SEQ_RB || !SAMPLE) && LOADS <= KS;
         if (more && !spread) stage((i + AHEAD) * tile_stride, b_new);
-        run_tile(cur, prev, i > 0, tile_row0(i - 1), tile_row0(i), b_cur, more && spread,
+        run_tile(cur, prev, LS_GEMM_STRAIGHT ? true : i > 0, tile_row0(i - 1), tile_row0(i), b_cur, more && spread,
                  (i + AHEAD) * tile_stride, b_new);
         // tile i+1 must be complete before anyone reads it. NBUF == 3: only when a younger tile
         // was requested in this iteration may LOADS pieces stay in flight.
@@ -713,16 +732,18 @@ __global__ __launch_bounds__(256) void ls_batch_select_kernel(
     }
 }
 
-int ls_launch_batch_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k, int64_t base,
+int ls_launch_batch_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k, int keys_need,
+                           int64_t base,
                            int64_t n, int64_t rows_per_split, float* d_out_scores,
                            int64_t* d_out_indices, hipStream_t s) {
     if (k > LS_GEMM_MAX_K || nsplits > LS_GEMM_MAX_SPLITS) {
         ls_set_error("batched path: k > %d or too many slices", LS_GEMM_MAX_K);
         return LS_ERR_INVALID_ARG;
     }
-    // candidates per query average ~2-5 k (the threshold's safety margin): room for 4 k, >= 2048
+    // candidates per query: the caller's +5 sigma estimate for its sample (~2-5 k for a 1/16
+    // sample, more for the thinner samples of long slices); at least 4 k and 2048
     int keys_cap = 2048;
-    while (keys_cap < 4 * k) keys_cap <<= 1;
+    while (keys_cap < 4 * k || (keys_cap < keys_need && keys_cap < LS_BSEL_MAX_KEYS)) keys_cap <<= 1;
     int res_cap = 256;
     while (res_cap < k) res_cap <<= 1;
     const size_t smem = ((size_t)keys_cap + 2 * (size_t)res_cap) * sizeof(u64) +

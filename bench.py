@@ -257,9 +257,11 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         index.force_exchange = True
         sharded_pipe, pipelined = nq <= 16, False
 
-    # 1 GPU, large batches (MFMA path): calls are queued asynchronously; the verification flags of
-    # up to 16 outstanding batches are checked (and flagged queries repaired) by local.check()
-    # inside the timed region, instead of one host round trip per batch
+    # 1 GPU, large batches (MFMA path): calls are queued on the index's two internal lanes
+    # (LS_FLAG_PIPELINE: consecutive batches alternate between two streams, so one batch's small
+    # kernels overlap the other's MFMA pass); the verification flags of up to 16 outstanding
+    # batches are checked (and flagged queries repaired) by local.check() inside the timed
+    # region, instead of one host round trip per batch
     batched_async = world == 1 and not pipelined and not env.rehearse
 
     def step():
@@ -268,7 +270,7 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         if pipelined:
             return local.search_device(tq, k, o[0], o[1], pipeline=True)
         if batched_async:
-            return local.search_device(tq, k, o[0], o[1], asynchronous=True)
+            return local.search_device(tq, k, o[0], o[1], pipeline=True)
         if sharded_pipe:
             return index.search_device_pipelined(tq, k, exchange_every=EXCHANGE_EVERY)
         return index.search_device(tq, k)

@@ -54,9 +54,12 @@ extern "C" {
 #define LS_FLAG_ASYNC 2u     /* ls_search_device only: queue and return; results are ordered  */
                              /* on `stream` like any other work queued there                  */
 #define LS_FLAG_PIPELINE 4u  /* ls_search_device only: queue on the index's internal lanes so */
-                             /* that consecutive calls overlap (the selection step of one     */
-                             /* query runs under the scan of the next); results are NOT       */
-                             /* ordered on `stream` - they are valid after ls_check()         */
+                             /* that consecutive calls overlap (scan path: the selection step */
+                             /* of one query runs under the scan of the next; batched MFMA    */
+                             /* path: consecutive batches alternate between two internal      */
+                             /* streams with their own scratch, behind whatever `stream` has  */
+                             /* queued so far); results are NOT ordered on `stream` - they    */
+                             /* are valid after ls_check()                                    */
 
 #define LS_MAX_K 2048 /* same ceiling as FAISS's GPU k-selection; reference uses k = 1000     */
 

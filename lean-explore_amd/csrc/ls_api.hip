@@ -19,6 +19,10 @@
 
 #define LS_NSETS 2
 #define LS_BC_SLOTS 16
+#ifndef LS_BC_LANES
+#define LS_BC_LANES 2  // internal streams (with their own scratch) that LS_FLAG_PIPELINE batches rotate over
+#endif
+#define LS_BC_SETS (1 + LS_BC_LANES)  // batched scratch sets: 0 = caller's stream, then the lanes
 #define LS_PROF_MAX 4096
 
 static thread_local char g_err[512] = "";
@@ -54,22 +58,33 @@ struct ls_index {
     bool scan_used = false;
     uint64_t set_rr = 0;
     int32_t last_set = 0;
-    // batched (MFMA) path scratch, allocated on first use. ONE set per handle. A handle that only
-    // ever sees one stream pays nothing for that; the first call on a second stream synchronises
-    // the previous one and switches the handle to multi-stream mode, where `bc_done` is recorded
-    // behind the last kernel of every call and waited for by the next call's stream (an event
-    // record costs a few us of GPU time per batch: a barrier packet with a release).
-    void* d_qh = nullptr;      size_t qh_cap = 0;       // bytes: fp16 queries [nq_pad, d_pad]
-    u64* d_queues = nullptr;   size_t queues_cap = 0;   // private candidate queues
-    u32* d_counts = nullptr;   size_t counts_cap = 0;
-    float* d_tau = nullptr;    size_t tau_cap = 0;
+    // batched (MFMA) path scratch, allocated on first use. Set 0 serves plain calls on the
+    // caller's stream: a handle that only ever sees one stream pays nothing for sharing it; the
+    // first call on a second stream synchronises the previous one and switches the set to
+    // multi-stream mode, where `done` is recorded behind the last kernel of every call and
+    // waited for by the next call's stream (an event record costs a few us of GPU time per
+    // batch: a barrier packet with a release). Sets 1 .. LS_BC_LANES are the internal LANES of
+    // LS_FLAG_PIPELINE calls: consecutive batches rotate over them, each lane on its own
+    // stream, so that one batch's latency-bound small kernels (prep, tau, select) and kernel
+    // boundaries overlap the other batch's MFMA pass.
+    struct bc_set {
+        void* d_qh = nullptr;      size_t qh_cap = 0;       // bytes: fp16 queries [nq_pad, d_pad]
+        u64* d_queues = nullptr;   size_t queues_cap = 0;   // private candidate queues
+        u32* d_counts = nullptr;   size_t counts_cap = 0;
+        float* d_tau = nullptr;    size_t tau_cap = 0;
+        u32* d_sample_top = nullptr; size_t sample_top_cap = 0;  // best sample scores per lane
+        hipEvent_t done = nullptr;        // set 0, multi-stream mode
+        hipStream_t last_stream = nullptr;
+        bool used = false;
+        bool multi_stream = false;
+        hipStream_t lane_stream = nullptr;  // sets 1 .. LS_BC_LANES
+        hipEvent_t lane_in = nullptr;       // recorded on the caller's stream, waited for by the lane
+        hipEvent_t lane_q = nullptr;        // the lane has consumed the caller's query buffer
+    } bc_sets[LS_BC_SETS];
+    uint64_t bc_lane_rr = 0;
+    int32_t bc_last_set = 0;  // the set of the most recent batched call (ls_export_flags)
     u32* d_overflow = nullptr; size_t overflow_cap = 0;
-    u32* d_sample_top = nullptr; size_t sample_top_cap = 0;  // 4 best sample scores per lane
     u32* h_overflow = nullptr; size_t h_overflow_cap = 0;  // pinned
-    hipEvent_t bc_done = nullptr;
-    hipStream_t bc_last_stream = nullptr;
-    bool bc_used = false;
-    bool bc_multi_stream = false;
     // async batched calls not yet checked: each keeps its own flag slice of d_overflow AND its own
     // copy of the raw queries (d_qkeep), so that several batches can be in flight before one
     // ls_check repairs whatever was flagged, whatever the caller did to its query buffer meanwhile
@@ -292,14 +307,22 @@ void ls_destroy(ls_index* ix) {
     (void)hipFree(ix->d_out_i);
     (void)hipFree(ix->d_counters);
     (void)hipFree(ix->d_qpad);
-    (void)hipFree(ix->d_qh);
-    (void)hipFree(ix->d_queues);
-    (void)hipFree(ix->d_counts);
+    for (auto& st : ix->bc_sets) {
+        if (st.lane_stream) {
+            (void)hipStreamSynchronize(st.lane_stream);
+            (void)hipStreamDestroy(st.lane_stream);
+        }
+        if (st.lane_in) (void)hipEventDestroy(st.lane_in);
+        if (st.lane_q) (void)hipEventDestroy(st.lane_q);
+        if (st.done) (void)hipEventDestroy(st.done);
+        (void)hipFree(st.d_qh);
+        (void)hipFree(st.d_queues);
+        (void)hipFree(st.d_counts);
+        (void)hipFree(st.d_tau);
+        (void)hipFree(st.d_sample_top);
+    }
     (void)hipFree(ix->d_qkeep);
-    if (ix->bc_done) (void)hipEventDestroy(ix->bc_done);
-    (void)hipFree(ix->d_tau);
     (void)hipFree(ix->d_overflow);
-    (void)hipFree(ix->d_sample_top);
     if (ix->h_overflow) (void)hipHostFree(ix->h_overflow);
     if (ix->h_q) (void)hipHostFree(ix->h_q);
     if (ix->h_done) (void)hipHostFree(ix->h_done);
@@ -580,14 +603,28 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         rc = batched_repair(ix);  // slots exhausted (or too small): check what is pending
         if (rc != LS_OK) return rc;
     }
-    // One scratch set per handle: a call on another stream waits for the previous call's kernels.
-    if (ix->bc_used && ix->bc_last_stream != s) {
-        if (!ix->bc_multi_stream) {
-            LS_HIP(hipStreamSynchronize(ix->bc_last_stream));  // once: no event was recorded yet
-            LS_HIP(hipEventCreateWithFlags(&ix->bc_done, hipEventDisableTiming));
-            ix->bc_multi_stream = true;
+    const bool lanes = (flags & LS_FLAG_PIPELINE) != 0;
+    const int set_id = lanes ? 1 + (int)(ix->bc_lane_rr++ % LS_BC_LANES) : 0;
+    ls_index::bc_set& st = ix->bc_sets[set_id];
+    hipStream_t const caller = s;
+    if (lanes) {
+        // the lane's kernels run behind everything the caller has queued so far (its queries)
+        if (!st.lane_stream) {
+            LS_HIP(hipStreamCreateWithFlags(&st.lane_stream, hipStreamNonBlocking));
+            LS_HIP(hipEventCreateWithFlags(&st.lane_in, hipEventDisableTiming));
+            LS_HIP(hipEventCreateWithFlags(&st.lane_q, hipEventDisableTiming));
+        }
+        LS_HIP(hipEventRecord(st.lane_in, caller));
+        LS_HIP(hipStreamWaitEvent(st.lane_stream, st.lane_in, 0));
+        s = st.lane_stream;
+    } else if (st.used && st.last_stream != s) {
+        // set 0 is shared by plain calls: a call on another stream waits for the previous one
+        if (!st.multi_stream) {
+            LS_HIP(hipStreamSynchronize(st.last_stream));  // once: no event was recorded yet
+            LS_HIP(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+            st.multi_stream = true;
         } else {
-            LS_HIP(hipStreamWaitEvent(s, ix->bc_done, 0));
+            LS_HIP(hipStreamWaitEvent(s, st.done, 0));
         }
     }
     const int nqt = (int)(nq_pad / QT);
@@ -639,13 +676,13 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     const size_t nrec = (size_t)nq_pad * nsplits;
 
     size_t c;
-    c = ix->qh_cap;
-    if ((rc = grow((unsigned char**)&ix->d_qh, &c, (size_t)nq_pad * g.d_pad * (f32 ? 4 : 2))) != LS_OK)
+    c = st.qh_cap;
+    if ((rc = grow((unsigned char**)&st.d_qh, &c, (size_t)nq_pad * g.d_pad * (f32 ? 4 : 2))) != LS_OK)
         return rc;
-    ix->qh_cap = c;
-    if ((rc = grow(&ix->d_queues, &ix->queues_cap, nrec * 4 * LS_GEMM_QCAP)) != LS_OK) return rc;
-    if ((rc = grow(&ix->d_counts, &ix->counts_cap, nrec * 4)) != LS_OK) return rc;
-    if ((rc = grow(&ix->d_tau, &ix->tau_cap, (size_t)nq_pad)) != LS_OK) return rc;
+    st.qh_cap = c;
+    if ((rc = grow(&st.d_queues, &st.queues_cap, nrec * 4 * LS_GEMM_QCAP)) != LS_OK) return rc;
+    if ((rc = grow(&st.d_counts, &st.counts_cap, nrec * 4)) != LS_OK) return rc;
+    if ((rc = grow(&st.d_tau, &st.tau_cap, (size_t)nq_pad)) != LS_OK) return rc;
     if (ix->bc_pending.empty()) {
         if (nq_pad > ix->bc_slot_stride) ix->bc_slot_stride = nq_pad;
         if (qkeep_need > ix->bc_qkeep_stride) ix->bc_qkeep_stride = qkeep_need;
@@ -659,15 +696,15 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     const int slot = (int)ix->bc_pending.size();
     u32* d_flags = ix->d_overflow + (size_t)slot * ix->bc_slot_stride;
     float* d_qkeep = ix->d_qkeep + (size_t)slot * ix->bc_qkeep_stride;
-    if ((rc = grow(&ix->d_sample_top, &ix->sample_top_cap, nrec * 16)) != LS_OK) return rc;
+    if ((rc = grow(&st.d_sample_top, &st.sample_top_cap, nrec * 16)) != LS_OK) return rc;
     if ((rc = grow_pinned(&ix->h_overflow, &ix->h_overflow_cap,
                           (size_t)ix->bc_slot_stride * LS_BC_SLOTS)) != LS_OK)
         return rc;
     ls_gemm_bufs bufs;
-    bufs.d_queues = ix->d_queues;
-    bufs.d_counts = ix->d_counts;
+    bufs.d_queues = st.d_queues;
+    bufs.d_counts = st.d_counts;
     bufs.d_overflow = d_flags;
-    bufs.d_sample_top = ix->d_sample_top;
+    bufs.d_sample_top = st.d_sample_top;
 
     const bool prof = ix->profiling && ix->prof_n < LS_PROF_MAX;
     hipEvent_t* pe = nullptr;
@@ -679,25 +716,34 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         }
         pe = &ix->prof_ev[2 * ix->prof_n];
     }
+    // two kept sample scores per lane are enough when a query has >= 4 j lanes (two of its best
+    // j sample scores then share a lane with probability ~1/8 each)
+    const bool top2 = LS_GEMM_SAMPLE_TOP2 && (long long)nsplits * 4 >= 4ll * jrank;
     auto pass = [&](const float* tau, int stride) {  // sample pass (tau == null) or full pass
-        return f32 ? ls_launch_gemm32_filter(ix->d_corpus, ix->n, g, (const float*)ix->d_qh, nq,
+        return f32 ? ls_launch_gemm32_filter(ix->d_corpus, ix->n, g, (const float*)st.d_qh, nq,
                                              nq_pad, tau, nsplits, rps, stride, bufs, s)
-                   : ls_launch_gemm_filter(ix->d_corpus, ix->n, g, ix->d_qh, nq, nq_pad, tau,
-                                           nsplits, rps, stride, bufs, s);
+                   : ls_launch_gemm_filter(ix->d_corpus, ix->n, g, st.d_qh, nq, nq_pad, tau,
+                                           nsplits, rps, stride, bufs, top2, s);
     };
-    rc = f32 ? ls_launch_prep_f32(d_q, (float*)ix->d_qh, d_qkeep, nq, nq_pad, g,
+    rc = f32 ? ls_launch_prep_f32(d_q, (float*)st.d_qh, d_qkeep, nq, nq_pad, g,
                                   (flags & LS_FLAG_NORMALIZE) != 0, d_flags, s)
-             : ls_launch_prep_f16(d_q, ix->d_qh, d_qkeep, nq, nq_pad, g,
+             : ls_launch_prep_f16(d_q, st.d_qh, d_qkeep, nq, nq_pad, g,
                                   (flags & LS_FLAG_NORMALIZE) != 0, d_flags, s);
     if (rc != LS_OK) return rc;
+    if (lanes) {
+        // the prep kernel was the only reader of the caller's query buffer (it also took the
+        // repair copy): work the caller queues on its stream from here on may overwrite it
+        LS_HIP(hipEventRecord(st.lane_q, s));
+        LS_HIP(hipStreamWaitEvent(caller, st.lane_q, 0));
+    }
     // sample pass: a few tiles of every slice, spread over the slice
     rc = pass(nullptr, sample_stride);
     if (rc != LS_OK) return rc;
-    rc = ls_launch_tau(ix->d_sample_top, nsplits, nq, nq_pad, jrank, ix->d_tau, s);
+    rc = ls_launch_tau(st.d_sample_top, nsplits, nq, nq_pad, jrank, st.d_tau, s);
     if (rc != LS_OK) return rc;
     // full pass
     if (prof) LS_HIP(hipEventRecord(pe[0], s));
-    rc = pass(ix->d_tau, 1);
+    rc = pass(st.d_tau, 1);
     if (rc != LS_OK) return rc;
     if (prof) {
         LS_HIP(hipEventRecord(pe[1], s));
@@ -706,9 +752,10 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     rc = ls_launch_batch_select(bufs, nsplits, nq, k, keys_need, ix->base, ix->n, rps, d_out_s, d_out_i,
                                 s);
     if (rc != LS_OK) return rc;
-    if (ix->bc_multi_stream) LS_HIP(hipEventRecord(ix->bc_done, s));
-    ix->bc_used = true;
-    ix->bc_last_stream = s;
+    if (st.multi_stream) LS_HIP(hipEventRecord(st.done, s));
+    st.used = true;
+    st.last_stream = s;
+    ix->bc_last_set = set_id;
     ix->n_batched_launches = 5;
     ix->d_last_flags = d_flags;
     ix->last_flags_n = nq;
@@ -991,9 +1038,10 @@ int ls_export_flags(ls_index* ix, void* d_dst, int64_t nq, void* stream) {
     LS_HIP(hipSetDevice(ix->device));
     hipStream_t s = (hipStream_t)stream;
     if (ix->d_last_flags && ix->last_flags_n == nq) {
-        if (ix->bc_last_stream != s) {  // flags are written on the search's stream
-            if (ix->bc_multi_stream) LS_HIP(hipStreamWaitEvent(s, ix->bc_done, 0));
-            else LS_HIP(hipStreamSynchronize(ix->bc_last_stream));
+        const ls_index::bc_set& st = ix->bc_sets[ix->bc_last_set];
+        if (st.last_stream != s) {  // flags are written on the search's stream (or lane)
+            if (st.multi_stream) LS_HIP(hipStreamWaitEvent(s, st.done, 0));
+            else LS_HIP(hipStreamSynchronize(st.last_stream));
         }
         LS_HIP(hipMemcpyAsync(d_dst, ix->d_last_flags, sizeof(u32) * (size_t)nq,
                               hipMemcpyDeviceToDevice, s));

@@ -52,6 +52,12 @@ typedef unsigned int u32;
 #ifndef LS_GEMM_STRAIGHT
 #define LS_GEMM_STRAIGHT 1           // tile loop without previous-/next-tile branches
 #endif
+#ifndef LS_GEMM_LEAN
+#define LS_GEMM_LEAN 0               // 1: every geometry recomputes DMA offsets / queue bases (fewer registers)
+#endif
+#ifndef LS_GEMM_SAMPLE_TOP2
+#define LS_GEMM_SAMPLE_TOP2 1        // 0: the sample pass always keeps four scores per lane
+#endif
 #ifndef LS_GEMM_RING3
 #define LS_GEMM_RING3 0              // 1: three tile buffers, DMA two tiles ahead (measured 1-2 % slower than two)
 #endif
@@ -203,7 +209,7 @@ int ls_launch_prep_f16(const float* d_q, void* d_qh, float* d_qkeep, int64_t nq,
 int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, const void* d_qh,
                           int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
                           int64_t rows_per_split, int tile_stride, const ls_gemm_bufs& b,
-                          hipStream_t s);
+                          bool sample_top2, hipStream_t s);
 int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_pad, int j_rank,
                   float* d_tau, hipStream_t s);
 int ls_gemm_qg(const ls_geom& g);         // query groups of 16 per wave (2, or 1 for 2 KiB rows)

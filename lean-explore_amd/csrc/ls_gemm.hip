@@ -134,6 +134,18 @@ __device__ __forceinline__ uint4 top4_keys(const float (&t)[4]) {  // 0 = "no sa
     return make_uint4(t[0] == -FLT_MAX ? 0u : ls_ord(t[0]), t[1] == -FLT_MAX ? 0u : ls_ord(t[1]),
                       t[2] == -FLT_MAX ? 0u : ls_ord(t[2]), t[3] == -FLT_MAX ? 0u : ls_ord(t[3]));
 }
+// The register-starved geometries (1.5 KiB rows: 14 registers spilled with four) keep the
+// lane's best TWO sample scores when the query has so many lanes that two of its best j
+// rarely share one (ls_launch_gemm_filter); the other two slots of the record stay "no
+// sample". Like the top-4, a shorter list can only lower tau.
+__device__ __forceinline__ void top4_insert(float (&t)[2], float v) {
+    const float a = fmaxf(v, t[1]);
+    t[1] = fminf(a, t[0]);
+    t[0] = fmaxf(a, t[0]);
+}
+__device__ __forceinline__ uint4 top4_keys(const float (&t)[2]) {
+    return make_uint4(t[0] == -FLT_MAX ? 0u : ls_ord(t[0]), t[1] == -FLT_MAX ? 0u : ls_ord(t[1]), 0u, 0u);
+}
 
 struct ls_gemm_out {
     uint2* queues;     // [nq_pad][nsplits][4][LS_GEMM_QCAP] (score bits, slice-relative row)
@@ -150,7 +162,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
-template <int CHUNKS, int QG, bool SAMPLE>
+template <int CHUNKS, int QG, bool SAMPLE, int TOPN = 4>  // TOPN: sample scores kept per lane
 __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_gemm_filter_kernel(
     const u32x4* __restrict__ corpus, long long n, const u32x4* __restrict__ qh, int nq, int nqt,
     const float* __restrict__ tau, long long rows_per_split, int tile_stride, ls_gemm_out out) {
@@ -199,8 +211,9 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // Other register-starved instantiations (ONE_ACC) recompute the generic per-lane offsets for
     // every tile behind an opaque copy of the lane id: hoisted out of the tile loop they would be
     // spilled and every reload would wait on the memory pipe.
-    int goff[(ONE_ACC || PAIRED) ? 1 : LOADS];
-    if constexpr (!ONE_ACC && !PAIRED) {
+    constexpr bool LEAN = ONE_ACC || LS_GEMM_LEAN;  // per-tile recomputation instead of registers
+    int goff[(LEAN || PAIRED) ? 1 : LOADS];
+    if constexpr (!LEAN && !PAIRED) {
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) {
             const int Lc = (wave * LOADS + j) * 64 + lane;
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     auto stage_piece = [&](int ti, int bufoff, int j) {
         const u32x4* base = corpus + (r_begin + (long long)ti * TM) * CHUNKS;
         int lane_v = lane;
-        if constexpr (ONE_ACC || PAIRED) asm volatile("" : "+v"(lane_v));
+        if constexpr (LEAN || PAIRED) asm volatile("" : "+v"(lane_v));
         if constexpr (PAIRED) {
             const int run = j / 3, which = j % 3;
             const int r0 = wave + LS_GEMM_WAVES * run;  // logical rows r0 and r0 + 16, key r0
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + off), (lds_ptr_t)dst, 16, 0, 0);
         } else {
             int off;
-            if constexpr (ONE_ACC) {
+            if constexpr (LEAN) {
                 const int Lc = (wave * LOADS + j) * 64 + lane_v;
                 const int r = Lc / CHUNKS, sl = Lc % CHUNKS;
                 off = r * CHUNKS + (sl ^ (r & 15));
@@ -298,13 +311,13 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // entry = {score bits, row relative to the slice}; the select kernel turns it into a key
     uint2* myq[QG];
     int cnt[QG];
-    float top[QG][4];
+    float top[QG][TOPN];  // sample scores kept per lane and query group
 #pragma unroll
     for (int g2 = 0; g2 < QG; ++g2) {
         myq[g2] = out.queues + queue_id(qj[g2], split, qd, nsplits) * cap;
         cnt[g2] = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) top[g2][e] = -FLT_MAX;
+        for (int e = 0; e < TOPN; ++e) top[g2][e] = -FLT_MAX;
     }
 
     // A fragment of k-step kk, row block rb: tile row rb*16 + li, chunk (4kk + qd) ^ li.
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             top4_insert(top[g2], (qj[g2] < nq && r_begin + lrow < r_end) ? s : -FLT_MAX);
         } else if (s >= tauv[g2]) {
             const int slot = cnt[g2] < cap ? cnt[g2] : cap - 1;
-            uint2* qp = ONE_ACC ? out.queues + queue_id(qj[g2], split, qd, nsplits) * cap : myq[g2];
+            uint2* qp = LEAN ? out.queues + queue_id(qj[g2], split, qd, nsplits) * cap : myq[g2];
             qp[slot] = make_uint2(__float_as_uint(s), (u32)lrow);
             ++cnt[g2];
         }
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                 const int pb = rb == 0 ? NRB - 1 : rb - 1;  // block whose scores are filtered now
                 const bool have = rb == 0 ? have_prev : true;
                 const int prow0 = (rb == 0 ? prev_row0 : cur_row0) + pb * 16;
-                constexpr int PF = LS_GEMM_PF, NA = PF + 1;  // A fragments are read PF k-steps ahead
+                constexpr int PF = SAMPLE ? 1 : LS_GEMM_PF, NA = PF + 1;  // A fragments are read PF k-steps ahead (the sample pass has 8 registers fewer)
                 half8 a[NA];
 #pragma unroll
                 for (int p0 = 0; p0 < PF; ++p0) a[p0] = a_frag(bufoff, rb, p0);
@@ -488,8 +501,8 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
         // one burst behind the barrier
         constexpr bool spread = (SEQ_RB || !SAMPLE) && LOADS <= KS;
         if (more && !spread) stage((i + AHEAD) * tile_stride, b_new);
-        run_tile(cur, prev, LS_GEMM_STRAIGHT ? true : i > 0, tile_row0(i - 1), tile_row0(i), b_cur, more && spread,
-                 (i + AHEAD) * tile_stride, b_new);
+        run_tile(cur, prev, LS_GEMM_STRAIGHT ? true : i > 0, tile_row0(i - 1), tile_row0(i), b_cur,
+                 more && spread, (i + AHEAD) * tile_stride, b_new);
         // tile i+1 must be complete before anyone reads it. NBUF == 3: only when a younger tile
         // was requested in this iteration may LOADS pieces stay in flight.
         hand_over(NBUF == 3 && more);
@@ -526,7 +539,7 @@ int ls_gemm_tile_rows(const ls_geom& g) { return gemm_tm(g.chunks); }
 int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, const void* d_qh,
                           int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
                           int64_t rows_per_split, int tile_stride, const ls_gemm_bufs& b,
-                          hipStream_t s) {
+                          bool sample_top2, hipStream_t s) {
     const int QG = ls_gemm_qg(g);
     const int nqt = (int)(nq_pad / (LS_GEMM_WAVES * 16 * QG));
     const dim3 grid((unsigned)(nsplits * nqt));
@@ -539,9 +552,9 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
     const size_t tile_bytes = (size_t)gemm_tile_bytes(g.chunks);
     const size_t smem = d_tau ? tile_bytes * gemm_nbuf(g.chunks)
                               : tile_bytes * (3 * tile_bytes <= LS_GEMM_LDS_BYTES ? 3 : 2);
-#define LS_GEMM_LAUNCH(C, SMP)                                                                    \
+#define LS_GEMM_LAUNCH(C, SMP, TOPN)                                                              \
     {                                                                                             \
-        auto kern = ls_gemm_filter_kernel<C, gemm_qg(C), SMP>;                                    \
+        auto kern = ls_gemm_filter_kernel<C, gemm_qg(C), SMP, TOPN>;                              \
         static ls_attr_once once;                                                                 \
         if (int rc = ls_set_max_dynamic_lds(once, (const void*)kern, LS_GEMM_LDS_BYTES)) return rc; \
         hipLaunchKernelGGL(kern, grid, dim3(LS_GEMM_THREADS), smem, s, (const u32x4*)d_corpus,    \
@@ -550,10 +563,11 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
         LS_HIP(hipGetLastError());                                                                \
         return LS_OK;                                                                             \
     }
-#define LS_GEMM_CASE(C)                     \
-    if (g.chunks == C) {                    \
-        if (d_tau) LS_GEMM_LAUNCH(C, false) \
-        else LS_GEMM_LAUNCH(C, true)        \
+#define LS_GEMM_CASE(C)                                                      \
+    if (g.chunks == C) {                                                     \
+        if (d_tau) LS_GEMM_LAUNCH(C, false, 4)                               \
+        else if (C / 4 * gemm_qg(C) * 4 >= 128 && sample_top2) LS_GEMM_LAUNCH(C, true, 2) \
+        else LS_GEMM_LAUNCH(C, true, 4)                                      \
     }
     LS_GEMM_CASE(16) LS_GEMM_CASE(32) LS_GEMM_CASE(48) LS_GEMM_CASE(64)
     LS_GEMM_CASE(96) LS_GEMM_CASE(128)

@@ -227,6 +227,44 @@ def test_async_repair_uses_the_librarys_query_copy():
     ix.close()
 
 
+def test_pipelined_batches_alternate_between_the_two_lanes():
+    """LS_FLAG_PIPELINE on the batched path: consecutive batches run on the handle's two internal
+    streams with their own scratch (one batch's small kernels overlap the other's MFMA pass).
+    Different queries, batch sizes and k per call, the query tensor overwritten right behind
+    the call in stream order, one planted cluster that needs a repair; mixed with a plain
+    async call on the caller's stream (scratch set 0). Everything is exact after ls_check."""
+    import torch
+
+    c = H.gauss(71, 150_000, 384)
+    rng = np.random.default_rng(9)
+    shapes = [(256, 100), (192, 50), (1024, 100), (40, 10), (256, 128), (300, 100), (64, 1000)]
+    qs = [H.gauss(80 + i, nq, 384) for i, (nq, _) in enumerate(shapes)]
+    lo = 70_000
+    for r in range(lo, lo + 300):  # > 32 rows of one lane's stripe pass query 0 of batch 2
+        v = qs[2][0] + 0.05 * rng.standard_normal(384).astype(np.float32)
+        c[r] = v / np.linalg.norm(v)
+    ix = FlatIPIndex.from_array(c, dtype="f16")
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream(dev)
+    outs = []
+    with torch.cuda.stream(st):
+        for i, (q, (nq, k)) in enumerate(zip(qs, shapes)):
+            tq = torch.from_numpy(q).to(dev)
+            s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            ii = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            ix.search_device(tq, k, s, ii, pipeline=(i != 4), asynchronous=(i == 4), stream=st)
+            tq.normal_()  # stream-ordered overwrite: the call made `st` wait for the lane.s prep
+            outs.append((s, ii))
+    ix.check(stream=st)
+    assert ix.debug_counter(8) >= 1, "the planted cluster must have gone through the repair"
+    for q, (nq, k), (s, ii) in zip(qs, shapes, outs):
+        Dr, Ir = oracle.c_search(c, q, k, f16=True)
+        _, _, S = oracle.np_search(c, q, k, f16=True)
+        rep = oracle.compare_topk(s.cpu().numpy(), ii.cpu().numpy(), Dr, Ir, S)
+        assert rep["recall"] >= 0.9999, (nq, k, rep)  # a near-tie AT rank k swaps one row of the set
+    ix.close()
+
+
 # ---------------------------------------------------------------- fp32 index: exact f32 MFMA path
 def check_batched_f32(c, q, k, normalize=False, base=0):
     ix = FlatIPIndex.from_array(c, dtype="f32", base=base)

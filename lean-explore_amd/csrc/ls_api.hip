@@ -572,7 +572,7 @@ static int batched_repair(ls_index* ix) {
         const u32* fl = ix->h_overflow + (size_t)bc.slot * ix->bc_slot_stride;
         const float* qk = ix->d_qkeep + (size_t)bc.slot * ix->bc_qkeep_stride;
         for (int64_t q = 0; q < bc.nq; ++q) {
-            if (!fl[q]) continue;
+            if (!fl[q] || LS_ABL_NOREPAIR) continue;
             ix->n_batched_fallback++;
             any = true;
             int rc = scan_search_on_stream(ix, qk + q * ix->g.d, 1, bc.k,

@@ -52,6 +52,19 @@ typedef unsigned int u32;
 #ifndef LS_GEMM_STRAIGHT
 #define LS_GEMM_STRAIGHT 1           // tile loop without previous-/next-tile branches
 #endif
+// timing ablations for variant builds (results are wrong with any of them set; never shipped)
+#ifndef LS_ABL_NOPASS
+#define LS_ABL_NOPASS 0    // the filter compares against +FLT_MAX: no append is ever taken
+#endif
+#ifndef LS_ABL_NOREPAIR
+#define LS_ABL_NOREPAIR 0  // flagged queries are not re-run (keeps the timing of broken variants clean)
+#endif
+#ifndef LS_ABL_NOBARRIER
+#define LS_ABL_NOBARRIER 0
+#endif
+#ifndef LS_ABL_NODMA
+#define LS_ABL_NODMA 0
+#endif
 #ifndef LS_GEMM_LEAN
 #define LS_GEMM_LEAN 0               // 1: every geometry recomputes DMA offsets / queue bases (fewer registers)
 #endif

@@ -162,7 +162,12 @@ __device__ __forceinline__ void wait_vmcnt() {
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
-template <int CHUNKS, int QG, bool SAMPLE, int TOPN = 4>  // TOPN: sample scores kept per lane
+// TOPN: sample scores kept per lane. SAMPLE stays the last parameter: the profile tooling tells
+// the two passes apart by the ", true>" / ", false>" tail of the kernel name.
+// NT: the tile DMA carries the non-temporal hint. Right when ONE workgroup reads each corpus slice
+// once (a single query tile, config 4: -1.5 %); wrong when the query tiles of a slice share it
+// through their XCD's L2 (config 3: +3.8 %).
+template <int CHUNKS, int QG, int TOPN, bool NT, bool SAMPLE>
 __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_gemm_filter_kernel(
     const u32x4* __restrict__ corpus, long long n, const u32x4* __restrict__ qh, int nq, int nqt,
     const float* __restrict__ tau, long long rows_per_split, int tile_stride, ls_gemm_out out) {
@@ -223,6 +228,9 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     }
     // piece j (0 .. LOADS-1) of tile ti -> the tile buffer at LDS byte offset bufoff
     auto stage_piece = [&](int ti, int bufoff, int j) {
+#if LS_ABL_NODMA
+        if (!SAMPLE && ti > 0) return;
+#endif
         const u32x4* base = corpus + (r_begin + (long long)ti * TM) * CHUNKS;
         int lane_v = lane;
         if constexpr (LEAN || PAIRED) asm volatile("" : "+v"(lane_v));
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             const int off = which == 0 ? t
                           : which == 1 ? (lane_v < 32 ? 64 + t : 16 * CHUNKS + t - 32)
                                        : 16 * CHUNKS + 32 + t;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + off), (lds_ptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + off), (lds_ptr_t)dst, 16, 0, NT ? 2 : 0);
         } else {
             int off;
             if constexpr (LEAN) {
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                 off = goff[j];
             }
             unsigned char* dst = smem + bufoff + (wave * LOADS + j) * 1024;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + off), (lds_ptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + off), (lds_ptr_t)dst, 16, 0, NT ? 2 : 0);
         }
     };
     auto stage = [&](int ti, int bufoff) {  // all pieces of tile ti, back to back
@@ -261,7 +269,9 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     auto hand_over = [&](bool newer) {
         asm volatile("" ::: "memory");
         if (newer) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+#if !LS_ABL_NOBARRIER
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
     };
     // The hand-over in front of the first tile drains everything (vmcnt(0)). Tried and removed:
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
         qj[g2] = (qt * LS_GEMM_WAVES + wave) * QPW + g2 * 16 + li;
         // fragment-ordered by ls_prep_f16_kernel: each load below is one contiguous KiB per wave
         qfrag[g2] = qh + ((((long long)(qt * LS_GEMM_WAVES + wave) * QG + g2) * KS) << 6) + lane;
-        tauv[g2] = SAMPLE ? 0.0f : tau[qj[g2]];
+        tauv[g2] = SAMPLE ? 0.0f : (LS_ABL_NOPASS ? FLT_MAX : tau[qj[g2]]);
     }
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)
@@ -552,9 +562,9 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
     const size_t tile_bytes = (size_t)gemm_tile_bytes(g.chunks);
     const size_t smem = d_tau ? tile_bytes * gemm_nbuf(g.chunks)
                               : tile_bytes * (3 * tile_bytes <= LS_GEMM_LDS_BYTES ? 3 : 2);
-#define LS_GEMM_LAUNCH(C, SMP, TOPN)                                                              \
+#define LS_GEMM_LAUNCH(C, SMP, TOPN, NT)                                                          \
     {                                                                                             \
-        auto kern = ls_gemm_filter_kernel<C, gemm_qg(C), SMP, TOPN>;                              \
+        auto kern = ls_gemm_filter_kernel<C, gemm_qg(C), TOPN, NT, SMP>;                          \
         static ls_attr_once once;                                                                 \
         if (int rc = ls_set_max_dynamic_lds(once, (const void*)kern, LS_GEMM_LDS_BYTES)) return rc; \
         hipLaunchKernelGGL(kern, grid, dim3(LS_GEMM_THREADS), smem, s, (const u32x4*)d_corpus,    \
@@ -565,9 +575,10 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
     }
 #define LS_GEMM_CASE(C)                                                      \
     if (g.chunks == C) {                                                     \
-        if (d_tau) LS_GEMM_LAUNCH(C, false, 4)                               \
-        else if (C / 4 * gemm_qg(C) * 4 >= 128 && sample_top2) LS_GEMM_LAUNCH(C, true, 2) \
-        else LS_GEMM_LAUNCH(C, true, 4)                                      \
+        if (d_tau && nqt == 1) LS_GEMM_LAUNCH(C, false, 4, true)             \
+        else if (d_tau) LS_GEMM_LAUNCH(C, false, 4, false)                   \
+        else if (C / 4 * gemm_qg(C) * 4 >= 128 && sample_top2) LS_GEMM_LAUNCH(C, true, 2, false) \
+        else LS_GEMM_LAUNCH(C, true, 4, false)                               \
     }
     LS_GEMM_CASE(16) LS_GEMM_CASE(32) LS_GEMM_CASE(48) LS_GEMM_CASE(64)
     LS_GEMM_CASE(96) LS_GEMM_CASE(128)

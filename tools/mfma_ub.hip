@@ -7,6 +7,8 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define MF(a,b,c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a,b,c,0,0,0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MF16(a,b,c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a,b,c,0,0,0)
 
 template <int PAT>
 __global__ __launch_bounds__(512, 2) void k(const u32x4* g, float* out, int iters, float tau) {
@@ -108,6 +110,19 @@ __global__ __launch_bounds__(512, 2) void k(const u32x4* g, float* out, int iter
             }
         }
     }
+    if (PAT == 10 || PAT == 11) {  // 16x16x32: 48 MFMAs = the flops of 24 32x32x16; 4 or 8 chains
+        f32x4 a4[8];
+        for (int i = 0; i < 8; ++i) a4[i] = f32x4{0, 0, 0, 0};
+        half8 a = __builtin_bit_cast(half8, *(const u32x4*)(p));
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int kk = 0; kk < 48; ++kk) {
+                const int c = PAT == 10 ? (kk & 3) : (kk & 7);
+                a4[c] = MF16(a, b[kk & 7], a4[c]);
+            }
+        }
+        for (int i = 0; i < 8; ++i) A[i] += a4[i][0] + a4[i][1] + a4[i][2] + a4[i][3];
+    }
     float s = 0;
     for (int i = 0; i < 16; ++i) s += A[i] + B[i] + C[i] + D[i];
     if (s == 12345.f || cnt == 777) out[tid] = s;
@@ -138,6 +153,8 @@ int main() {
     }
     if (getenv("UB_CONST")) for (auto& v : h) v = 0x3c00;
     hipMemcpy(g, h.data(), 8 << 20, hipMemcpyHostToDevice);
+    run<10>(g, o, "P10 16x16x32 x2 (same flops), 4 chains, pure");
+    run<11>(g, o, "P11 16x16x32 x2 (same flops), 8 chains, pure");
     run<0>(g, o, "P0 1 acc, pure dependent chain");
     run<1>(g, o, "P1 1 acc, ds_read between");
     run<2>(g, o, "P2 2 acc alternating, pure");

@@ -265,6 +265,65 @@ def test_pipelined_batches_alternate_between_the_two_lanes():
     ix.close()
 
 
+def test_pipelined_lanes_mixed_with_scan_path_and_add():
+    """One handle, one ls_check: pipelined batched calls (lanes), pipelined single queries (scan
+    path, finalize riding on the next launch) and an async batched call interleaved; then
+    index.add() (which must drain the lanes before it moves the corpus) and another round."""
+    import torch
+
+    c = H.gauss(91, 90_000, 384)
+    extra = H.gauss(92, 10_000, 384)
+    ix = FlatIPIndex.from_array(c, dtype="f16")
+    dev = torch.device("cuda:0")
+    plan = [("lane", 256, 64), ("scan", 1, 50), ("lane", 100, 100), ("scan", 4, 10),
+            ("async", 64, 32), ("lane", 512, 20), ("scan", 1, 1000)]
+
+    def run(corpus, seed):
+        outs = []
+        for i, (mode, nq, k) in enumerate(plan):
+            q = H.gauss(seed + i, nq, 384)
+            tq = torch.from_numpy(q).to(dev)
+            s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            ii = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            ix.search_device(tq, k, s, ii, pipeline=(mode != "async"), asynchronous=(mode == "async"))
+            outs.append((q, k, s, ii, tq))
+        ix.check()
+        for q, k, s, ii, _ in outs:
+            Dr, Ir = oracle.c_search(corpus, q, k, f16=True)
+            _, _, S = oracle.np_search(corpus, q, k, f16=True)
+            rep = oracle.compare_topk(s.cpu().numpy(), ii.cpu().numpy(), Dr, Ir, S)
+            assert rep["recall"] >= 0.9999, (q.shape, k, rep)
+
+    run(c, 100)
+    ix.add(extra)
+    run(np.concatenate([c, extra]), 200)
+    ix.close()
+
+
+def test_pipelined_lanes_large_and_ragged_batches():
+    """nq far above one query tile (several tiles per slice, few slices) and nq just past the
+    scan-path limit, k > rows of a slice, on a small corpus; through the lanes."""
+    import torch
+
+    c = H.gauss(93, 40_000, 64)
+    ix = FlatIPIndex.from_array(c, dtype="f16")
+    dev = torch.device("cuda:0")
+    outs = []
+    for i, (nq, k) in enumerate([(5000, 10), (17, 700), (1025, 33), (2048, 100)]):
+        q = H.gauss(300 + i, nq, 64)
+        tq = torch.from_numpy(q).to(dev)
+        s, ii = ix.search_device(tq, k, pipeline=True)
+        outs.append((q, k, s, ii))
+    ix.check()
+    for q, k, s, ii in outs:
+        nchk = min(len(q), 256)
+        Dr, Ir = oracle.c_search(c, q[:nchk], k, f16=True)
+        _, _, S = oracle.np_search(c, q[:nchk], k, f16=True)
+        rep = oracle.compare_topk(s[:nchk].cpu().numpy(), ii[:nchk].cpu().numpy(), Dr, Ir, S)
+        assert rep["recall"] >= 0.9999, (q.shape, k, rep)
+    ix.close()
+
+
 # ---------------------------------------------------------------- fp32 index: exact f32 MFMA path
 def check_batched_f32(c, q, k, normalize=False, base=0):
     ix = FlatIPIndex.from_array(c, dtype="f32", base=base)
@@ -334,3 +393,27 @@ def test_f32_batched_ragged_small_and_clustered():
         c[r] = v / np.linalg.norm(v)
     rep, fb = check_batched_f32(c, q, 100)
     print("f32 clustered", rep, "fallbacks", fb)
+
+
+def test_f32_batched_through_the_lanes():
+    """fp32 index, batches of >= 24 queries with LS_FLAG_PIPELINE: the exact f32 MFMA path shares
+    the lanes and scratch sets with the fp16 path."""
+    import torch
+
+    c = H.gauss(95, 60_000, 256)
+    ix = FlatIPIndex.from_array(c, dtype="f32")
+    dev = torch.device("cuda:0")
+    outs = []
+    for i, (nq, k) in enumerate([(64, 100), (200, 10), (24, 1000), (128, 50)]):
+        q = H.gauss(400 + i, nq, 256)
+        tq = torch.from_numpy(q).to(dev)
+        s, ii = ix.search_device(tq, k, pipeline=True)
+        outs.append((q, k, s, ii))
+    ix.check()
+    assert ix.debug_counter(9) == 5
+    for q, k, s, ii in outs:
+        Dr, Ir = oracle.c_search(c, q, k)
+        _, _, S = oracle.np_search(c, q, k)
+        rep = oracle.compare_topk(s.cpu().numpy(), ii.cpu().numpy(), Dr, Ir, S, score_tol=1e-5, tie_eps=2e-6)
+        assert rep["recall"] >= 0.9999, (q.shape, k, rep)
+    ix.close()

@@ -53,7 +53,21 @@ def test_random_parity_sweep(default_seed):
         try:
             if min(k, n) > 2048:
                 continue
-            D, I = ix.search(q, k, normalize=normalize)
+            if cases % 3 == 2:
+                # every third case goes through the device API instead: the same batch queued
+                # three times with LS_FLAG_PIPELINE (scan path: finalize rides on the next launch;
+                # batched paths: the two internal lanes), one ls_check, all three compared
+                import torch
+
+                tq = torch.from_numpy(q).cuda()
+                outs = [ix.search_device(tq, k, normalize=normalize, pipeline=True) for _ in range(3)]
+                ix.check()
+                D, I = outs[0][0].cpu().numpy(), outs[0][1].cpu().numpy()
+                for s_, i_ in outs[1:]:
+                    assert np.array_equal(s_.cpu().numpy(), D) and np.array_equal(i_.cpu().numpy(), I), \
+                        f"{label}: pipelined repeats differ"
+            else:
+                D, I = ix.search(q, k, normalize=normalize)
         finally:
             ix.close()
         f16 = dtype == "f16"

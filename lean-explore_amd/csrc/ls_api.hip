@@ -1166,6 +1166,14 @@ int ls_debug_read_scores(ls_index* ix, float* out, int64_t count) {
 }
 
 int64_t ls_debug_counter(ls_index* ix, int32_t which) {
+#ifdef LS_SCAN_TIMING
+    if (ix && which >= 10 && which < 14) {  // phase stamps of the last scan launch (ls_scan.hip)
+        u64 v = 0;
+        if (hipMemcpy(&v, ix->sets[ix->last_set].d_cand + (size_t)ix->max_blocks * LS_KP_MAX - 8 + (which - 10),
+                      sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        return (int64_t)v;
+    }
+#endif
     if (!ix || which < 0 || which > 9) return -1;
     std::lock_guard<std::mutex> lk(ix->mu);
     if (which == 8) return (int64_t)ix->n_batched_fallback;

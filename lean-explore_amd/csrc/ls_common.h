@@ -28,6 +28,15 @@ typedef unsigned int u32;
 #define LS_FINAL_THREADS 1024
 #define LS_FINAL_CAP 8192            // keys the finalize workgroup sorts in LDS (64 KiB)
 #define LS_SCAN_MAX_NQ 16            // nq <= this: per-query HBM-bound scan path
+#ifndef LS_SCAN_SMALL
+#define LS_SCAN_SMALL 1              // small shards: waves rank their <= 64 keys once instead of inserting row by row
+#endif
+#ifndef LS_SCAN_SMALL_ROWS
+#define LS_SCAN_SMALL_ROWS 64        // ... when no wave sees more rows than this (<= 64: one key per lane)
+#endif
+#ifndef LS_SCAN_SMALL_MAX_BLOCKS
+#define LS_SCAN_SMALL_MAX_BLOCKS 256 // ... and the launch has at most one scan workgroup per CU
+#endif
 #ifndef LS_GEMM_THREADS
 #define LS_GEMM_THREADS 512          // batched path: 8 waves per workgroup
 #endif

@@ -158,7 +158,14 @@ __device__ __forceinline__ float pick_group(float s, int lane) {
     return out;
 }
 
-template <bool F16, int L, int V, int U, int NQ>
+// SMALL: a wave sees at most 64 rows in the whole launch (small shards: a few tiles per wave).
+// The running sorted list is then the wrong tool - nearly every row of a wave's first tiles
+// enters it, one serial insert (~0.2 us) per row: 3.5 of the 10.3 us of a scan-only launch at
+// N = 10 k - so the wave parks tile i's TR scores in lanes i*TR .. and ranks its <= 64 keys
+// once, by counting, after the last tile.
+// SMALL also keeps PF = 4 tiles in flight per wave: with a handful of tiles per wave each HBM round
+// trip would otherwise be paid in sequence (1.0-1.4 us per tile of a 4-tile wave).
+template <bool F16, int L, int V, int U, int NQ, bool SMALL>
 __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
     const f32x4* __restrict__ corpus, long long n, int chunks, const float* __restrict__ qraw,
     int d, int normalize, int reverse, float* __restrict__ S, long long s_stride,
@@ -174,6 +181,13 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
     }
     const int bid = (int)blockIdx.x - nfin;
     const int nblk = (int)gridDim.x - nfin;
+#ifdef LS_SCAN_TIMING  // developer instrumentation: phase stamps (100 MHz ticks) of one scan workgroup
+    unsigned long long stamp[6];
+#define LS_SSTAMP(i) stamp[i] = wall_clock64()
+#else
+#define LS_SSTAMP(i) do {} while (0)
+#endif
+    LS_SSTAMP(0);
     constexpr int R = LS_WAVE / L;  // rows per wave load step
     constexpr int TR = U * R;       // rows per tile: one tile = U steps = TR contiguous rows
     static_assert(TR <= LS_WAVE, "a tile's scores must fit one per lane");
@@ -189,8 +203,9 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
     const long long gw = (long long)bid * LS_SCAN_WAVES + wave;
     const long long NT = (n + TR - 1) / TR;
 
-    f32x4 x[U][V];
-    auto issue_loads = [&](long long t) {
+    constexpr int PF = SMALL ? 4 : 1;  // tile buffers (statically indexed: the loop body is unrolled PF times)
+    f32x4 xb[PF][U][V];
+    auto issue_loads = [&](f32x4 (&x)[U][V], long long t) {
         if (reverse) t = NT - 1 - t;  // optional back-to-front sweep (see ls_api.hip)
         const long long r0 = t * TR + grp;
 #pragma unroll
@@ -203,7 +218,9 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
         }
     };
     long long t = gw;
-    if (t < NT) issue_loads(t);  // first tile's loads fly while the queries are prepared
+    // the first tile's loads fly while the queries are prepared (SMALL: the query goes first -
+    // loads return in order, it must not queue behind four tiles - and the tiles follow it)
+    if (!SMALL && t < NT) issue_loads(xb[0], t);
 
     // NQ queries -> registers, with faiss.normalize_L2 (reference search/engine.py:242) fused
     // in: x *= 1/sqrt(sum x^2), rows of zero norm untouched. One pass over the corpus then
@@ -221,6 +238,15 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
         qr[qi].scale(inv);
     }
 
+    if constexpr (SMALL) {
+        // hipcc waits with vmcnt(0) for the query (the normalise branch merges in front of its
+        // first use), i.e. for every load issued before: the four tiles go out behind it
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf)
+            if (t + pf * W < NT) issue_loads(xb[pf], t + pf * W);
+    }
+    LS_SSTAMP(1);
     u64 lst[NQ];  // per query, lanes 0..kp-1: this wave's best keys, descending
     u64 thr[NQ];  // key in lane kp-1 (wave-uniform): a row must beat it to matter
 #pragma unroll
@@ -229,25 +255,39 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
         thr[qi] = 0;
     }
 
-    while (t < NT) {
-        // lane i < TR collects the score of tile row i, per query
+    int ti = 0;  // SMALL: tiles this wave has seen
+    auto tile_step = [&](f32x4 (&x)[U][V]) {  // tile t sits in buffer x
+        if (t >= NT) return;
+        // lane i < TR collects the score of tile row i, per query (SMALL: lane ti*TR + i)
         float sc[NQ];
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) sc[qi] = 0.0f;
+        const int lane0 = SMALL ? ti * TR : 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
                 const float s = group_sum<L>(qr[qi].dot(x[u]));   // valid in all L lanes of a group
                 const float sel = pick_group<L>(s, lane);         // lane i <- group (i % R)
-                if (lane / R == u) sc[qi] = sel;
+                if (lane / R == (SMALL ? ti * U : 0) + u) sc[qi] = sel;
             }
         }
         const long long tt = reverse ? NT - 1 - t : t;
-        const long long row = tt * TR + lane;
+        const long long row = tt * TR + (lane - lane0);
         t += W;
-        if (t < NT) issue_loads(t);  // next tile's loads overlap the selection below
-        const bool valid = lane < TR && row < n;
+        if (t + (PF - 1) * W < NT) issue_loads(x, t + (PF - 1) * W);  // overlaps the selection below
+        const bool valid = lane >= lane0 && lane < lane0 + TR && row < n;
+        ++ti;
+        if constexpr (SMALL) {
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+                if (valid) {
+                    S[qi * s_stride + row] = sc[qi];
+                    lst[qi] = ls_make_key(sc[qi], (u32)row);  // this lane's one key of the launch
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
             if (valid) S[qi * s_stride + row] = sc[qi];  // TR contiguous floats
@@ -261,25 +301,65 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
                 thr[qi] = readlane64(lst[qi], kp - 1);
             }
         }
+    };
+    while (t < NT) {  // buffers are named statically: PF calls per round
+        tile_step(xb[0]);
+        if constexpr (PF == 4) {
+            tile_step(xb[1]);
+            tile_step(xb[2]);
+            tile_step(xb[3]);
+        }
     }
 
+    LS_SSTAMP(2);
     // merge the 4 wave lists of every query -> this workgroup's best kprime keys + bound
     __shared__ u64 sm[NQ][LS_SCAN_WAVES * LS_KP_MAX];
+    if constexpr (SMALL) {
+        // every lane holds at most one key: its rank among the wave's keys by counting (non-zero
+        // keys are unique; the "no row" lanes hold 0 and rank behind every real key)
 #pragma unroll
-    for (int qi = 0; qi < NQ; ++qi)
-        if (lane < LS_KP_MAX) sm[qi][wave * LS_KP_MAX + lane] = (lane < kp) ? lst[qi] : 0ull;
+        for (int qi = 0; qi < NQ; ++qi) {
+            const u64 mine = lst[qi];
+            int rank = 0;
+            for (int t2 = 0; t2 < ti; ++t2) {  // only the lanes that can hold a key: ti tiles of TR rows
+#pragma unroll
+                for (int r = 0; r < TR; ++r) rank += readlane64(mine, t2 * TR + r) > mine;
+            }
+            if (lane < LS_KP_MAX) sm[qi][wave * LS_KP_MAX + lane] = 0ull;
+            if (mine != 0ull && rank < kp) sm[qi][wave * LS_KP_MAX + rank] = mine;
+        }
+    } else {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi)
+            if (lane < LS_KP_MAX) sm[qi][wave * LS_KP_MAX + lane] = (lane < kp) ? lst[qi] : 0ull;
+    }
     __syncthreads();
+    LS_SSTAMP(3);
     for (int qi = wave; qi < NQ; qi += LS_SCAN_WAVES) {  // wave w ranks queries w, w+4, ..
         const u64 mine = sm[qi][lane];  // LS_SCAN_WAVES * LS_KP_MAX == 64 slots
         int rank = 0;
+        if constexpr (SMALL) {  // only the kp slots each wave filled (the others hold 0)
+            for (int w = 0; w < LS_SCAN_WAVES; ++w)
+                for (int j = 0; j < kp; ++j) {
+                    const int i = w * LS_KP_MAX + j;
+                    const u64 o = sm[qi][i];
+                    rank += (o > mine) || (o == mine && i < lane);
+                }
+        } else {
 #pragma unroll 8
-        for (int i = 0; i < LS_SCAN_WAVES * LS_KP_MAX; ++i) {
-            const u64 o = sm[qi][i];
-            rank += (o > mine) || (o == mine && i < lane);
+            for (int i = 0; i < LS_SCAN_WAVES * LS_KP_MAX; ++i) {
+                const u64 o = sm[qi][i];
+                rank += (o > mine) || (o == mine && i < lane);
+            }
         }
         if (rank < kprime) cand[qi * c_stride + (long long)bid * kprime + rank] = mine;
         if (rank == kprime) bound[qi * b_stride + bid] = mine;
     }
+#ifdef LS_SCAN_TIMING
+    LS_SSTAMP(4);
+    if (bid == nblk / 2 && threadIdx.x == 0)
+        for (int i = 0; i < 4; ++i) cand[c_stride - 8 + i] = stamp[i + 1] - stamp[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -331,14 +411,31 @@ static int launch_lvq(const void* corpus, int64_t n, const ls_geom& g, const ls_
         const int keff = (int)((long long)fp.k < fp.n ? fp.k : fp.n);
         smem = std::max(smem, ls_fin_lds_bytes(fp.keys_cap, keff));
     }
-    auto kern = ls_scan_kernel<F16, L, V, U, NQ>;
-    static ls_attr_once once;
-    if (int rc = ls_set_max_dynamic_lds(once, (const void*)kern, LS_PIGGY_LDS_MAX)) return rc;
-    hipLaunchKernelGGL(kern, dim3(a.blocks + a.nfin), dim3(LS_SCAN_THREADS), smem, s,
-                       (const f32x4*)corpus, (long long)n, g.chunks, a.d_q, g.d,
-                       a.normalize ? 1 : 0, a.reverse ? 1 : 0, a.d_S, (long long)a.s_stride,
-                       a.d_cand, (long long)a.c_stride, a.d_bound, (long long)a.b_stride, a.kprime,
-                       a.nfin, a.fin);
+    // single-query launches in which no wave sees more than 64 rows rank once instead of inserting
+    constexpr int TR = U * (LS_WAVE / L);
+    const long long waves = (long long)a.blocks * LS_SCAN_WAVES;
+    const long long tiles_per_wave = ((n + TR - 1) / TR + waves - 1) / waves;
+    // (with two or more workgroups per CU the other one hides the latency: measured neutral at
+    // N = 50 k, 3 % slower at 100 k, 6-11 % faster at 25 k and 10 k)
+    const bool small = LS_SCAN_SMALL && NQ == 1 && tiles_per_wave * TR <= LS_SCAN_SMALL_ROWS &&
+                       a.blocks <= LS_SCAN_SMALL_MAX_BLOCKS;
+#define LS_SCAN_LAUNCH(SM)                                                                         \
+    {                                                                                              \
+        auto kern = ls_scan_kernel<F16, L, V, U, NQ, SM>;                                          \
+        static ls_attr_once once;                                                                  \
+        if (int rc = ls_set_max_dynamic_lds(once, (const void*)kern, LS_PIGGY_LDS_MAX)) return rc; \
+        hipLaunchKernelGGL(kern, dim3(a.blocks + a.nfin), dim3(LS_SCAN_THREADS), smem, s,          \
+                           (const f32x4*)corpus, (long long)n, g.chunks, a.d_q, g.d,               \
+                           a.normalize ? 1 : 0, a.reverse ? 1 : 0, a.d_S, (long long)a.s_stride,   \
+                           a.d_cand, (long long)a.c_stride, a.d_bound, (long long)a.b_stride,      \
+                           a.kprime, a.nfin, a.fin);                                               \
+    }
+    if constexpr (NQ == 1) {
+        if (small) LS_SCAN_LAUNCH(true) else LS_SCAN_LAUNCH(false)
+    } else {
+        LS_SCAN_LAUNCH(false)
+    }
+#undef LS_SCAN_LAUNCH
     LS_HIP(hipGetLastError());
     return LS_OK;
 }

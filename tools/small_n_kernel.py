@@ -30,3 +30,22 @@ th = time.perf_counter() - t0
 ix.check()
 dt = time.perf_counter() - t0
 print(f"N={n} two_stage={two}: {dt / R * 1e6:.2f} us/step, host issue {th / R * 1e6:.2f} us/call", flush=True)
+
+# the same steps through a bare ctypes call on cached addresses (what lean_explore_amd.sharded's
+# pipelined path does): how much of the step is the Python wrapper?
+from lean_explore_amd import native  # noqa: E402
+
+lib, h = native.load(), ix._ensure_built()
+call = lib.ls_search_device
+st = torch.cuda.current_stream().cuda_stream
+args = [(h, tq.data_ptr(), 1, 50, native.LS_FLAG_PIPELINE, o[0].data_ptr(), o[1].data_ptr(), st) for o in outs]
+for i in range(500):
+    call(*args[i & 15])
+ix.check()
+t0 = time.perf_counter()
+for i in range(R):
+    call(*args[i & 15])
+th = time.perf_counter() - t0
+ix.check()
+dt = time.perf_counter() - t0
+print(f"N={n} bare ctypes: {dt / R * 1e6:.2f} us/step, host issue {th / R * 1e6:.2f} us/call", flush=True)

@@ -1167,6 +1167,13 @@ int ls_debug_read_scores(ls_index* ix, float* out, int64_t count) {
 
 int64_t ls_debug_counter(ls_index* ix, int32_t which) {
 #ifdef LS_SCAN_TIMING
+    if (ix && which >= 1000) {  // start / end tick of scan workgroup (which - 1000) / 2
+        u64 v = 0;
+        if (hipMemcpy(&v, reinterpret_cast<const u64*>(ix->sets[ix->last_set].d_S + 7 * ix->s_stride) +
+                              (which - 1000), sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+        return (int64_t)v;
+    }
     if (ix && which >= 10 && which < 14) {  // phase stamps of the last scan launch (ls_scan.hip)
         u64 v = 0;
         if (hipMemcpy(&v, ix->sets[ix->last_set].d_cand + (size_t)ix->max_blocks * LS_KP_MAX - 8 + (which - 10),

@@ -359,6 +359,11 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
     LS_SSTAMP(4);
     if (bid == nblk / 2 && threadIdx.x == 0)
         for (int i = 0; i < 4; ++i) cand[c_stride - 8 + i] = stamp[i + 1] - stamp[i];
+    if (threadIdx.x == 0 && NQ == 1) {  // every workgroup's start / end tick: slot 7 of S is unused
+        unsigned long long* life = reinterpret_cast<unsigned long long*>(S + 7 * s_stride);
+        life[2 * bid] = stamp[0];
+        life[2 * bid + 1] = stamp[4];
+    }
 #endif
 }
 

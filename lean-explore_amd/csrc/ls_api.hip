@@ -1166,6 +1166,15 @@ int ls_debug_read_scores(ls_index* ix, float* out, int64_t count) {
 }
 
 int64_t ls_debug_counter(ls_index* ix, int32_t which) {
+#ifdef LS_GEMM_TIMING
+    if (ix && which >= 2000) {  // start / end tick of MFMA-pass workgroup (which - 2000) / 2
+        u64 v = 0;
+        if (hipMemcpy(&v, reinterpret_cast<const u64*>(ix->bc_sets[ix->bc_last_set].d_sample_top) + (which - 2000),
+                      sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+        return (int64_t)v;
+    }
+#endif
 #ifdef LS_SCAN_TIMING
     if (ix && which >= 1000) {  // start / end tick of scan workgroup (which - 1000) / 2
         u64 v = 0;

@@ -190,6 +190,9 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // the tile ring
 
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef LS_GEMM_TIMING  // developer instrumentation: start / end tick (100 MHz) of every workgroup
+    const unsigned long long t_start = wall_clock64();
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar DMA addressing
     const int qd = lane >> 4, li = lane & 15;  // quarter (k-chunk / row group), index in group
     int split, qt;
@@ -541,6 +544,13 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             if (cnt[g2] > cap) out.overflow[qj[g2]] = 1u;
         }
     }
+#ifdef LS_GEMM_TIMING
+    if (!SAMPLE && tid == 0) {  // the sample tops are dead once tau has been computed
+        unsigned long long* life = reinterpret_cast<unsigned long long*>(out.sample_top);
+        life[2 * blockIdx.x] = t_start;
+        life[2 * blockIdx.x + 1] = wall_clock64();
+    }
+#endif
 }
 
 int ls_gemm_qg(const ls_geom& g) { return gemm_qg(g.chunks); }

@@ -34,6 +34,9 @@ typedef unsigned int u32;
 #ifndef LS_SCAN_SMALL_ROWS
 #define LS_SCAN_SMALL_ROWS 64        // ... when no wave sees more rows than this (<= 64: one key per lane)
 #endif
+#ifndef LS_SCAN_MERGE_FILLED
+#define LS_SCAN_MERGE_FILLED 1       // the workgroup merge walks the 4*(k'+1) filled slots instead of all 64
+#endif
 #ifndef LS_SCAN_SMALL_MAX_BLOCKS
 #define LS_SCAN_SMALL_MAX_BLOCKS 256 // ... and the launch has at most one scan workgroup per CU
 #endif

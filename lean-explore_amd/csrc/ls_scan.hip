@@ -338,7 +338,7 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
     for (int qi = wave; qi < NQ; qi += LS_SCAN_WAVES) {  // wave w ranks queries w, w+4, ..
         const u64 mine = sm[qi][lane];  // LS_SCAN_WAVES * LS_KP_MAX == 64 slots
         int rank = 0;
-        if constexpr (SMALL) {  // only the kp slots each wave filled (the others hold 0)
+        if constexpr (SMALL || LS_SCAN_MERGE_FILLED) {  // only the kp slots each wave filled (the others hold 0)
             for (int w = 0; w < LS_SCAN_WAVES; ++w)
                 for (int j = 0; j < kp; ++j) {
                     const int i = w * LS_KP_MAX + j;

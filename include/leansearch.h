@@ -72,6 +72,35 @@ typedef struct ls_index ls_index; /* opaque */
 int ls_create(ls_index** out, const float* corpus, int64_t n, int32_t d, int32_t dtype,
               int32_t device);
 
+/* Row-sharded index over several GPUs of one node, in ONE process and behind the SAME handle type:
+ * every function of this header accepts the handle it returns (the
+ * reference's backend is a single process that owns one index, reference src/lean_explore/mcp/
+ * server.py:147-151, and calls index.search from it, search/engine.py:250).
+ * Shard g holds the contiguous row block [g*ceil(n/G), min(n, (g+1)*ceil(n/G))) on device_ids[g].
+ * A search copies the queries to every device, runs the local exact top-k on all of them
+ * concurrently, exchanges the packed per-shard results [scores | rows | flags] with ONE RCCL
+ * all-gather over xGMI (ncclCommInitAll communicators, bound at first use) and merges the G sorted
+ * lists on device_ids[0] under the total order: results are bit-identical to the unsharded index
+ * for every G. Queries / outputs of ls_search_device live on device_ids[0] (= ls_device()).
+ * Duplicate ids (e.g. {0,0,0}: G shards rehearsed on one GPU) are allowed; they exchange by
+ * device-to-device copies because RCCL needs distinct devices. n_devices == 0 fails with
+ * LS_ERR_NO_DEVICE (there is no CPU backend). LS_FLAG_PIPELINE reaches the shards' batched path
+ * only; on the per-query scan path a sharded handle treats it as LS_FLAG_ASYNC. ls_add appends to
+ * the last shard. ls_export_flags and ls_debug_read_scores are not available on a sharded handle. */
+int ls_create_sharded(ls_index** out, const float* corpus, int64_t n, int32_t d, int32_t dtype,
+                      const int32_t* device_ids, int32_t n_devices);
+
+/* As ls_create_sharded with the row blocks already in HBM: d_blocks[g] is device memory on
+ * device_ids[g], row-major float32 [rows[g], d]; global rows are numbered block after block. */
+int ls_create_sharded_from_device(ls_index** out, const void* const* d_blocks, const int64_t* rows,
+                                  int32_t d, int32_t dtype, const int32_t* device_ids,
+                                  int32_t n_devices);
+
+/* Number of shards of a handle (0 for a plain single-device handle) and one shard's placement. */
+int32_t ls_shard_count(const ls_index* index);
+int ls_shard_info(const ls_index* index, int32_t shard, int32_t* device, int64_t* row0,
+                  int64_t* rows);
+
 /* As ls_create, but `d_corpus` is device memory on `device`, row-major float32 [n, d]
  * (used to build multi-GB synthetic shards without a host round trip). */
 int ls_create_from_device(ls_index** out, const void* d_corpus, int64_t n, int32_t d,
@@ -165,8 +194,16 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * group on the next scan launch (default on); option 4: allow the batched MFMA path (default on);
  * option 5: speculative, verified sample threshold on the batched path (default on; off = the
  * certified k-th sample score); option 6: several queries per corpus pass on the scan path
- * (default on); option 7: force the number of scan workgroups per launch (0 = automatic).
- * counter 9: kernel launches of the most recent batched call.
+ * (default on); option 7: force the number of scan workgroups per launch (0 = automatic);
+ * option 8 (sharded handles): exchange step 0 = RCCL all-gather between distinct devices (default),
+ * 1 = peer copies into the primary device's gather buffer.
+ * counter 9: kernel launches the most recent batched call queued (counted per launch);
+ * counter 10: path of the most recent search (1 per-query scan, 2 fp16 MFMA, 3 fp32 MFMA);
+ * counter 11: kernel launches queued by searches on this handle so far; counter 12: batched calls
+ * that were cut into sub-batches because the candidate queues could not hold the whole batch;
+ * sharded handles: counter 13 exchange steps run, 14 re-exchanges after a shard repaired a
+ * query, 15 exchange transport (0 copies, 1 RCCL selected, 2 RCCL communicators initialised);
+ * counters 0, 1, 8, 11, 12 are summed over the shards, 9 and 10 are the primary shard's.
  * counter 0: searches whose finalize step left the fast path (rescue or general); counter 1:
  * those that took the general path; counter 8: queries of batched calls that were repaired by
  * the exact scan path. */

@@ -3,7 +3,7 @@
 //
 // There is deliberately no CPU path in this library: with no HIP device every compute entry
 // point returns LS_ERR_NO_DEVICE.
-#include "ls_common.h"
+#include "ls_index.h"
 
 #include <immintrin.h>
 
@@ -17,14 +17,6 @@
 #include <new>
 #include <vector>
 
-#define LS_NSETS 2
-#define LS_BC_SLOTS 16
-#ifndef LS_BC_LANES
-#define LS_BC_LANES 2  // internal streams (with their own scratch) that LS_FLAG_PIPELINE batches rotate over
-#endif
-#define LS_BC_SETS (1 + LS_BC_LANES)  // batched scratch sets: 0 = caller's stream, then the lanes
-#define LS_PROF_MAX 4096
-
 static thread_local char g_err[512] = "";
 
 void ls_set_error(const char* fmt, ...) {
@@ -34,110 +26,7 @@ void ls_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-struct ls_index {
-    int32_t device = 0;
-    int32_t n_cu = 256;
-    int64_t n = 0;
-    int32_t dtype = 0;
-    int64_t base = 0;
-    ls_geom g{};
-    void* d_corpus = nullptr;
-    std::mutex mu;
-    hipStream_t own_stream = nullptr;
-
-    // scratch (grown on demand, reused by every search on this handle)
-    float* d_qraw = nullptr;   size_t qraw_cap = 0;   // floats
-    // per-query scan scratch, LS_NSETS generations: launch i's piggy-backed finalize of group i-1
-    // reads one generation while its scan of group i fills the other
-    struct scratch_set {
-        float* d_S = nullptr;        // n floats
-        u64* d_cand = nullptr;       // max_blocks * LS_KP_MAX
-        u64* d_bound = nullptr;      // max_blocks
-    } sets[LS_NSETS];
-    hipStream_t last_scan_stream = nullptr;
-    bool scan_used = false;
-    uint64_t set_rr = 0;
-    int32_t last_set = 0;
-    // batched (MFMA) path scratch, allocated on first use. Set 0 serves plain calls on the
-    // caller's stream: a handle that only ever sees one stream pays nothing for sharing it; the
-    // first call on a second stream synchronises the previous one and switches the set to
-    // multi-stream mode, where `done` is recorded behind the last kernel of every call and
-    // waited for by the next call's stream (an event record costs a few us of GPU time per
-    // batch: a barrier packet with a release). Sets 1 .. LS_BC_LANES are the internal LANES of
-    // LS_FLAG_PIPELINE calls: consecutive batches rotate over them, each lane on its own
-    // stream, so that one batch's latency-bound small kernels (prep, tau, select) and kernel
-    // boundaries overlap the other batch's MFMA pass.
-    struct bc_set {
-        void* d_qh = nullptr;      size_t qh_cap = 0;       // bytes: fp16 queries [nq_pad, d_pad]
-        u64* d_queues = nullptr;   size_t queues_cap = 0;   // private candidate queues
-        u32* d_counts = nullptr;   size_t counts_cap = 0;
-        float* d_tau = nullptr;    size_t tau_cap = 0;
-        u32* d_sample_top = nullptr; size_t sample_top_cap = 0;  // best sample scores per lane
-        hipEvent_t done = nullptr;        // set 0, multi-stream mode
-        hipStream_t last_stream = nullptr;
-        bool used = false;
-        bool multi_stream = false;
-        hipStream_t lane_stream = nullptr;  // sets 1 .. LS_BC_LANES
-        hipEvent_t lane_in = nullptr;       // recorded on the caller's stream, waited for by the lane
-        hipEvent_t lane_q = nullptr;        // the lane has consumed the caller's query buffer
-    } bc_sets[LS_BC_SETS];
-    uint64_t bc_lane_rr = 0;
-    int32_t bc_last_set = 0;  // the set of the most recent batched call (ls_export_flags)
-    u32* d_overflow = nullptr; size_t overflow_cap = 0;
-    u32* h_overflow = nullptr; size_t h_overflow_cap = 0;  // pinned
-    // async batched calls not yet checked: each keeps its own flag slice of d_overflow AND its own
-    // copy of the raw queries (d_qkeep), so that several batches can be in flight before one
-    // ls_check repairs whatever was flagged, whatever the caller did to its query buffer meanwhile
-    struct batched_call {
-        int64_t nq = 0;
-        int32_t k = 0;
-        uint32_t flags = 0;
-        float* d_out_s = nullptr;
-        int64_t* d_out_i = nullptr;
-        hipStream_t stream = nullptr;
-        int32_t slot = 0;
-    };
-    std::vector<batched_call> bc_pending;
-    int64_t bc_slot_stride = 0;  // u32 per flag slot
-    float* d_qkeep = nullptr;  size_t qkeep_cap = 0;  // LS_BC_SLOTS x bc_qkeep_stride floats
-    int64_t bc_qkeep_stride = 0;
-    u32* d_last_flags = nullptr;  // flag slice of the most recent batched call (ls_export_flags)
-    int64_t last_flags_n = 0;
-    uint64_t n_batched_fallback = 0;  // queries repaired by the scan path (host counter)
-    int32_t n_batched_launches = 0;   // kernel launches of the most recent batched call
-    int32_t opt_gemm = 1;             // allow the batched MFMA path
-    int32_t opt_spec_tau = 1;         // speculative (verified) sample threshold
-
-    int n_pending = 0;                 // queries whose finalize has not been launched yet
-    ls_fin_batch pending{};
-    hipStream_t pending_stream = nullptr;
-    float* d_qpad = nullptr; size_t qpad_cap = 0;  // padded query group (ragged last group)
-    long long s_stride = 0;            // floats between the score vectors of one generation
-    int32_t opt_multi_query = 1;       // several queries per corpus pass (groups of 8 / 4)
-    int32_t max_blocks = 0;
-    float* d_out_s = nullptr;  int64_t* d_out_i = nullptr;  size_t out_cap = 0;  // nq*k
-    u32* d_counters = nullptr;                        // [0] finalize slow-path count
-    u32* h_done = nullptr;     // pinned [LS_SCAN_MAX_NQ]: completion words of the host API
-    u32 done_seq = 0;
-    u32* done_base = nullptr;  // set by ls_search around its scan-path call, else null
-    float* h_q = nullptr;      size_t h_q_cap = 0;    // pinned
-    float* h_out_s = nullptr;  int64_t* h_out_i = nullptr;  size_t h_out_cap = 0;
-
-    // options / instrumentation
-    int32_t opt_kprime = 0;  // 0 = automatic
-    int32_t opt_blocks = 0;  // 0 = automatic (scan workgroups per launch)
-    int32_t opt_force_slow = 0;
-    int32_t opt_overlap = 1;    // finalize of group i-1 rides on the scan launch of group i
-    int32_t opt_alternate = 0;  // alternate sweep direction between consecutive scans
-    uint64_t sweep_count = 0;
-    // profiling: hipEvent pairs around EVERY scan launch (and the finalize after it), recorded
-    // on the stream the kernels run on, up to LS_PROF_MAX launches; read by ls_last_kernel_ms
-    bool profiling = false;
-    std::vector<hipEvent_t> prof_ev;  // 2 events per launch: begin, end
-    size_t prof_n = 0;
-};
-
-static int check_device(int32_t device) {
+int ls_i_check_device(int32_t device) {
     int cnt = 0;
     hipError_t e = hipGetDeviceCount(&cnt);
     if (e != hipSuccess || cnt <= 0) {
@@ -149,29 +38,6 @@ static int check_device(int32_t device) {
         ls_set_error("device %d out of range (have %d)", device, cnt);
         return LS_ERR_NO_DEVICE;
     }
-    return LS_OK;
-}
-
-template <typename T>
-static int grow(T** p, size_t* cap, size_t need) {
-    if (need <= *cap) return LS_OK;
-    if (*p) LS_HIP(hipFree(*p));
-    *p = nullptr;
-    *cap = 0;
-    size_t want = need + need / 2;
-    LS_HIP(hipMalloc((void**)p, want * sizeof(T)));
-    *cap = want;
-    return LS_OK;
-}
-template <typename T>
-static int grow_pinned(T** p, size_t* cap, size_t need) {
-    if (need <= *cap) return LS_OK;
-    if (*p) LS_HIP(hipHostFree(*p));
-    *p = nullptr;
-    *cap = 0;
-    size_t want = need + need / 2;
-    LS_HIP(hipHostMalloc((void**)p, want * sizeof(T), hipHostMallocDefault));
-    *cap = want;
     return LS_OK;
 }
 
@@ -196,7 +62,7 @@ static int create_common(ls_index** out, int64_t n, int32_t d, int32_t dtype, in
                      dtype);
         return LS_ERR_INVALID_ARG;
     }
-    int rc = check_device(device);
+    int rc = ls_i_check_device(device);
     if (rc != LS_OK) return rc;
     LS_HIP(hipSetDevice(device));
     ls_index* ix = new (std::nothrow) ls_index();
@@ -217,40 +83,78 @@ static int create_common(ls_index** out, int64_t n, int32_t d, int32_t dtype, in
 }
 
 // (Re)allocate what depends on the row count: the corpus with its zero pad rows (old rows are
-// carried over device-to-device when the index grows) and the scan path's per-query scratch.
-static int alloc_rows(ls_index* ix, int64_t new_n) {
+// carried over device-to-device when the index grows) and the scan path's score vectors. Nothing
+// of the handle changes unless every allocation succeeded. `amortise`: grow the capacity
+// geometrically (index.add in a loop stays linear in the rows added).
+static int alloc_rows(ls_index* ix, int64_t new_n, bool amortise) {
     const size_t row_bytes = (size_t)ix->g.chunks * 16;
-    // the batched path reads whole tiles: keep LS_CORPUS_PAD_ROWS zero rows past n
-    void* d_new = nullptr;
-    if (new_n > 0) {
-        LS_HIP(hipMalloc(&d_new, (size_t)(new_n + LS_CORPUS_PAD_ROWS) * row_bytes));
-        if (ix->d_corpus && ix->n > 0)
-            LS_HIP(hipMemcpy(d_new, ix->d_corpus, (size_t)std::min(ix->n, new_n) * row_bytes,
-                             hipMemcpyDeviceToDevice));
-        LS_HIP(hipMemset((char*)d_new + (size_t)new_n * row_bytes, 0,
+    if (ix->max_blocks == 0) {
+        // ls_scan_blocks() <= 2 workgroups per CU; room for the tuning hook (debug option 7) to
+        // force up to 4 per CU
+        ix->max_blocks = 4 * ix->n_cu;
+        for (auto& st : ix->sets) {  // room for LS_SCAN_NQ_MAX queries per generation
+            LS_HIP(hipMalloc((void**)&st.d_cand,
+                             sizeof(u64) * (size_t)ix->max_blocks * LS_KP_MAX * LS_SCAN_NQ_MAX));
+            LS_HIP(hipMalloc((void**)&st.d_bound,
+                             sizeof(u64) * (size_t)ix->max_blocks * LS_SCAN_NQ_MAX));
+        }
+    }
+    if (new_n > ix->cap_rows || !ix->sets[0].d_S) {
+        int64_t want = std::max<int64_t>(new_n, 1);
+        if (amortise && ix->cap_rows > 0)
+            want = std::min<int64_t>(std::max(want, ix->cap_rows + ix->cap_rows / 2), 0xfffffffell);
+        void* d_new = nullptr;
+        float* S_new[LS_NSETS] = {};
+        long long stride = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            stride = (want + 63) / 64 * 64;
+            bool ok = new_n == 0 ||
+                      hipMalloc(&d_new, (size_t)(want + LS_CORPUS_PAD_ROWS) * row_bytes) == hipSuccess;
+            for (int i = 0; ok && i < LS_NSETS; ++i)
+                ok = hipMalloc((void**)&S_new[i], sizeof(float) * (size_t)stride * LS_SCAN_NQ_MAX) ==
+                     hipSuccess;
+            if (ok) break;
+            (void)hipGetLastError();
+            (void)hipFree(d_new);
+            d_new = nullptr;
+            for (auto& p : S_new) {
+                (void)hipFree(p);
+                p = nullptr;
+            }
+            if (attempt == 1 || want == std::max<int64_t>(new_n, 1)) {
+                ls_set_error("out of device memory for %lld rows of %zu bytes", (long long)want,
+                             row_bytes);
+                return LS_ERR_HIP;
+            }
+            want = std::max<int64_t>(new_n, 1);  // the amortised size did not fit: exact size
+        }
+        if (d_new && ix->d_corpus && ix->n > 0 &&
+            hipMemcpy(d_new, ix->d_corpus, (size_t)std::min(ix->n, new_n) * row_bytes,
+                      hipMemcpyDeviceToDevice) != hipSuccess) {
+            (void)hipFree(d_new);
+            for (auto& p : S_new) (void)hipFree(p);
+            ls_set_error("carrying the stored rows over failed");
+            return LS_ERR_HIP;
+        }
+        if (ix->d_corpus) (void)hipFree(ix->d_corpus);
+        ix->d_corpus = d_new;
+        for (int i = 0; i < LS_NSETS; ++i) {
+            if (ix->sets[i].d_S) (void)hipFree(ix->sets[i].d_S);
+            ix->sets[i].d_S = S_new[i];
+        }
+        ix->s_stride = stride;
+        ix->cap_rows = new_n > 0 ? want : 0;
+    }
+    // the batched path reads whole tiles: LS_CORPUS_PAD_ROWS zero rows follow row new_n
+    if (ix->d_corpus)
+        LS_HIP(hipMemset((char*)ix->d_corpus + (size_t)new_n * row_bytes, 0,
                          (size_t)LS_CORPUS_PAD_ROWS * row_bytes));
-    }
-    if (ix->d_corpus) LS_HIP(hipFree(ix->d_corpus));
-    ix->d_corpus = d_new;
-    // room for the tuning hook (debug option 7) to force up to 4 workgroups per CU
-    ix->max_blocks = std::max(ls_scan_blocks(new_n > 0 ? new_n : 1, ix->g, ix->n_cu), 4 * ix->n_cu);
-    ix->s_stride = ((new_n > 0 ? new_n : 1) + 63) / 64 * 64;
-    for (auto& st : ix->sets) {  // room for LS_SCAN_NQ_MAX queries per generation
-        if (st.d_S) LS_HIP(hipFree(st.d_S));
-        if (st.d_cand) LS_HIP(hipFree(st.d_cand));
-        if (st.d_bound) LS_HIP(hipFree(st.d_bound));
-        st.d_S = nullptr; st.d_cand = nullptr; st.d_bound = nullptr;
-        LS_HIP(hipMalloc((void**)&st.d_S, sizeof(float) * (size_t)ix->s_stride * LS_SCAN_NQ_MAX));
-        LS_HIP(hipMalloc((void**)&st.d_cand,
-                         sizeof(u64) * (size_t)ix->max_blocks * LS_KP_MAX * LS_SCAN_NQ_MAX));
-        LS_HIP(hipMalloc((void**)&st.d_bound, sizeof(u64) * (size_t)ix->max_blocks * LS_SCAN_NQ_MAX));
-    }
     return LS_OK;
 }
 
 static int alloc_index_buffers(ls_index* ix) {
     LS_HIP(hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking));
-    int rc = alloc_rows(ix, ix->n);
+    int rc = alloc_rows(ix, ix->n, false);
     if (rc != LS_OK) return rc;
     LS_HIP(hipMalloc((void**)&ix->d_counters, sizeof(u32) * 8));
     LS_HIP(hipMemset(ix->d_counters, 0, sizeof(u32) * 8));
@@ -294,6 +198,11 @@ extern "C" {
 
 void ls_destroy(ls_index* ix) {
     if (!ix) return;
+    if (ix->group) {
+        ls_group_destroy(ix);
+        delete ix;
+        return;
+    }
     (void)hipSetDevice(ix->device);
     if (ix->own_stream) (void)hipStreamSynchronize(ix->own_stream);
     (void)hipFree(ix->d_corpus);
@@ -314,6 +223,7 @@ void ls_destroy(ls_index* ix) {
         }
         if (st.lane_in) (void)hipEventDestroy(st.lane_in);
         if (st.lane_q) (void)hipEventDestroy(st.lane_q);
+        if (st.lane_out) (void)hipEventDestroy(st.lane_out);
         if (st.done) (void)hipEventDestroy(st.done);
         (void)hipFree(st.d_qh);
         (void)hipFree(st.d_queues);
@@ -388,6 +298,7 @@ int ls_set_base(ls_index* ix, int64_t base) {
         return LS_ERR_INVALID_ARG;
     }
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->group) return ls_group_set_base(ix, base);
     ix->base = base;
     return LS_OK;
 }
@@ -413,12 +324,13 @@ static size_t ls_fin_lds_bytes_host(int keys_cap, int keff) {
 
 // Launch the pending selection jobs on their own (1024 threads each, LDS for the full
 // 8192-key capacity).
-static int flush_pending(ls_index* ix) {
+int ls_i_flush_pending(ls_index* ix) {
     const int np = ix->n_pending;
     if (np == 0) return LS_OK;
     ix->n_pending = 0;
     ls_fin_batch jobs = ix->pending;
     for (int i = 0; i < np; ++i) jobs.p[i].keys_cap = LS_FINAL_CAP;
+    ix->n_launches_total++;
     return ls_launch_finalize(jobs, np, ix->pending_stream);  // one launch, one workgroup per job
 }
 
@@ -449,7 +361,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
     ix->last_scan_stream = s;
     if (ix->n_pending && (ix->pending_stream != s || !ix->opt_overlap)) {
         hipStream_t old = ix->pending_stream;
-        rc = flush_pending(ix);
+        rc = ls_i_flush_pending(ix);
         if (rc != LS_OK) return rc;
         // a different stream takes over: do not let its scans race the old stream's finalize
         if (old != s) LS_HIP(hipStreamSynchronize(old));
@@ -472,7 +384,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         const int gen = (int)(ix->set_rr++ % LS_NSETS);
         ls_index::scratch_set& st = ix->sets[gen];
         if (ix->n_pending && ix->n <= 0) {  // an empty index launches no scan to ride on
-            rc = flush_pending(ix);
+            rc = ls_i_flush_pending(ix);
             if (rc != LS_OK) return rc;
         }
         ls_scan_args a{};
@@ -483,14 +395,14 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
                 a.nfin = ix->n_pending;
                 a.fin = ix->pending;
             } else {
-                rc = flush_pending(ix);
+                rc = ls_i_flush_pending(ix);
                 if (rc != LS_OK) return rc;
             }
         }
         // padded query slots re-read the last real query (their results are never finalised)
         const float* qsrc = d_q + q0 * g.d;
         if (real < NQ) {
-            rc = grow(&ix->d_qpad, &ix->qpad_cap, (size_t)LS_SCAN_NQ_MAX * g.d);
+            rc = ls_grow(&ix->d_qpad, &ix->qpad_cap, (size_t)LS_SCAN_NQ_MAX * g.d);
             if (rc != LS_OK) return rc;
             for (int i = 0; i < NQ; ++i)
                 LS_HIP(hipMemcpyAsync(ix->d_qpad + (size_t)i * g.d,
@@ -513,6 +425,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         if (prof) LS_HIP(hipEventRecord(pe[0], s));
         rc = ls_launch_scan(ix->d_corpus, ix->n, g, a, s);
         if (rc != LS_OK) return rc;
+        ix->n_launches_total++;
         if (prof) {
             LS_HIP(hipEventRecord(pe[1], s));
             ix->prof_n++;
@@ -540,12 +453,12 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         ix->last_set = gen;
         q0 += real;
     }
-    if (!pipeline || !ix->opt_overlap) return flush_pending(ix);
+    if (!pipeline || !ix->opt_overlap) return ls_i_flush_pending(ix);
     return LS_OK;
 }
 
 // ---- batched MFMA path (ls_gemm.hip) ---------------------------------------------------------------
-static bool batched_eligible(const ls_index* ix, int64_t nq, int32_t k) {
+bool ls_i_batched_eligible(const ls_index* ix, int64_t nq, int32_t k) {
     if (!ix->opt_gemm || k > LS_GEMM_MAX_K) return false;
     const bool big = ix->n >= LS_GEMM_MIN_ROWS ||
                      (ix->n >= LS_GEMM_MIN_ROWS_BIGNQ && nq >= LS_GEMM_BIGNQ);
@@ -556,7 +469,7 @@ static bool batched_eligible(const ls_index* ix, int64_t nq, int32_t k) {
 
 // Re-run the queries of the pending batched calls whose candidate queues overflowed (or were
 // short) through the exact per-query scan path, from the calls' OWN query copies. Synchronises.
-static int batched_repair(ls_index* ix) {
+int ls_i_batched_repair(ls_index* ix) {
     if (ix->bc_pending.empty()) return LS_OK;
     std::vector<ls_index::batched_call> pend;
     pend.swap(ix->bc_pending);
@@ -571,36 +484,136 @@ static int batched_repair(ls_index* ix) {
     for (const auto& bc : pend) {
         const u32* fl = ix->h_overflow + (size_t)bc.slot * ix->bc_slot_stride;
         const float* qk = ix->d_qkeep + (size_t)bc.slot * ix->bc_qkeep_stride;
-        for (int64_t q = 0; q < bc.nq; ++q) {
-            if (!fl[q] || LS_ABL_NOREPAIR) continue;
-            ix->n_batched_fallback++;
+        for (int64_t q = 0; q < bc.nq;) {
+            if (!fl[q] || LS_ABL_NOREPAIR) {
+                ++q;
+                continue;
+            }
+            // a run of flagged neighbours shares corpus passes (the scan path's 8- / 4-query groups)
+            int64_t run = 1;
+            while (q + run < bc.nq && fl[q + run]) ++run;
+            ix->n_batched_fallback += (uint64_t)run;
             any = true;
-            int rc = scan_search_on_stream(ix, qk + q * ix->g.d, 1, bc.k,
+            int rc = scan_search_on_stream(ix, qk + q * ix->g.d, run, bc.k,
                                            bc.flags & LS_FLAG_NORMALIZE, bc.d_out_s + q * bc.k,
                                            bc.d_out_i + q * bc.k, s);
             if (rc != LS_OK) return rc;
+            q += run;
         }
     }
     if (any) LS_HIP(hipStreamSynchronize(s));
     return LS_OK;
 }
 
-static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k,
-                                    uint32_t flags, float* d_out_s, int64_t* d_out_i,
-                                    hipStream_t s) {
-    int rc = flush_pending(ix);
-    if (rc != LS_OK) return rc;
+// Geometry of one batched call: corpus slices, sample thinning, speculative rank, expected passes.
+struct bc_plan {
+    int QT, TM;               // queries per workgroup, corpus rows per LDS tile
+    int64_t nq_pad, rps;      // padded queries, rows per slice
+    int nsplits, sample_stride, jrank, keys_need;
+    double per_queue;         // expected entries of one private candidate queue (capacity LS_GEMM_QCAP)
+};
+static bc_plan bc_make_plan(const ls_index* ix, int64_t nq, int32_t k) {
     const ls_geom& g = ix->g;
     const bool f32 = ix->dtype == LS_DTYPE_F32;
     const int QG = ls_gemm_qg(g);
     const int QT = f32 ? 64 : LS_GEMM_WAVES * 16 * QG;  // queries per workgroup
     const int TM = f32 ? 64 : ls_gemm_tile_rows(g);
     const int64_t nq_pad = (nq + QT - 1) / QT * QT;
+    const int nqt = (int)(nq_pad / QT);
+    // corpus slices: one 8-wave workgroup per CU in total, a multiple of the 8 XCDs. The fp32
+    // kernel is light on registers (two workgroups share a CU) and each workgroup walks two slices.
+    int nsplits = (LS_GEMM_WG_PER_CU * ix->n_cu / nqt) / 8 * 8;
+    nsplits = std::max(8, std::min(nsplits, 256));
+    if (f32) nsplits = 2 * std::max(8, std::min(LS_GEMM_MAX_SPLITS / 2, (2 * ix->n_cu / nqt) / 8 * 8));
+    int64_t rps = (ix->n + nsplits - 1) / nsplits;
+    rps = (rps + TM - 1) / TM * TM;
+    const int tiles_per_split = (int)(rps / TM);
+    // the sample is a fixed FRACTION of the corpus (~1/24 of every slice, at least
+    // LS_GEMM_SAMPLE_ROWS rows; ~1/48 for slices of more than 1536 tiles, where the sample pass
+    // itself is what costs): the expected number of rows passing tau, ~j*N/M0, then does not
+    // grow with N
+    // The fraction thins out on long slices (about 16 tiles per slice up to 1/96 of the rows:
+    // config 4's 12.5 M-row shard spent 7 % of its batch in a 1/24 sample): a thinner sample
+    // passes more rows per query (~j*N/M0 +- that over sqrt(j)), which the select kernel's key
+    // buffer must hold; the fraction is halved until the +5 sigma count fits LS_BSEL_MAX_KEYS.
+    int frac = std::max(24, std::min(96, tiles_per_split / 16));
+    int sample_tiles, sample_stride, jrank, keys_need;
+    double pass_mean = 0.0;
+    for (;; frac /= 2) {
+        sample_tiles = std::max(std::max(1, LS_GEMM_SAMPLE_ROWS / TM),
+                                (tiles_per_split + frac - 1) / frac);
+        sample_stride = std::max(1, (tiles_per_split + sample_tiles - 1) / sample_tiles);
+        // Speculative threshold. The k-th best SAMPLE score is a certified lower bound of the
+        // final k-th best but passes ~k*N/M0 rows per query. The j-th best sample score (j < k)
+        // passes only ~j*N/M0 rows; it is not certified, so the select kernel verifies that at
+        // least k rows passed and flags the query for the exact scan path otherwise. j is the
+        // smallest rank whose expected pass count exceeds k by 4.5 standard deviations (relative
+        // sd of an order statistic ~ 1/sqrt(j)): a flag is a ~1e-5 event per query on
+        // exchangeable rows.
+        jrank = k;
+        const int visited = (tiles_per_split + sample_stride - 1) / sample_stride;
+        const double m0 = (double)nsplits * visited * TM;
+        const double r = (double)ix->n / std::max(1.0, m0);
+        if (ix->opt_spec_tau) {
+            for (int j = 1; j <= k; ++j) {
+                if ((double)j * r * (1.0 - 4.5 / __builtin_sqrt((double)j)) >= (double)k) {
+                    jrank = j;
+                    break;
+                }
+            }
+        }
+        pass_mean = (double)jrank * r;
+        const double expect = pass_mean * (1.0 + 5.0 / __builtin_sqrt((double)jrank));
+        keys_need = (int)std::min(expect, 1e9);
+        if (keys_need <= LS_BSEL_MAX_KEYS || frac <= 24) break;
+    }
+    bc_plan p;
+    p.QT = QT;
+    p.TM = TM;
+    p.nq_pad = nq_pad;
+    p.rps = rps;
+    p.nsplits = nsplits;
+    p.sample_stride = sample_stride;
+    p.jrank = jrank;
+    p.keys_need = keys_need;
+    p.per_queue = pass_mean / ((double)nsplits * 4.0);
+    return p;
+}
+
+// The candidate queues are private per (query, slice, quarter) and hold LS_GEMM_QCAP entries: a
+// batch fits when a queue's expected length leaves 5 sigma of Poisson headroom. nsplits shrinks
+// as n_cu / query tiles, so big batches at big k (nq = 4096, k = 1000: 16 slices) would overflow
+// every queue and send every query to the repair path; such calls are cut into sub-batches.
+static bool bc_plan_fits(const bc_plan& p) {
+    return p.per_queue + 5.0 * __builtin_sqrt(p.per_queue) <= (double)LS_GEMM_QCAP &&
+           p.keys_need <= LS_BSEL_MAX_KEYS;
+}
+// Largest sub-batch (a multiple of the query tile) whose plan fits; 0 = not even one tile does.
+static int64_t bc_chunk(const ls_index* ix, int64_t nq, int32_t k) {
+    bc_plan p = bc_make_plan(ix, nq, k);
+    if (bc_plan_fits(p)) return nq;
+    for (int64_t tiles = p.nq_pad / p.QT / 2; tiles >= 1; tiles /= 2) {
+        p = bc_make_plan(ix, tiles * p.QT, k);
+        if (bc_plan_fits(p)) return tiles * p.QT;
+    }
+    return 0;
+}
+
+static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k,
+                                    uint32_t flags, float* d_out_s, int64_t* d_out_i,
+                                    hipStream_t s) {
+    int rc = ls_i_flush_pending(ix);
+    if (rc != LS_OK) return rc;
+    const ls_geom& g = ix->g;
+    const bool f32 = ix->dtype == LS_DTYPE_F32;
+    const int QG = ls_gemm_qg(g);
+    const int QT = f32 ? 64 : LS_GEMM_WAVES * 16 * QG;  // queries per workgroup
+    const int64_t nq_pad = (nq + QT - 1) / QT * QT;
     const int64_t qkeep_need = nq * g.d;
     if ((int)ix->bc_pending.size() >= LS_BC_SLOTS ||
         (!ix->bc_pending.empty() &&
          (nq_pad > ix->bc_slot_stride || qkeep_need > ix->bc_qkeep_stride))) {
-        rc = batched_repair(ix);  // slots exhausted (or too small): check what is pending
+        rc = ls_i_batched_repair(ix);  // slots exhausted (or too small): check what is pending
         if (rc != LS_OK) return rc;
     }
     const bool lanes = (flags & LS_FLAG_PIPELINE) != 0;
@@ -627,77 +640,35 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
             LS_HIP(hipStreamWaitEvent(s, st.done, 0));
         }
     }
-    const int nqt = (int)(nq_pad / QT);
-    // corpus slices: one 8-wave workgroup per CU in total, a multiple of the 8 XCDs. The fp32
-    // kernel is light on registers (two workgroups share a CU) and each workgroup walks two slices.
-    int nsplits = (LS_GEMM_WG_PER_CU * ix->n_cu / nqt) / 8 * 8;
-    nsplits = std::max(8, std::min(nsplits, 256));
-    if (f32) nsplits = 2 * std::max(8, std::min(LS_GEMM_MAX_SPLITS / 2, (2 * ix->n_cu / nqt) / 8 * 8));
-    int64_t rps = (ix->n + nsplits - 1) / nsplits;
-    rps = (rps + TM - 1) / TM * TM;
-    const int tiles_per_split = (int)(rps / TM);
-    // the sample is a fixed FRACTION of the corpus (~1/24 of every slice, at least
-    // LS_GEMM_SAMPLE_ROWS rows; ~1/48 for slices of more than 1536 tiles, where the sample pass
-    // itself is what costs): the expected number of rows passing tau, ~j*N/M0, then does not
-    // grow with N
-    // The fraction thins out on long slices (about 16 tiles per slice up to 1/96 of the rows:
-    // config 4's 12.5 M-row shard spent 7 % of its batch in a 1/24 sample): a thinner sample
-    // passes more rows per query (~j*N/M0 +- that over sqrt(j)), which the select kernel's key
-    // buffer must hold; the fraction is halved until the +5 sigma count fits LS_BSEL_MAX_KEYS.
-    int frac = std::max(24, std::min(96, tiles_per_split / 16));
-    int sample_tiles, sample_stride, jrank, keys_need;
-    for (;; frac /= 2) {
-        sample_tiles = std::max(std::max(1, LS_GEMM_SAMPLE_ROWS / TM),
-                                (tiles_per_split + frac - 1) / frac);
-        sample_stride = std::max(1, (tiles_per_split + sample_tiles - 1) / sample_tiles);
-        // Speculative threshold. The k-th best SAMPLE score is a certified lower bound of the
-        // final k-th best but passes ~k*N/M0 rows per query. The j-th best sample score (j < k)
-        // passes only ~j*N/M0 rows; it is not certified, so the select kernel verifies that at
-        // least k rows passed and flags the query for the exact scan path otherwise. j is the
-        // smallest rank whose expected pass count exceeds k by 4.5 standard deviations (relative
-        // sd of an order statistic ~ 1/sqrt(j)): a flag is a ~1e-5 event per query on
-        // exchangeable rows.
-        jrank = k;
-        const int visited = (tiles_per_split + sample_stride - 1) / sample_stride;
-        const double m0 = (double)nsplits * visited * TM;
-        const double r = (double)ix->n / std::max(1.0, m0);
-        if (ix->opt_spec_tau) {
-            for (int j = 1; j <= k; ++j) {
-                if ((double)j * r * (1.0 - 4.5 / __builtin_sqrt((double)j)) >= (double)k) {
-                    jrank = j;
-                    break;
-                }
-            }
-        }
-        const double expect = (double)jrank * r * (1.0 + 5.0 / __builtin_sqrt((double)jrank));
-        keys_need = (int)std::min(expect, 1e9);
-        if (keys_need <= LS_BSEL_MAX_KEYS || frac <= 24) break;
-    }
+    const bc_plan plan = bc_make_plan(ix, nq, k);
+    const int nsplits = plan.nsplits, sample_stride = plan.sample_stride, jrank = plan.jrank;
+    const int keys_need = plan.keys_need;
+    const int64_t rps = plan.rps;
     const size_t nrec = (size_t)nq_pad * nsplits;
 
     size_t c;
     c = st.qh_cap;
-    if ((rc = grow((unsigned char**)&st.d_qh, &c, (size_t)nq_pad * g.d_pad * (f32 ? 4 : 2))) != LS_OK)
+    if ((rc = ls_grow((unsigned char**)&st.d_qh, &c, (size_t)nq_pad * g.d_pad * (f32 ? 4 : 2))) != LS_OK)
         return rc;
     st.qh_cap = c;
-    if ((rc = grow(&st.d_queues, &st.queues_cap, nrec * 4 * LS_GEMM_QCAP)) != LS_OK) return rc;
-    if ((rc = grow(&st.d_counts, &st.counts_cap, nrec * 4)) != LS_OK) return rc;
-    if ((rc = grow(&st.d_tau, &st.tau_cap, (size_t)nq_pad)) != LS_OK) return rc;
+    if ((rc = ls_grow(&st.d_queues, &st.queues_cap, nrec * 4 * LS_GEMM_QCAP)) != LS_OK) return rc;
+    if ((rc = ls_grow(&st.d_counts, &st.counts_cap, nrec * 4)) != LS_OK) return rc;
+    if ((rc = ls_grow(&st.d_tau, &st.tau_cap, (size_t)nq_pad)) != LS_OK) return rc;
     if (ix->bc_pending.empty()) {
         if (nq_pad > ix->bc_slot_stride) ix->bc_slot_stride = nq_pad;
         if (qkeep_need > ix->bc_qkeep_stride) ix->bc_qkeep_stride = qkeep_need;
     }
-    if ((rc = grow(&ix->d_overflow, &ix->overflow_cap,
+    if ((rc = ls_grow(&ix->d_overflow, &ix->overflow_cap,
                    (size_t)ix->bc_slot_stride * LS_BC_SLOTS)) != LS_OK)
         return rc;
-    if ((rc = grow(&ix->d_qkeep, &ix->qkeep_cap,
+    if ((rc = ls_grow(&ix->d_qkeep, &ix->qkeep_cap,
                    (size_t)ix->bc_qkeep_stride * LS_BC_SLOTS)) != LS_OK)
         return rc;
     const int slot = (int)ix->bc_pending.size();
     u32* d_flags = ix->d_overflow + (size_t)slot * ix->bc_slot_stride;
     float* d_qkeep = ix->d_qkeep + (size_t)slot * ix->bc_qkeep_stride;
-    if ((rc = grow(&st.d_sample_top, &st.sample_top_cap, nrec * 16)) != LS_OK) return rc;
-    if ((rc = grow_pinned(&ix->h_overflow, &ix->h_overflow_cap,
+    if ((rc = ls_grow(&st.d_sample_top, &st.sample_top_cap, nrec * 16)) != LS_OK) return rc;
+    if ((rc = ls_grow_pinned(&ix->h_overflow, &ix->h_overflow_cap,
                           (size_t)ix->bc_slot_stride * LS_BC_SLOTS)) != LS_OK)
         return rc;
     ls_gemm_bufs bufs;
@@ -730,6 +701,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
              : ls_launch_prep_f16(d_q, st.d_qh, d_qkeep, nq, nq_pad, g,
                                   (flags & LS_FLAG_NORMALIZE) != 0, d_flags, s);
     if (rc != LS_OK) return rc;
+    int launches = 1;  // counted, not assumed: debug counter 9
     if (lanes) {
         // the prep kernel was the only reader of the caller's query buffer (it also took the
         // repair copy): work the caller queues on its stream from here on may overwrite it
@@ -739,12 +711,15 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     // sample pass: a few tiles of every slice, spread over the slice
     rc = pass(nullptr, sample_stride);
     if (rc != LS_OK) return rc;
+    ++launches;
     rc = ls_launch_tau(st.d_sample_top, nsplits, nq, nq_pad, jrank, st.d_tau, s);
     if (rc != LS_OK) return rc;
+    ++launches;
     // full pass
     if (prof) LS_HIP(hipEventRecord(pe[0], s));
     rc = pass(st.d_tau, 1);
     if (rc != LS_OK) return rc;
+    ++launches;
     if (prof) {
         LS_HIP(hipEventRecord(pe[1], s));
         ix->prof_n++;
@@ -752,11 +727,14 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     rc = ls_launch_batch_select(bufs, nsplits, nq, k, keys_need, ix->base, ix->n, rps, d_out_s, d_out_i,
                                 s);
     if (rc != LS_OK) return rc;
+    ++launches;
     if (st.multi_stream) LS_HIP(hipEventRecord(st.done, s));
     st.used = true;
     st.last_stream = s;
     ix->bc_last_set = set_id;
-    ix->n_batched_launches = 5;
+    ix->n_batched_launches = launches;
+    ix->n_launches_total += (uint64_t)launches;
+    ix->last_path = f32 ? 3 : 2;
     ix->d_last_flags = d_flags;
     ix->last_flags_n = nq;
     ls_index::batched_call bc;
@@ -768,23 +746,41 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     bc.stream = s;
     bc.slot = slot;
     ix->bc_pending.push_back(bc);
-    if (!(flags & (LS_FLAG_ASYNC | LS_FLAG_PIPELINE))) return batched_repair(ix);
+    if (!(flags & (LS_FLAG_ASYNC | LS_FLAG_PIPELINE))) return ls_i_batched_repair(ix);
     return LS_OK;
 }
 
-static int search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
-                            float* d_out_s, int64_t* d_out_i, hipStream_t s, bool host_api) {
-    if (batched_eligible(ix, nq, k)) {
+int ls_i_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
+                          float* d_out_s, int64_t* d_out_i, hipStream_t s, bool host_api) {
+    const int64_t chunk = ls_i_batched_eligible(ix, nq, k) ? bc_chunk(ix, nq, k) : 0;
+    if (chunk >= nq) {
         // the host API synchronises anyway: repair right away
         uint32_t f = host_api ? (flags & ~(LS_FLAG_ASYNC | LS_FLAG_PIPELINE)) : flags;
         return batched_search_on_stream(ix, d_q, nq, k, f, d_out_s, d_out_i, s);
     }
+    if (chunk > 0) {
+        // The candidate queues cannot hold the whole batch (big nq x big k leaves too few corpus
+        // slices per query tile): sub-batches, each verified and repaired before the next, so the
+        // call is exact when it returns whatever the flags say (rare shape; it trades the
+        // asynchrony for not sending every query through the repair path).
+        for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+            const int64_t m = std::min(chunk, nq - q0);
+            int rc = batched_search_on_stream(ix, d_q + q0 * ix->g.d, m, k, flags & LS_FLAG_NORMALIZE,
+                                              d_out_s + q0 * k, d_out_i + q0 * k, s);
+            if (rc != LS_OK) return rc;
+        }
+        ix->d_last_flags = nullptr;  // already repaired: nothing provisional to export
+        ix->last_flags_n = 0;
+        ix->n_chunked_calls++;
+        return LS_OK;
+    }
     ix->d_last_flags = nullptr;  // the scan path is exact in stream order: nothing to verify
     ix->last_flags_n = 0;
+    ix->last_path = 1;
     return scan_search_on_stream(ix, d_q, nq, k, flags, d_out_s, d_out_i, s);
 }
 
-static int check_search_args(const ls_index* ix, const void* q, int64_t nq, int32_t k,
+int ls_i_check_search_args(const ls_index* ix, const void* q, int64_t nq, int32_t k,
                              uint32_t flags, const void* os, const void* oi) {
     if (!ix) {
         ls_set_error("search: index is null");
@@ -811,26 +807,29 @@ extern "C" {
 
 int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flags,
               float* out_scores, int64_t* out_indices) {
-    int rc = check_search_args(ix, q, nq, k, flags & ~(LS_FLAG_ASYNC | LS_FLAG_PIPELINE), out_scores,
+    int rc = ls_i_check_search_args(ix, q, nq, k, flags & ~(LS_FLAG_ASYNC | LS_FLAG_PIPELINE), out_scores,
                                out_indices);
     if (rc != LS_OK) return rc;
     if (nq == 0) return LS_OK;
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->group)
+        return ls_group_search(ix, q, true, nq, k, flags & LS_FLAG_NORMALIZE, out_scores, out_indices,
+                               nullptr);
     LS_HIP(hipSetDevice(ix->device));
     hipStream_t s = ix->own_stream;
     const size_t qn = (size_t)nq * ix->g.d, on = (size_t)nq * k;
-    if ((rc = grow(&ix->d_qraw, &ix->qraw_cap, qn)) != LS_OK) return rc;
-    if ((rc = grow_pinned(&ix->h_q, &ix->h_q_cap, qn)) != LS_OK) return rc;
+    if ((rc = ls_grow(&ix->d_qraw, &ix->qraw_cap, qn)) != LS_OK) return rc;
+    if ((rc = ls_grow_pinned(&ix->h_q, &ix->h_q_cap, qn)) != LS_OK) return rc;
     if (on > ix->out_cap) {
         size_t c1 = ix->out_cap, c2 = ix->out_cap;
-        if ((rc = grow(&ix->d_out_s, &c1, on)) != LS_OK) return rc;
-        if ((rc = grow(&ix->d_out_i, &c2, on)) != LS_OK) return rc;
+        if ((rc = ls_grow(&ix->d_out_s, &c1, on)) != LS_OK) return rc;
+        if ((rc = ls_grow(&ix->d_out_i, &c2, on)) != LS_OK) return rc;
         ix->out_cap = std::min(c1, c2);
     }
     if (on > ix->h_out_cap) {
         size_t c1 = ix->h_out_cap, c2 = ix->h_out_cap;
-        if ((rc = grow_pinned(&ix->h_out_s, &c1, on)) != LS_OK) return rc;
-        if ((rc = grow_pinned(&ix->h_out_i, &c2, on)) != LS_OK) return rc;
+        if ((rc = ls_grow_pinned(&ix->h_out_s, &c1, on)) != LS_OK) return rc;
+        if ((rc = ls_grow_pinned(&ix->h_out_i, &c2, on)) != LS_OK) return rc;
         ix->h_out_cap = std::min(c1, c2);
     }
     // Pinned host buffers are device-visible: kernels read the queries from h_q and write the
@@ -842,7 +841,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
     // in pinned host memory once its (pinned) output rows are visible; the host spins on those
     // words instead of sleeping in hipStreamSynchronize (whose wake-up costs more than the
     // 47 us scan's launch). Falls back to the stream sync after 2 ms.
-    const bool spin = in_direct && out_direct && !batched_eligible(ix, nq, k) && ix->n > 0;
+    const bool spin = in_direct && out_direct && !ls_i_batched_eligible(ix, nq, k) && ix->n > 0;
     if (spin && !ix->h_done) {
         LS_HIP(hipHostMalloc((void**)&ix->h_done, sizeof(u32) * LS_SCAN_MAX_NQ, hipHostMallocDefault));
         memset(ix->h_done, 0, sizeof(u32) * LS_SCAN_MAX_NQ);
@@ -854,7 +853,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         if (++ix->done_seq == 0) ix->done_seq = 1;
         ix->done_base = ix->h_done;
     }
-    rc = search_on_stream(ix, in_direct ? ix->h_q : ix->d_qraw, nq, k, flags & LS_FLAG_NORMALIZE,
+    rc = ls_i_search_on_stream(ix, in_direct ? ix->h_q : ix->d_qraw, nq, k, flags & LS_FLAG_NORMALIZE,
                           out_direct ? ix->h_out_s : ix->d_out_s,
                           out_direct ? ix->h_out_i : ix->d_out_i, s, true);
     ix->done_base = nullptr;
@@ -887,13 +886,16 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
 
 int ls_search_device(ls_index* ix, const void* d_q, int64_t nq, int32_t k, uint32_t flags,
                      void* d_out_scores, void* d_out_indices, void* stream) {
-    int rc = check_search_args(ix, d_q, nq, k, flags, d_out_scores, d_out_indices);
+    int rc = ls_i_check_search_args(ix, d_q, nq, k, flags, d_out_scores, d_out_indices);
     if (rc != LS_OK) return rc;
     if (nq == 0) return LS_OK;
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->group)
+        return ls_group_search(ix, (const float*)d_q, false, nq, k, flags, (float*)d_out_scores,
+                               (int64_t*)d_out_indices, (hipStream_t)stream);
     LS_HIP(hipSetDevice(ix->device));
     hipStream_t s = (hipStream_t)stream;
-    rc = search_on_stream(ix, (const float*)d_q, nq, k, flags, (float*)d_out_scores,
+    rc = ls_i_search_on_stream(ix, (const float*)d_q, nq, k, flags, (float*)d_out_scores,
                           (int64_t*)d_out_indices, s, false);
     if (rc != LS_OK) return rc;
     if (!(flags & (LS_FLAG_ASYNC | LS_FLAG_PIPELINE))) LS_HIP(hipStreamSynchronize(s));
@@ -906,10 +908,11 @@ int ls_check(ls_index* ix, void* stream) {
         return LS_ERR_INVALID_ARG;
     }
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->group) return ls_group_check(ix, (hipStream_t)stream);
     LS_HIP(hipSetDevice(ix->device));
-    int rc = flush_pending(ix);
+    int rc = ls_i_flush_pending(ix);
     if (rc != LS_OK) return rc;
-    rc = batched_repair(ix);  // queries whose candidate queues overflowed: exact scan path
+    rc = ls_i_batched_repair(ix);  // queries whose candidate queues overflowed: exact scan path
     if (rc != LS_OK) return rc;
     LS_HIP(hipStreamSynchronize((hipStream_t)stream));
     return LS_OK;
@@ -924,21 +927,29 @@ int ls_add(ls_index* ix, const float* rows, int64_t n_add) {
     }
     if (n_add == 0) return LS_OK;
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->group) return ls_group_add(ix, rows, n_add);
     if (ix->n + n_add >= 0xffffffffll) {
         ls_set_error("ls_add: %lld rows exceed the 2^32-1 rows one shard can index",
                      (long long)(ix->n + n_add));
         return LS_ERR_INVALID_ARG;
     }
     LS_HIP(hipSetDevice(ix->device));
-    int rc = flush_pending(ix);
-    if (rc == LS_OK) rc = batched_repair(ix);
+    int rc = ls_i_flush_pending(ix);
+    if (rc == LS_OK) rc = ls_i_batched_repair(ix);
     if (rc != LS_OK) return rc;
     LS_HIP(hipDeviceSynchronize());  // nothing queued on any stream may still read the old buffers
     const int64_t old_n = ix->n;
-    rc = alloc_rows(ix, old_n + n_add);
+    rc = alloc_rows(ix, old_n + n_add, true);  // on failure the handle is unchanged
     if (rc != LS_OK) return rc;
-    ix->n = old_n + n_add;
-    return upload_rows(ix, old_n, rows, n_add);
+    rc = upload_rows(ix, old_n, rows, n_add);
+    if (rc != LS_OK) {
+        // the new rows never became searchable: restore the zero pad rows behind the old ones
+        (void)hipMemset((char*)ix->d_corpus + (size_t)old_n * ix->g.chunks * 16, 0,
+                        (size_t)LS_CORPUS_PAD_ROWS * ix->g.chunks * 16);
+        return rc;
+    }
+    ix->n = old_n + n_add;  // committed only after the rows are in HBM
+    return LS_OK;
 }
 
 // index.reconstruct_n(row0, count): the stored rows as float32 [count, d] in host memory (fp16
@@ -950,6 +961,7 @@ int ls_reconstruct(ls_index* ix, int64_t row0, int64_t count, float* out) {
     }
     if (count == 0) return LS_OK;
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->group) return ls_group_reconstruct(ix, row0, count, out);
     LS_HIP(hipSetDevice(ix->device));
     const ls_geom& g = ix->g;
     const char* src = (const char*)ix->d_corpus + (size_t)row0 * g.chunks * 16;
@@ -992,7 +1004,7 @@ int ls_normalize_l2(float* x, int64_t nq, int32_t d, int32_t device) {
         ls_set_error("ls_normalize_l2: bad argument");
         return LS_ERR_INVALID_ARG;
     }
-    int rc = check_device(device);
+    int rc = ls_i_check_device(device);
     if (rc != LS_OK) return rc;
     if (nq == 0) return LS_OK;
     if (device >= 64) {
@@ -1012,8 +1024,8 @@ int ls_normalize_l2(float* x, int64_t nq, int32_t d, int32_t device) {
         const size_t cnt = (size_t)rows * d;
         if (cnt > nc.cap) {
             size_t c1 = nc.cap, c2 = nc.cap;
-            if ((rc = grow_pinned(&nc.h_in, &c1, cnt)) != LS_OK) return rc;
-            if ((rc = grow_pinned(&nc.h_out, &c2, cnt)) != LS_OK) return rc;
+            if ((rc = ls_grow_pinned(&nc.h_in, &c1, cnt)) != LS_OK) return rc;
+            if ((rc = ls_grow_pinned(&nc.h_out, &c2, cnt)) != LS_OK) return rc;
             nc.cap = std::min(c1, c2);
         }
         memcpy(nc.h_in, x + r0 * d, cnt * sizeof(float));
@@ -1035,13 +1047,31 @@ int ls_export_flags(ls_index* ix, void* d_dst, int64_t nq, void* stream) {
     }
     if (nq == 0) return LS_OK;
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->group) {
+        ls_set_error("ls_export_flags: not available on a sharded handle (its shards' flags travel "
+                     "with the exchange; ls_check repairs and re-merges)");
+        return LS_ERR_INVALID_ARG;
+    }
     LS_HIP(hipSetDevice(ix->device));
-    hipStream_t s = (hipStream_t)stream;
+    return ls_i_export_flags(ix, d_dst, nq, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+int ls_i_export_flags(ls_index* ix, void* d_dst, int64_t nq, hipStream_t s) {
     if (ix->d_last_flags && ix->last_flags_n == nq) {
-        const ls_index::bc_set& st = ix->bc_sets[ix->bc_last_set];
+        ls_index::bc_set& st = ix->bc_sets[ix->bc_last_set];
         if (st.last_stream != s) {  // flags are written on the search's stream (or lane)
-            if (st.multi_stream) LS_HIP(hipStreamWaitEvent(s, st.done, 0));
-            else LS_HIP(hipStreamSynchronize(st.last_stream));
+            if (st.lane_stream) {
+                // a lane is the library's own stream: order `s` behind it with an event
+                if (!st.lane_out) LS_HIP(hipEventCreateWithFlags(&st.lane_out, hipEventDisableTiming));
+                LS_HIP(hipEventRecord(st.lane_out, st.lane_stream));
+                LS_HIP(hipStreamWaitEvent(s, st.lane_out, 0));
+            } else if (st.multi_stream) {
+                LS_HIP(hipStreamWaitEvent(s, st.done, 0));
+            } else {
+                LS_HIP(hipStreamSynchronize(st.last_stream));
+            }
         }
         LS_HIP(hipMemcpyAsync(d_dst, ix->d_last_flags, sizeof(u32) * (size_t)nq,
                               hipMemcpyDeviceToDevice, s));
@@ -1051,6 +1081,8 @@ int ls_export_flags(ls_index* ix, void* d_dst, int64_t nq, void* stream) {
     return LS_OK;
 }
 
+extern "C" {
+
 int ls_merge_topk(const void* d_scores_in, const void* d_indices_in, int32_t n_lists, int64_t nq,
                   int32_t k, void* d_out_scores, void* d_out_indices, int32_t device,
                   void* stream) {
@@ -1059,7 +1091,7 @@ int ls_merge_topk(const void* d_scores_in, const void* d_indices_in, int32_t n_l
         ls_set_error("ls_merge_topk: bad argument");
         return LS_ERR_INVALID_ARG;
     }
-    int rc = check_device(device);
+    int rc = ls_i_check_device(device);
     if (rc != LS_OK) return rc;
     LS_HIP(hipSetDevice(device));
     return ls_launch_merge((const float*)d_scores_in, (const int64_t*)d_indices_in,
@@ -1076,7 +1108,7 @@ int ls_merge_topk_strided(const void* d_scores_in, const void* d_indices_in,
         ls_set_error("ls_merge_topk_strided: bad argument");
         return LS_ERR_INVALID_ARG;
     }
-    int rc = check_device(device);
+    int rc = ls_i_check_device(device);
     if (rc != LS_OK) return rc;
     LS_HIP(hipSetDevice(device));
     return ls_launch_merge((const float*)d_scores_in, (const int64_t*)d_indices_in,
@@ -1087,6 +1119,7 @@ int ls_merge_topk_strided(const void* d_scores_in, const void* d_indices_in,
 int ls_set_profiling(ls_index* ix, int32_t enabled) {
     if (!ix) return LS_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->group) return ls_group_set_profiling(ix, enabled);
     ix->profiling = enabled != 0;
     ix->prof_n = 0;
     return LS_OK;
@@ -1095,6 +1128,7 @@ int ls_set_profiling(ls_index* ix, int32_t enabled) {
 int ls_last_kernel_ms(ls_index* ix, float* scan_ms, float* total_ms) {
     if (!ix || !scan_ms || !total_ms) return LS_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->group) return ls_group_last_kernel_ms(ix, scan_ms, total_ms);
     if (ix->prof_n == 0) {
         ls_set_error("ls_last_kernel_ms: no profiled search recorded");
         return LS_ERR_INVALID_ARG;
@@ -1119,6 +1153,7 @@ int ls_last_kernel_ms(ls_index* ix, float* scan_ms, float* total_ms) {
 int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
     if (!ix) return LS_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->group) return ls_group_debug_option(ix, which, value);
     if (which == 0) {  // force k' (0 = automatic)
         ix->opt_kprime = value;
         return LS_OK;
@@ -1156,7 +1191,7 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
 }
 
 int ls_debug_read_scores(ls_index* ix, float* out, int64_t count) {
-    if (!ix || !out || count < 0 || count > ix->n) return LS_ERR_INVALID_ARG;
+    if (!ix || !out || count < 0 || count > ix->n || ix->group) return LS_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ix->mu);
     LS_HIP(hipSetDevice(ix->device));
     LS_HIP(hipDeviceSynchronize());
@@ -1190,10 +1225,15 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 9) return -1;
+    if (!ix || which < 0 || which > 15) return -1;
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->group) return ls_group_debug_counter(ix, which);
     if (which == 8) return (int64_t)ix->n_batched_fallback;
     if (which == 9) return (int64_t)ix->n_batched_launches;
+    if (which == 10) return (int64_t)ix->last_path;
+    if (which == 11) return (int64_t)ix->n_launches_total;
+    if (which == 12) return (int64_t)ix->n_chunked_calls;
+    if (which > 9) return 0;  // 13..15 are group counters
     if (hipSetDevice(ix->device) != hipSuccess) return -1;
     u32 v = 0;
     if (hipMemcpy(&v, ix->d_counters + which, sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess)

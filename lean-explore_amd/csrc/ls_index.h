@@ -1,0 +1,179 @@
+// ls_index.h — private: the index handle behind include/leansearch.h's opaque `ls_index`, shared by
+// ls_api.hip (single-device orchestration) and ls_shard.hip (the row-sharded group handle).
+#pragma once
+#include "ls_common.h"
+
+#include <cstddef>
+#include <mutex>
+#include <vector>
+
+struct ls_shard_group;  // ls_shard.hip
+
+#define LS_NSETS 2
+#define LS_BC_SLOTS 16
+#ifndef LS_BC_LANES
+#define LS_BC_LANES 2  // internal streams (with their own scratch) that LS_FLAG_PIPELINE batches rotate over
+#endif
+#define LS_BC_SETS (1 + LS_BC_LANES)  // batched scratch sets: 0 = caller's stream, then the lanes
+#define LS_PROF_MAX 4096
+
+struct ls_index {
+    int32_t device = 0;
+    int32_t n_cu = 256;
+    int64_t n = 0;
+    int32_t dtype = 0;
+    int64_t base = 0;
+    ls_geom g{};
+    void* d_corpus = nullptr;
+    int64_t cap_rows = 0;  // rows d_corpus has room for (+ LS_CORPUS_PAD_ROWS); >= n
+    std::mutex mu;
+    hipStream_t own_stream = nullptr;
+    // non-null: this handle is a row-sharded GROUP (ls_create_sharded): `n`, `dtype`, `g` and
+    // `device` (the primary shard's) describe the whole index, every other member below is unused
+    // and the per-device sub-handles live in the group (ls_shard.hip)
+    ls_shard_group* group = nullptr;
+
+    // scratch (grown on demand, reused by every search on this handle)
+    float* d_qraw = nullptr;   size_t qraw_cap = 0;   // floats
+    // per-query scan scratch, LS_NSETS generations: launch i's piggy-backed finalize of group i-1
+    // reads one generation while its scan of group i fills the other
+    struct scratch_set {
+        float* d_S = nullptr;        // n floats
+        u64* d_cand = nullptr;       // max_blocks * LS_KP_MAX
+        u64* d_bound = nullptr;      // max_blocks
+    } sets[LS_NSETS];
+    hipStream_t last_scan_stream = nullptr;
+    bool scan_used = false;
+    uint64_t set_rr = 0;
+    int32_t last_set = 0;
+    // batched (MFMA) path scratch, allocated on first use. Set 0 serves plain calls on the
+    // caller's stream: a handle that only ever sees one stream pays nothing for sharing it; the
+    // first call on a second stream synchronises the previous one and switches the set to
+    // multi-stream mode, where `done` is recorded behind the last kernel of every call and
+    // waited for by the next call's stream (an event record costs a few us of GPU time per
+    // batch: a barrier packet with a release). Sets 1 .. LS_BC_LANES are the internal LANES of
+    // LS_FLAG_PIPELINE calls: consecutive batches rotate over them, each lane on its own
+    // stream, so that one batch's latency-bound small kernels (prep, tau, select) and kernel
+    // boundaries overlap the other batch's MFMA pass.
+    struct bc_set {
+        void* d_qh = nullptr;      size_t qh_cap = 0;       // bytes: fp16 queries [nq_pad, d_pad]
+        u64* d_queues = nullptr;   size_t queues_cap = 0;   // private candidate queues
+        u32* d_counts = nullptr;   size_t counts_cap = 0;
+        float* d_tau = nullptr;    size_t tau_cap = 0;
+        u32* d_sample_top = nullptr; size_t sample_top_cap = 0;  // best sample scores per lane
+        hipEvent_t done = nullptr;        // set 0, multi-stream mode
+        hipStream_t last_stream = nullptr;
+        bool used = false;
+        bool multi_stream = false;
+        hipStream_t lane_stream = nullptr;  // sets 1 .. LS_BC_LANES
+        hipEvent_t lane_in = nullptr;       // recorded on the caller's stream, waited for by the lane
+        hipEvent_t lane_q = nullptr;        // the lane has consumed the caller's query buffer
+        hipEvent_t lane_out = nullptr;      // orders another stream behind the lane (ls_i_export_flags)
+    } bc_sets[LS_BC_SETS];
+    uint64_t bc_lane_rr = 0;
+    int32_t bc_last_set = 0;  // the set of the most recent batched call (ls_export_flags)
+    u32* d_overflow = nullptr; size_t overflow_cap = 0;
+    u32* h_overflow = nullptr; size_t h_overflow_cap = 0;  // pinned
+    // async batched calls not yet checked: each keeps its own flag slice of d_overflow AND its own
+    // copy of the raw queries (d_qkeep), so that several batches can be in flight before one
+    // ls_check repairs whatever was flagged, whatever the caller did to its query buffer meanwhile
+    struct batched_call {
+        int64_t nq = 0;
+        int32_t k = 0;
+        uint32_t flags = 0;
+        float* d_out_s = nullptr;
+        int64_t* d_out_i = nullptr;
+        hipStream_t stream = nullptr;
+        int32_t slot = 0;
+    };
+    std::vector<batched_call> bc_pending;
+    int64_t bc_slot_stride = 0;  // u32 per flag slot
+    float* d_qkeep = nullptr;  size_t qkeep_cap = 0;  // LS_BC_SLOTS x bc_qkeep_stride floats
+    int64_t bc_qkeep_stride = 0;
+    u32* d_last_flags = nullptr;  // flag slice of the most recent batched call (ls_export_flags)
+    int64_t last_flags_n = 0;
+    uint64_t n_batched_fallback = 0;  // queries repaired by the scan path (host counter)
+    int32_t n_batched_launches = 0;   // kernel launches of the most recent batched call (counted)
+    int32_t last_path = 0;            // most recent search: 1 scan path, 2 fp16 MFMA path, 3 fp32 MFMA path
+    uint64_t n_chunked_calls = 0;     // batched calls cut into sub-batches (candidate-queue capacity)
+    uint64_t n_launches_total = 0;    // kernel launches queued by searches on this handle
+    int32_t opt_gemm = 1;             // allow the batched MFMA path
+    int32_t opt_spec_tau = 1;         // speculative (verified) sample threshold
+
+    int n_pending = 0;                 // queries whose finalize has not been launched yet
+    ls_fin_batch pending{};
+    hipStream_t pending_stream = nullptr;
+    float* d_qpad = nullptr; size_t qpad_cap = 0;  // padded query group (ragged last group)
+    long long s_stride = 0;            // floats between the score vectors of one generation
+    int32_t opt_multi_query = 1;       // several queries per corpus pass (groups of 8 / 4)
+    int32_t max_blocks = 0;
+    float* d_out_s = nullptr;  int64_t* d_out_i = nullptr;  size_t out_cap = 0;  // nq*k
+    u32* d_counters = nullptr;                        // [0] finalize slow-path count
+    u32* h_done = nullptr;     // pinned [LS_SCAN_MAX_NQ]: completion words of the host API
+    u32 done_seq = 0;
+    u32* done_base = nullptr;  // set by ls_search around its scan-path call, else null
+    float* h_q = nullptr;      size_t h_q_cap = 0;    // pinned
+    float* h_out_s = nullptr;  int64_t* h_out_i = nullptr;  size_t h_out_cap = 0;
+
+    // options / instrumentation
+    int32_t opt_kprime = 0;  // 0 = automatic
+    int32_t opt_blocks = 0;  // 0 = automatic (scan workgroups per launch)
+    int32_t opt_force_slow = 0;
+    int32_t opt_overlap = 1;    // finalize of group i-1 rides on the scan launch of group i
+    int32_t opt_alternate = 0;  // alternate sweep direction between consecutive scans
+    uint64_t sweep_count = 0;
+    // profiling: hipEvent pairs around EVERY scan launch (and the finalize after it), recorded
+    // on the stream the kernels run on, up to LS_PROF_MAX launches; read by ls_last_kernel_ms
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_ev;  // 2 events per launch: begin, end
+    size_t prof_n = 0;
+};
+
+
+template <typename T>
+static inline int ls_grow(T** p, size_t* cap, size_t need) {
+    if (need <= *cap) return LS_OK;
+    if (*p) LS_HIP(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    size_t want = need + need / 2;
+    LS_HIP(hipMalloc((void**)p, want * sizeof(T)));
+    *cap = want;
+    return LS_OK;
+}
+template <typename T>
+static inline int ls_grow_pinned(T** p, size_t* cap, size_t need, unsigned flags = hipHostMallocDefault) {
+    if (need <= *cap) return LS_OK;
+    if (*p) LS_HIP(hipHostFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    size_t want = need + need / 2;
+    LS_HIP(hipHostMalloc((void**)p, want * sizeof(T), flags));
+    *cap = want;
+    return LS_OK;
+}
+
+// ---- internals of ls_api.hip that the group handle drives. The caller holds the mutex of the
+// handle it passes and has made that handle's device current. ---------------------------------
+int ls_i_check_device(int32_t device);
+int ls_i_check_search_args(const ls_index* ix, const void* q, int64_t nq, int32_t k, uint32_t flags,
+                           const void* os, const void* oi);
+bool ls_i_batched_eligible(const ls_index* ix, int64_t nq, int32_t k);
+int ls_i_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
+                          float* d_out_s, int64_t* d_out_i, hipStream_t s, bool host_api);
+int ls_i_flush_pending(ls_index* ix);
+int ls_i_batched_repair(ls_index* ix);
+int ls_i_export_flags(ls_index* ix, void* d_dst, int64_t nq, hipStream_t s);
+
+// ---- the group handle (ls_shard.hip); every function takes the GROUP's ls_index -----------------
+int ls_group_search(ls_index* ix, const float* q, bool q_on_host, int64_t nq, int32_t k,
+                    uint32_t flags, float* out_s, int64_t* out_i, hipStream_t s);
+int ls_group_check(ls_index* ix, hipStream_t s);
+void ls_group_destroy(ls_index* ix);
+int ls_group_add(ls_index* ix, const float* rows, int64_t n_add);
+int ls_group_reconstruct(ls_index* ix, int64_t row0, int64_t count, float* out);
+int ls_group_set_base(ls_index* ix, int64_t base);
+int ls_group_debug_option(ls_index* ix, int32_t which, int32_t value);
+int64_t ls_group_debug_counter(ls_index* ix, int32_t which);
+int ls_group_set_profiling(ls_index* ix, int32_t enabled);
+int ls_group_last_kernel_ms(ls_index* ix, float* scan_ms, float* total_ms);

@@ -43,17 +43,37 @@ def normalize_L2(x: np.ndarray, device: int = 0) -> None:
     native.check(lib.ls_normalize_l2(x.ctypes.data, x.shape[0], x.shape[1], device))
 
 
+def _device_list(devices: Any) -> list[int] | None:
+    """``None`` -> single device; ``"all"`` -> every visible GPU; else a list of ordinals."""
+    if devices is None:
+        return None
+    if isinstance(devices, str):
+        if devices.strip().lower() == "all":
+            return list(range(native.device_count()))
+        devices = [int(t) for t in devices.replace(",", " ").split()]
+    out = [int(t) for t in devices]
+    if not out:
+        raise ValueError("devices must name at least one GPU")
+    return out
+
+
 class FlatIPIndex:
-    """Exact inner-product index resident in one GPU's HBM."""
+    """Exact inner-product index resident in HBM: one GPU, or — ``devices=[...]`` — row-sharded
+    over several GPUs of the node inside this one process (ls_create_sharded: concurrent local
+    top-k, one RCCL all-gather of the packed results, merge on ``devices[0]``; bit-identical
+    to the single-GPU answer). The reference's backend is one process holding one index
+    (reference mcp/server.py:147-151), so this is how `Service.search()` uses a whole node."""
 
     supports_fused_normalize = True  # search(..., normalize=True) fuses faiss.normalize_L2
 
-    def __init__(self, d: int, dtype: Any = "f32", device: int = 0, base: int = 0):
+    def __init__(self, d: int, dtype: Any = "f32", device: int = 0, base: int = 0,
+                 devices: Any = None):
         if d <= 0:
             raise ValueError("d must be positive")
         self.d = int(d)
         self._dtype = _dtype_code(dtype)
-        self.device = int(device)
+        self.devices = _device_list(devices)
+        self.device = int(self.devices[0]) if self.devices else int(device)
         self._base = int(base)
         self._handle: ctypes.c_void_p | None = None
         # rows added before the first search: uploaded (and released) when the handle is built.
@@ -67,11 +87,11 @@ class FlatIPIndex:
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_array(cls, corpus: np.ndarray, dtype: Any = "f32", device: int = 0,
-                   base: int = 0) -> "FlatIPIndex":
+                   base: int = 0, devices: Any = None) -> "FlatIPIndex":
         corpus = np.asarray(corpus)
         if corpus.ndim != 2:
             raise ValueError("corpus must be [n, d]")
-        ix = cls(corpus.shape[1], dtype=dtype, device=device, base=base)
+        ix = cls(corpus.shape[1], dtype=dtype, device=device, base=base, devices=devices)
         ix.add(corpus)
         ix._ensure_built()
         return ix
@@ -96,6 +116,50 @@ class FlatIPIndex:
         if base:
             native.check(lib.ls_set_base(h, base))
         return ix
+
+    @classmethod
+    def from_device_blocks(cls, blocks: list, dtype: Any = "f32", base: int = 0) -> "FlatIPIndex":
+        """Row-sharded index from per-device float32 CUDA tensors ``blocks[g]`` of shape
+        [rows_g, d] (block g stays on its own GPU; global rows are numbered block after block).
+        Multi-GB synthetic shards never cross the host (ls_create_sharded_from_device)."""
+        import torch
+
+        if not blocks:
+            raise ValueError("need at least one block")
+        d = int(blocks[0].shape[1])
+        for b in blocks:
+            if not (isinstance(b, torch.Tensor) and b.is_cuda and b.dim() == 2 and b.shape[1] == d
+                    and b.dtype == torch.float32 and b.is_contiguous()):
+                raise ValueError("every block must be a contiguous float32 CUDA tensor [rows, d]")
+        devs = [b.device.index or 0 for b in blocks]
+        ix = cls(d, dtype=dtype, base=base, devices=devs)
+        n = len(blocks)
+        ptrs = (ctypes.c_void_p * n)(*[b.data_ptr() for b in blocks])
+        rows = (ctypes.c_int64 * n)(*[int(b.shape[0]) for b in blocks])
+        ids = (ctypes.c_int32 * n)(*devs)
+        for b in blocks:
+            torch.cuda.synchronize(b.device)
+        h = ctypes.c_void_p()
+        lib = native.load()
+        native.check(lib.ls_create_sharded_from_device(ctypes.byref(h), ptrs, rows, d, ix._dtype, ids, n))
+        ix._handle = h
+        ix._ntotal = int(sum(int(b.shape[0]) for b in blocks))
+        ix._device_built = True
+        if base:
+            native.check(lib.ls_set_base(h, base))
+        return ix
+
+    def shards(self) -> list[tuple[int, int, int]]:
+        """(device, first global row, rows) of every shard; [] for a single-device index."""
+        h = self._ensure_built()
+        lib = native.load()
+        out = []
+        for g in range(int(lib.ls_shard_count(h))):
+            dev, row0, rows = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+            native.check(lib.ls_shard_info(h, g, ctypes.byref(dev), ctypes.byref(row0),
+                                           ctypes.byref(rows)))
+            out.append((dev.value, row0.value, rows.value))
+        return out
 
     def add(self, x: np.ndarray) -> None:
         """index.add(x) (reference extract/index.py:116): append float32 rows. On a built index
@@ -124,8 +188,14 @@ class FlatIPIndex:
             self._pending = [np.concatenate(self._pending, axis=0)]
         corpus = self._pending[0] if self._pending else np.zeros((0, self.d), np.float32)
         h = ctypes.c_void_p()
-        native.check(lib.ls_create(ctypes.byref(h), corpus.ctypes.data if corpus.size else None,
-                                   corpus.shape[0], self.d, self._dtype, self.device))
+        if self.devices is not None:
+            ids = (ctypes.c_int32 * len(self.devices))(*self.devices)
+            native.check(lib.ls_create_sharded(
+                ctypes.byref(h), corpus.ctypes.data if corpus.size else None, corpus.shape[0],
+                self.d, self._dtype, ids, len(self.devices)))
+        else:
+            native.check(lib.ls_create(ctypes.byref(h), corpus.ctypes.data if corpus.size else None,
+                                       corpus.shape[0], self.d, self._dtype, self.device))
         self._handle = h
         self._pending = []  # the rows live in HBM now
         if self._base:

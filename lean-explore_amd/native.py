@@ -40,6 +40,11 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 SYMBOLS: dict[str, tuple] = {
     "ls_create": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _i64, _i32, _i32, _i32]),
     "ls_create_from_device": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _i64, _i32, _i32, _i32]),
+    "ls_create_sharded": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _i64, _i32, _i32, _vp, _i32]),
+    "ls_create_sharded_from_device": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _vp, _i32, _i32, _vp,
+                                                     _i32]),
+    "ls_shard_count": (_i32, [_vp]),
+    "ls_shard_info": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_i32), _i64p, _i64p]),
     "ls_add": (ctypes.c_int, [_vp, _vp, _i64]),
     "ls_reconstruct": (ctypes.c_int, [_vp, _i64, _i64, _vp]),
     "ls_destroy": (None, [_vp]),

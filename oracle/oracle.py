@@ -221,10 +221,23 @@ def compare_topk(D_a: np.ndarray, I_a: np.ndarray, D_ref: np.ndarray, I_ref: np.
                 f"query {qi} rank {j}: got row {I_a[qi, j]} (ref score {sa}) want "
                 f"{I_ref[qi, j]} (ref score {sr})")
             n_excused += 1
+    # recall@k. A row the reference does not list still counts when the reference's own score for
+    # it is within tie_eps of the reference's k-th score: a near-tie AT the rank-k boundary, where
+    # either row is a correct k-th result (the rank-by-rank check above has already verified that
+    # this is the only way the two lists differ).
     recall = 1.0
+    n_boundary = 0
     if ok.any():
-        hits = sum(len(set(I_a[i][I_a[i] >= 0]) & set(I_ref[i][I_ref[i] >= 0]))
-                   for i in range(I_a.shape[0]))
+        hits = 0
+        for i in range(I_a.shape[0]):
+            a = set(I_a[i][I_a[i] >= 0].tolist())
+            r = set(I_ref[i][I_ref[i] >= 0].tolist())
+            hits += len(a & r)
+            if S_ref is not None and r and a - r:
+                kth = min(float(S_ref[i, j - base]) for j in r)
+                tied = sum(1 for j in a - r if float(S_ref[i, j - base]) >= kth - tie_eps)
+                hits += tied
+                n_boundary += tied
         recall = hits / int(ok.sum())
     return {"max_score_err": max_ds, "index_mismatches": n_diff, "near_ties_excused": n_excused,
-            "recall": recall}
+            "boundary_ties": n_boundary, "recall": recall}

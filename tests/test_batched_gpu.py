@@ -154,7 +154,7 @@ def test_batched_reference_call_shape_k1000(nq):
     ix = FlatIPIndex.from_array(c, dtype="f16")
     nchk = min(nq, 48)  # the oracle needs ~0.2 s per query at this size
     D, I = ix.search(q, 1000)
-    assert ix.debug_counter(9) == 5, "k=1000 must stay on the batched MFMA path"
+    assert ix.debug_counter(10) == 2, "k=1000 must stay on the batched MFMA path"
     Dr, Ir = oracle.c_search(c, q[:nchk], 1000, f16=True)
     _, _, S = oracle.np_search(c, q[:nchk], 1000, f16=True)
     rep = oracle.compare_topk(D[:nchk], I[:nchk], Dr, Ir, S)
@@ -261,7 +261,7 @@ def test_pipelined_batches_alternate_between_the_two_lanes():
         Dr, Ir = oracle.c_search(c, q, k, f16=True)
         _, _, S = oracle.np_search(c, q, k, f16=True)
         rep = oracle.compare_topk(s.cpu().numpy(), ii.cpu().numpy(), Dr, Ir, S)
-        assert rep["recall"] >= 0.9999, (nq, k, rep)  # a near-tie AT rank k swaps one row of the set
+        assert rep["recall"] == 1.0, (nq, k, rep)  # rank-k boundary ties are resolved by compare_topk
     ix.close()
 
 
@@ -292,7 +292,7 @@ def test_pipelined_lanes_mixed_with_scan_path_and_add():
             Dr, Ir = oracle.c_search(corpus, q, k, f16=True)
             _, _, S = oracle.np_search(corpus, q, k, f16=True)
             rep = oracle.compare_topk(s.cpu().numpy(), ii.cpu().numpy(), Dr, Ir, S)
-            assert rep["recall"] >= 0.9999, (q.shape, k, rep)
+            assert rep["recall"] == 1.0, (q.shape, k, rep)
 
     run(c, 100)
     ix.add(extra)
@@ -320,7 +320,7 @@ def test_pipelined_lanes_large_and_ragged_batches():
         Dr, Ir = oracle.c_search(c, q[:nchk], k, f16=True)
         _, _, S = oracle.np_search(c, q[:nchk], k, f16=True)
         rep = oracle.compare_topk(s[:nchk].cpu().numpy(), ii[:nchk].cpu().numpy(), Dr, Ir, S)
-        assert rep["recall"] >= 0.9999, (q.shape, k, rep)
+        assert rep["recall"] == 1.0, (q.shape, k, rep)
     ix.close()
 
 
@@ -328,7 +328,7 @@ def test_pipelined_lanes_large_and_ragged_batches():
 def check_batched_f32(c, q, k, normalize=False, base=0):
     ix = FlatIPIndex.from_array(c, dtype="f32", base=base)
     D, I = ix.search(q, k, normalize=normalize)
-    assert ix.debug_counter(9) == 5, "fp32 batches of >= 24 queries take the f32 MFMA path"
+    assert ix.debug_counter(10) == 3, "fp32 batches of >= 24 queries take the f32 MFMA path"
     qn = oracle.c_normalize_l2(q) if normalize else q
     Dr, Ir = oracle.c_search(c, qn, k, base=base)
     _, _, S = oracle.np_search(c, qn, k)
@@ -353,7 +353,7 @@ def test_f32_batched_integer_corpus_bit_exact():
     q = H.int_corpus(74, 96, 384)
     ix = FlatIPIndex.from_array(c, dtype="f32")
     D, I = ix.search(q, 64)
-    assert ix.debug_counter(9) == 5
+    assert ix.debug_counter(10) == 3
     Dr, Ir = oracle.c_search(c, q, 64)
     assert np.array_equal(D, Dr) and np.array_equal(I, Ir)
     print("f32 int corpus fallbacks (ties overflow the queues):", ix.debug_counter(8))
@@ -368,7 +368,7 @@ def test_f32_batched_reference_call_shape(nq):
     q = H.gauss(42, nq, 1024)
     ix = FlatIPIndex.from_array(c, dtype="f32")
     D, I = ix.search(q, 1000)
-    assert ix.debug_counter(9) == 5
+    assert ix.debug_counter(10) == 3
     nchk = 32
     Dr, Ir = oracle.c_search(c, q[:nchk], 1000)
     _, _, S = oracle.np_search(c, q[:nchk], 1000)
@@ -410,10 +410,56 @@ def test_f32_batched_through_the_lanes():
         s, ii = ix.search_device(tq, k, pipeline=True)
         outs.append((q, k, s, ii))
     ix.check()
-    assert ix.debug_counter(9) == 5
+    assert ix.debug_counter(10) == 3
     for q, k, s, ii in outs:
         Dr, Ir = oracle.c_search(c, q, k)
         _, _, S = oracle.np_search(c, q, k)
         rep = oracle.compare_topk(s.cpu().numpy(), ii.cpu().numpy(), Dr, Ir, S, score_tol=1e-5, tie_eps=2e-6)
-        assert rep["recall"] >= 0.9999, (q.shape, k, rep)
+        assert rep["recall"] == 1.0, (q.shape, k, rep)
+    ix.close()
+
+
+def test_launch_counter_counts_and_path_counter():
+    """debug counter 9 is incremented per kernel launch of a batched call (prep, sample pass, tau,
+    MFMA pass, select), counter 11 accumulates every search launch of the handle, counter 10 names
+    the path of the most recent search."""
+    c = H.gauss(91, 60_000, 128)
+    q = H.gauss(92, 40, 128)
+    ix = FlatIPIndex.from_array(c, dtype="f16")
+    before = ix.debug_counter(11)
+    ix.search(q, 10)
+    assert ix.debug_counter(10) == 2
+    assert ix.debug_counter(9) == 5          # the five launches, counted one by one
+    if ix.debug_counter(8) == 0:             # (a repaired query would add scan launches)
+        assert ix.debug_counter(11) - before == 5
+    before = ix.debug_counter(11)
+    ix.search(q[:1], 10)                     # per-query scan path: scan + selection launch
+    assert ix.debug_counter(10) == 1 and ix.debug_counter(11) - before == 2
+    ix.debug_option(4, 0)                    # MFMA path off: 40 queries = 5 groups of 8 + selection
+    before = ix.debug_counter(11)
+    ix.search(q, 10)
+    assert ix.debug_counter(10) == 1 and ix.debug_counter(11) - before == 6
+    ix.close()
+
+
+def test_big_batch_big_k_is_cut_into_sub_batches_not_repaired():
+    """nq = 4096 x k = 1000 leaves 16 corpus slices per query tile: 2048 queue entries per query
+    against ~3 k expected passes. The call is cut into sub-batches whose queues fit instead of
+    sending every query through the repair path; the fallback count stays small."""
+    c = H.gauss(93, 120_000, 384)
+    q = H.gauss(94, 4096, 384)
+    ix = FlatIPIndex.from_array(c, dtype="f16")
+    D, I = ix.search(q, 1000)
+    assert ix.debug_counter(12) >= 1, "expected the call to be chunked"
+    assert ix.debug_counter(8) <= 41, f"{ix.debug_counter(8)} of 4096 queries fell back to the scan path"
+    nchk = 24
+    pick = np.r_[0:8, 2040:2048, 4088:4096]
+    Dr, Ir = oracle.c_search(c, q[pick], 1000, f16=True)
+    _, _, S = oracle.np_search(c, q[pick], 1000, f16=True)
+    rep = oracle.compare_topk(D[pick], I[pick], Dr, Ir, S)
+    assert rep["recall"] == 1.0 and nchk == len(pick), rep
+    # nq = 2048 fits (or is chunked): either way at most 1 % of the queries may need a repair
+    ix2_before = ix.debug_counter(8)
+    ix.search(q[:2048], 1000)
+    assert ix.debug_counter(8) - ix2_before <= 20
     ix.close()

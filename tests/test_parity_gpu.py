@@ -156,6 +156,35 @@ def test_config2_full_size(dtype):
     ix.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_headline_instantiation_single_queries_full_size(dtype):
+    """The kernel instance bench.py times (one query per launch, N = 200k Gaussian rows) is the
+    one checked here: 8 single-query calls through the host API and 8 pipelined single-query
+    launches through the device API, k = 50 and k = 1000."""
+    import torch
+
+    c = H.gauss(1234, 200_000, 384)
+    q = H.gauss(5678, 8, 384)
+    f16 = dtype == "f16"
+    ix = FlatIPIndex.from_array(c, dtype=dtype)
+    tq = torch.from_numpy(q).cuda()
+    for k in (50, 1000):
+        Dr, Ir = oracle.c_search(c, q, k, f16=f16)
+        _, _, S = oracle.np_search(c, q, k, f16=f16)
+        D = np.concatenate([ix.search(q[j:j + 1], k)[0] for j in range(8)])
+        I = np.concatenate([ix.search(q[j:j + 1], k)[1] for j in range(8)])
+        assert ix.debug_counter(10) == 1
+        rep = oracle.compare_topk(D, I, Dr, Ir, S)
+        assert rep["recall"] == 1.0, rep
+        outs = [ix.search_device(tq[j:j + 1], k, pipeline=True) for j in range(8)]
+        ix.check()
+        D = torch.cat([o[0] for o in outs]).cpu().numpy()
+        I = torch.cat([o[1] for o in outs]).cpu().numpy()
+        rep = oracle.compare_topk(D, I, Dr, Ir, S)
+        assert rep["recall"] == 1.0, rep
+    ix.close()
+
+
 def test_real_call_shape_d1024_k1000():
     """The reference's production call: d=1024 (Qwen3-Embedding), faiss_k=1000."""
     c = H.gauss(1234, 50_000, 1024)

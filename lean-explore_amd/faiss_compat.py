@@ -91,8 +91,17 @@ def _read_flat_payload(f) -> tuple[int, np.ndarray]:
     return d, xb.reshape(ntotal, d).astype(np.float32, copy=True)
 
 
-def write_index(index: FlatIPIndex, path: str | Path) -> None:
-    """faiss.write_index for a flat inner-product index (container ``IxFI``)."""
+def write_index(index: FlatIPIndex, path: str | Path, *, allow_lossy: bool = False) -> None:
+    """faiss.write_index for a flat inner-product index (container ``IxFI``).
+
+    A built fp16 index holds only the ROUNDED rows in HBM (no host copy is kept), so the file
+    would not round-trip the float32 embeddings that were added and would score differently in
+    the reference's faiss: refused unless ``allow_lossy=True``."""
+    if (getattr(index, "storage_dtype", "f32") == "f16" and getattr(index, "_handle", None) is not None
+            and not allow_lossy):
+        raise ValueError("write_index on a built fp16 index would write fp16-rounded rows, not the "
+                         "float32 embeddings that were added; pass allow_lossy=True to do that, or "
+                         "write the index before the first search / from an f32 index")
     corpus = np.ascontiguousarray(index.host_corpus(), dtype="<f4")
     with open(path, "wb") as f:
         f.write(struct.pack("<I", _fourcc("IxFI")))
@@ -101,8 +110,9 @@ def write_index(index: FlatIPIndex, path: str | Path) -> None:
         f.write(corpus.tobytes())
 
 
-def read_index(path: str | Path, dtype="f32", device: int = 0) -> FlatIPIndex:
-    """faiss.read_index (reference search/engine.py:159) -> exact HIP index."""
+def read_index(path: str | Path, dtype="f32", device: int = 0, devices=None) -> FlatIPIndex:
+    """faiss.read_index (reference search/engine.py:159) -> exact HIP index (``devices``: row-sharded
+    over several GPUs inside this process)."""
     path = Path(path)
     with open(path, "rb") as f:
         (cc,) = struct.unpack("<I", f.read(4))
@@ -114,7 +124,7 @@ def read_index(path: str | Path, dtype="f32", device: int = 0) -> FlatIPIndex:
             tag = struct.pack("<I", cc).decode("ascii", "replace")
             raise ValueError(f"{path}: unsupported index container {tag!r} "
                              "(expected IxFI flat-IP or IwFl IVF-flat)")
-    index = FlatIPIndex(d, dtype=dtype, device=device)
+    index = FlatIPIndex(d, dtype=dtype, device=device, devices=devices)
     if corpus.shape[0]:
         index.add(corpus)
     return index

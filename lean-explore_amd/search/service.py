@@ -11,9 +11,8 @@ from .types import SearchResponse, SearchResult
 
 class Service:
     def __init__(self, engine: SearchEngine | None = None):
-        if engine is None:
-            raise ValueError("Service needs a SearchEngine (paths are deployment specific)")
-        self.engine = engine
+        # reference service.py:21: no engine -> the default one (cache paths from the environment)
+        self.engine = engine or SearchEngine()
 
     async def search(self, query: str, limit: int = 20, rerank_top: int | None = 50,
                      packages: list[str] | None = None) -> SearchResponse:

@@ -39,9 +39,9 @@ def test_service_search_drop_in(tmp_path, container):
         faiss_compat.write_ivf_flat_for_tests(index_path, loaded, assign, 256)
 
     qvec = corpus[123] * 3.0 + 0.01 * H.gauss(5, 1, d)[0]
-    hip = S.SearchEngine(base_path=tmp_path, embedding_client=FakeEmbed(qvec))
+    hip = S.SearchEngine(base_path=tmp_path, embedding_client=FakeEmbed(qvec), lexical_retriever=False)
     ref = S.SearchEngine(db_path=db, embedding_client=FakeEmbed(qvec), index=OracleIndex(loaded),
-                         ids_map=ids)
+                         ids_map=ids, lexical_retriever=False)
     sem_hip = run(hip._retrieve_semantic_candidates("q", 1000))
     sem_ref = run(ref._retrieve_semantic_candidates("q", 1000))
     assert list(sem_hip) == list(sem_ref)                       # same ids in the same rank order
@@ -105,7 +105,7 @@ def test_rerank_mixing_weights(tmp_path):
     ix.add(loaded)
     rr = FakeReranker()
     eng = S.SearchEngine(db_path=db, embedding_client=FakeEmbed(corpus[10]), index=ix, ids_map=ids,
-                         reranker_client=rr)
+                         reranker_client=rr, lexical_retriever=False)
     res = run(eng.search("sum and zero", limit=5, rerank_top=20))
     assert len(res) == 5 and len(rr.documents) == 20
     assert rr.documents[0].startswith("Pkg.decl")            # "name: informalization"

@@ -21,10 +21,14 @@ The ONE JSON line rank 0 prints carries the headline workload at the top level a
   "host_api":  the synchronous host-array call the reference makes (ls_search, nq=1, PCIe and sync
                inclusive; reference search/engine.py:250) for c2 and c2p.
 
-N > 1: the corpus is row-sharded over the ranks (strong scaling for c1..c3: the same corpus, the
-same queries; every rank ends with the identical merged top-k after one RCCL all-gather).
-`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run
-with N ranks; the run aborts unless the communicator really has N ranks on N distinct devices.
+N > 1: the corpus is row-sharded over the GPUs (strong scaling for c1..c3: the same corpus, the
+same queries; the merged top-k is identical to the 1-GPU answer after one RCCL all-gather).
+Under a launcher (WORLD_SIZE set: `python -m torch.distributed.run ... bench.py --gpus N`, how the
+driver runs it) it is one process per GPU over torch.distributed and the run aborts unless the
+communicator really has N ranks on N distinct devices. `python bench.py --gpus N` without a
+launcher runs ONE process that drives the N GPUs through the library's own sharded handle
+(ls_create_sharded: the reference's process model); `--launcher torchrun` re-executes under
+torch.distributed.run instead.
 """
 
 from __future__ import annotations
@@ -134,6 +138,26 @@ class Env:
         import torch.distributed as dist
 
         self.torch, self.dist, self.args = torch, dist, args
+        # `--gpus N` with no launcher: ONE process drives N GPUs through the library's own sharded
+        # handle (ls_create_sharded: per-device streams, RCCL all-gather inside the library).
+        # Under a launcher (WORLD_SIZE set, how the driver runs N > 1) it is one process per GPU
+        # over torch.distributed.
+        self.inlib = args.gpus > 1 and "WORLD_SIZE" not in os.environ
+        self.shard_devices = None
+        if self.inlib:
+            ndev = torch.cuda.device_count()
+            self.share_gpu = bool(os.environ.get("LS_BENCH_SHARE_GPU")) and args.gpus > ndev
+            if args.gpus > ndev and not self.share_gpu:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} visible GPUs")
+            self.shard_devices = [g % max(1, ndev) for g in range(args.gpus)]
+            self.world, self.rank, self.local_rank = 1, 0, 0
+            self.device_index = self.shard_devices[0]
+            torch.cuda.set_device(self.device_index)
+            self.dev = torch.device("cuda", self.device_index)
+            self.rehearse = False
+            self.ranks_seen = args.gpus     # confirmed from the handle after the first exchange
+            self.devices_seen = len(set(self.shard_devices))
+            return
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -174,13 +198,17 @@ class Env:
         else:
             self.devices_seen = 1
 
+    @property
+    def n_gpus(self):
+        return len(self.shard_devices) if self.inlib else self.world
+
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
     def close(self):
-        if self.world > 1 or self.rehearse:
+        if not self.inlib and (self.world > 1 or self.rehearse):
             self.dist.destroy_process_group()
 
 
@@ -198,54 +226,90 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
     c4 = workload == "c4"
     c4_ref = None
     NV_C4 = 16  # queries of the c4 batch checked against the torch reference
-    if c4:
-        # config 4: every rank generates its own shard in HBM (the 153.6 GB corpus never exists
-        # on the host); queries come from one seed, identical on every rank
-        rows = c4_rows or n
-        n, lo, hi = rows * world, rank * rows, (rank + 1) * rows
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(1234 + rank)
-        shard = torch.empty((rows, d), dtype=torch.float32, device=dev)
+    inlib = env.inlib
+    G = env.n_gpus  # shards: ranks under a launcher, devices of the one process otherwise
+
+    def c4_block(seed, rows, device):
+        """One shard of config 4 generated in that device's HBM (the 153.6 GB corpus never exists
+        on the host): float32 [rows, d], rows L2-normalised."""
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed)
+        shard = torch.empty((rows, d), dtype=torch.float32, device=device)
         for r0 in range(0, rows, 1 << 20):
-            blk = torch.randn((min(1 << 20, rows - r0), d), device=dev, generator=gen)
+            blk = torch.randn((min(1 << 20, rows - r0), d), device=device, generator=gen)
             shard[r0:r0 + blk.shape[0]] = blk / blk.norm(dim=1, keepdim=True)
+        return shard
+
+    def c4_reference(shard, q16, row0):
+        """torch fp32 reference of the same op on one shard (fp16-rounded operands, fp32
+        accumulate), in row blocks: the CPU oracle cannot hold 12.5 M rows."""
+        nv = q16.shape[0]
+        best_s = torch.full((nv, 0), 0.0, device=shard.device)
+        best_i = torch.zeros((nv, 0), dtype=torch.int64, device=shard.device)
+        for r0 in range(0, shard.shape[0], 1 << 20):
+            sc = q16 @ shard[r0:r0 + (1 << 20)].half().float().T
+            ts, ti = sc.topk(min(k, sc.shape[1]), dim=1)
+            best_s = torch.cat([best_s, ts], 1)
+            best_i = torch.cat([best_i, ti + r0 + row0], 1)
+            ts, sel = best_s.topk(min(k, best_s.shape[1]), dim=1)
+            best_s, best_i = ts, best_i.gather(1, sel)
+        return best_s.cpu(), best_i.cpu()
+
+    if c4:
+        # config 4: every GPU generates its own shard (seed 1234 + shard); queries come from one
+        # seed, identical everywhere
+        rows = c4_rows or n
+        n = rows * G
+        gen = torch.Generator(device=dev)
         gen.manual_seed(5678)
         tq = torch.randn((nq, d), device=dev, generator=gen)
         tq /= tq.norm(dim=1, keepdim=True)
-        local = FlatIPIndex.from_device_tensor(shard, dtype=dtype, base=lo)
         queries = tq.cpu().numpy()
-        corpus = shard[:200_000].cpu().numpy()  # the CPU baseline's bounded sample
-        if verify:
-            # torch fp32 reference of the same op on this rank's shard (fp16-rounded operands,
-            # fp32 accumulate), NV_C4 queries, in row blocks: the oracle cannot hold 12.5 M rows
-            nv = NV_C4
-            q16 = tq[:nv].half().float()
-            best_s = torch.full((nv, 0), 0.0, device=dev)
-            best_i = torch.zeros((nv, 0), dtype=torch.int64, device=dev)
-            for r0 in range(0, rows, 1 << 20):
-                sc = q16 @ shard[r0:r0 + (1 << 20)].half().float().T
-                ts, ti = sc.topk(min(k, sc.shape[1]), dim=1)
-                best_s = torch.cat([best_s, ts], 1)
-                best_i = torch.cat([best_i, ti + r0 + lo], 1)
-                ts, sel = best_s.topk(min(k, best_s.shape[1]), dim=1)
-                best_s, best_i = ts, best_i.gather(1, sel)
-            c4_ref = (best_s.cpu().numpy(), best_i.cpu().numpy())
-        del shard
+        q16 = tq[:NV_C4].half().float()
+        if inlib:
+            lo, hi = 0, rows
+            blocks, refs = [], []
+            for g, di in enumerate(env.shard_devices):
+                blk = c4_block(1234 + g, rows, torch.device("cuda", di))
+                if g == 0:
+                    corpus = blk[:200_000].cpu().numpy()  # the CPU baseline's bounded sample
+                if verify:
+                    refs.append(c4_reference(blk, q16.to(blk.device), g * rows))
+                blocks.append(blk)
+            local = FlatIPIndex.from_device_blocks(blocks, dtype=dtype)
+            del blocks, blk
+            if verify:  # merged reference of the whole sharded corpus
+                rs, ri = torch.cat([r[0] for r in refs], 1), torch.cat([r[1] for r in refs], 1)
+                ts, sel = rs.topk(k, dim=1)
+                c4_ref = (ts.numpy(), ri.gather(1, sel).numpy())
+        else:
+            lo, hi = rank * rows, (rank + 1) * rows
+            shard = c4_block(1234 + rank, rows, dev)
+            local = FlatIPIndex.from_device_tensor(shard, dtype=dtype, base=lo)
+            corpus = shard[:200_000].cpu().numpy()
+            if verify:
+                rs, ri = c4_reference(shard, q16, lo)
+                c4_ref = (rs.numpy(), ri.numpy())
+            del shard
         torch.cuda.empty_cache()
     else:
         corpus = gauss(1234, n, d)
         queries = gauss(5678, nq, d)
-        lo, hi = shard_bounds(n, world, rank)
-        local = FlatIPIndex.from_array(np.ascontiguousarray(corpus[lo:hi]), dtype=dtype,
-                                       device=env.device_index, base=lo)
+        if inlib:
+            lo, hi = shard_bounds(n, G, 0)
+            local = FlatIPIndex.from_array(corpus, dtype=dtype, devices=env.shard_devices)
+        else:
+            lo, hi = shard_bounds(n, world, rank)
+            local = FlatIPIndex.from_array(np.ascontiguousarray(corpus[lo:hi]), dtype=dtype,
+                                           device=env.device_index, base=lo)
         tq = torch.from_numpy(queries).to(dev)
-    index = ShardedFlatIPIndex(local, n)
+    index = None if inlib else ShardedFlatIPIndex(local, n)
 
     # nq <= 16 is the per-query HBM-bound scan path: consecutive steps are pipelined
     # (LS_FLAG_PIPELINE: launch i = scan of step i + one workgroup finalising step i-1, all on
     # one stream); the last finalize is flushed and everything validated by local.check() inside
     # the timed region.
-    pipelined = world == 1 and nq <= 16
+    pipelined = world == 1 and nq <= 16 and not inlib
     out_ring = [(torch.empty((nq, k), dtype=torch.float32, device=dev),
                  torch.empty((nq, k), dtype=torch.int64, device=dev)) for _ in range(16)]
     step_i = [0]
@@ -253,7 +317,7 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
     # N > 1, small batches: the sharded pipeline (local search of step i carries the finalize of
     # step i-1; the all-gather of step i-1 runs asynchronously; step i-2 is merged)
     sharded_pipe = world > 1 and nq <= 16
-    if env.rehearse:
+    if env.rehearse and not inlib:
         index.force_exchange = True
         sharded_pipe, pipelined = nq <= 16, False
 
@@ -262,11 +326,15 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
     # kernels overlap the other's MFMA pass); the verification flags of up to 16 outstanding
     # batches are checked (and flagged queries repaired) by local.check() inside the timed
     # region, instead of one host round trip per batch
-    batched_async = world == 1 and not pipelined and not env.rehearse
+    batched_async = world == 1 and not pipelined and not env.rehearse and not inlib
 
     def step():
         o = out_ring[step_i[0] & 15]
         step_i[0] += 1
+        if inlib:
+            # one process, every GPU: the sharded handle queues the local searches on its per-device
+            # streams, one RCCL all-gather and the merge; batches ride the shards' two lanes
+            return local.search_device(tq, k, o[0], o[1], asynchronous=nq <= 16, pipeline=nq > 16)
         if pipelined:
             return local.search_device(tq, k, o[0], o[1], pipeline=True)
         if batched_async:
@@ -276,7 +344,9 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         return index.search_device(tq, k)
 
     def drain():
-        if sharded_pipe:
+        if inlib:
+            local.check()
+        elif sharded_pipe:
             index.flush()
         elif world > 1 or env.rehearse:
             index.finish()  # looks at the gathered verification flags, repairs + re-exchanges if any
@@ -371,6 +441,11 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
     local.set_profiling(False)
     recall = verify_fn()
     repaired = local.debug_counter(8) if (nq > 16 and dtype == "f16") else 0
+    if inlib:
+        # what the handle itself says about the exchange: 2 = RCCL communicators initialised and
+        # used; 0 = copies (shards sharing a device cannot form a communicator)
+        env.rccl_in_library = local.debug_counter(15) == 2
+        env.shards_seen = local.shards()
     ev_ms = scan_ms_avg
     roof_src = "mean of hipEvent pairs bracketing each launch (second pass of the same steps)"
     if pipelined and nq == 1:
@@ -424,13 +499,17 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         "ms_per_step": round(batch_ms, 5),
         "device_ms_per_step": round(dev_ms / steps, 5),
         "scaling": "weak" if c4 else "strong",
+        "n_shards": G,
         "dtype": dtype,
         "data": ("synthetic (standard-normal rows, L2-normalised; generated in HBM per shard, "
                  "corpus seed 1234+rank, query seed 5678)" if c4 else
                  "synthetic (standard-normal rows, L2-normalised; corpus seed 1234, query seed 5678)"),
         "config": {"workload": f"{workload}: N={n} d={d} {dtype} nq={nq} k={k}",
-                   "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
-                   "exchange": (f"pipelined: one packed all-gather + merge per {EXCHANGE_EVERY} "
+                   "rows_per_gpu": n_local, "parallelism": f"row-shard x{G}",
+                   "process_model": ("one process, sharded handle (ls_create_sharded)" if inlib
+                                     else "one process per GPU (torch.distributed)"),
+                   "exchange": ("one in-library all-gather + merge per step" if inlib else
+                                f"pipelined: one packed all-gather + merge per {EXCHANGE_EVERY} "
                                 "steps, overlapping the next scans"
                                 if sharded_pipe else ("one all-gather per step" if world > 1
                                                       else "none")),
@@ -449,7 +528,7 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         "repaired_queries": repaired,
         "roofline": roof,
     }
-    if want_cpu and rank == 0 and world == 1:
+    if want_cpu and rank == 0 and world == 1 and not inlib:
         cb = cpu_baseline(corpus, queries, k, dtype == "f16", budget_s=cpu_budget_s)
         if c4:  # timed on the first 200k rows; a flat scan is linear in the row count
             cb["value"] = round(cb["value"] * corpus.shape[0] / n, 3)
@@ -519,10 +598,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--c4-rows", type=int, default=0, help="rows per GPU for c4 (default 12.5M)")
+    ap.add_argument("--launcher", default="inlib", choices=["inlib", "torchrun"],
+                    help="--gpus N without a launcher: 'inlib' = one process drives the N GPUs through "
+                         "the library's sharded handle; 'torchrun' = re-execute under "
+                         "torch.distributed.run, one process per GPU")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.launcher == "torchrun":
         sys.exit(self_spawn(args))
 
     env = Env(args)
@@ -531,8 +614,9 @@ def main():
                      c4_rows=args.c4_rows)
     if args.secondary == "auto":
         sec = []
-        if args.workload == "c2":  # the default, driver-timed run carries both halves of the metric
-            sec = ["c3"] if env.world == 1 else ["c3", "c4"]
+        if args.workload == "c2":  # the default, driver-timed run carries both halves of the metric,
+            # the reference's real call shape and the per-GPU shard of config 4
+            sec = ["c3", "c2p", "c4"] if env.n_gpus == 1 else ["c3", "c4"]
     elif args.secondary in ("none", ""):
         sec = []
     else:
@@ -544,7 +628,7 @@ def main():
         secondary[w] = run_dense(env, w, st, wu, want_cpu=not args.no_cpu_baseline,
                                  verify=not args.no_verify, c4_rows=args.c4_rows, cpu_budget_s=9.0)
     host_api = None
-    if not args.no_host_api and env.world == 1 and args.workload == "c2" and env.rank == 0:
+    if not args.no_host_api and env.n_gpus == 1 and args.workload == "c2" and env.rank == 0:
         host_api = {w: run_host_api(env, w) for w in ("c2", "c2p")}
 
     if env.rank == 0:
@@ -552,9 +636,11 @@ def main():
             "metric": "queries/sec (exact inner-product top-k, recall vs FAISS-flat restatement)",
             "value": head["value"],
             "unit": head["unit"],
-            "n_gpus": env.world,
-            "rccl_ranks_seen": env.ranks_seen,
-            "devices_seen": env.devices_seen,
+            "n_gpus": env.n_gpus,
+            "rccl_ranks_seen": ((env.n_gpus if getattr(env, "rccl_in_library", False) else 0)
+                                if env.inlib else env.ranks_seen),
+            "devices_seen": (len({sh[0] for sh in getattr(env, "shards_seen", [])})
+                             if env.inlib else env.devices_seen),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"],
@@ -577,8 +663,16 @@ def main():
             out["secondary"] = secondary
         if host_api:
             out["host_api"] = host_api
+        if env.inlib:
+            out["process_model"] = ("one process: ls_create_sharded over devices "
+                                    f"{env.shard_devices}; exchange = "
+                                    + ("RCCL all-gather inside the library"
+                                       if getattr(env, "rccl_in_library", False)
+                                       else "device-to-device copies (shards share a device)"))
+            if not env.share_gpu and out["devices_seen"] != env.n_gpus:
+                raise SystemExit("bench.py: the sharded handle did not land on N distinct devices")
         if env.share_gpu:
-            out["rehearsal"] = (f"{env.world} ranks share {env.devices_seen} GPU(s) over gloo: "
+            out["rehearsal"] = (f"{env.n_gpus} shards share {out['devices_seen']} GPU(s): "
                                 "exercises the N > 1 code path only, the value is not a result")
         print(json.dumps(out), flush=True)
     env.close()

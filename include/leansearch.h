@@ -138,8 +138,10 @@ int ls_search(ls_index* index, const float* q, int64_t nq, int32_t k, uint32_t f
  * Lifetimes of an async / pipelined call: the QUERY buffer may be reused as soon as the work
  * queued on `stream` so far has consumed it (stream order; the library keeps its own copy for
  * repairs); the OUTPUT buffers must stay valid until the ls_check that covers the call, because a
- * repaired query is re-written in place. Call ls_check before trusting the results of batched
- * (MFMA path, nq > 16 on an fp16 index) or pipelined searches. */
+ * repaired query is re-written in place. Call ls_check before trusting the results of ANY batched
+ * call (the speculative MFMA paths: nq > 16 on an fp16 index, nq >= 24 on an fp32 index, on shards
+ * of at least 8192 rows) or of any pipelined search; per-query scan-path calls (everything else)
+ * are exact in stream order. ls_debug_counter(index, 10) names the path the last call took. */
 int ls_search_device(ls_index* index, const void* d_q, int64_t nq, int32_t k, uint32_t flags,
                      void* d_out_scores, void* d_out_indices, void* stream);
 

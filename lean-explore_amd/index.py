@@ -260,10 +260,12 @@ class FlatIPIndex:
 
         q: float32 CUDA tensor [nq, d]. Work is queued on ``stream`` (default: torch's current
         stream). Returns (scores float32 [nq, k], indices int64 [nq, k]) CUDA tensors.
-        ``asynchronous``: queue and return, results ordered on the stream. For batched calls
-        (nq > 16 on an fp16 index) call :meth:`check` before trusting them: it repairs the rare
-        query the speculative threshold short-changed, re-writing its rows of the output tensors
-        (keep those alive until then; ``q`` may be reused at once in stream order).
+        ``asynchronous``: queue and return, results ordered on the stream. For ANY batched call
+        (the speculative MFMA paths: nq > 16 on an fp16 index, nq >= 24 on an fp32 index) call
+        :meth:`check` before trusting them: it repairs the rare query the speculative threshold
+        short-changed, re-writing its rows of the output tensors (keep those alive until then;
+        ``q`` may be reused at once in stream order). On a sharded index (``devices=[...]``) ``q``
+        and the outputs live on ``devices[0]``.
         ``pipeline``: queue on the index's internal lanes so consecutive calls overlap; results
         are valid only after :meth:`check`.
         """

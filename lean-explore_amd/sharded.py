@@ -12,7 +12,8 @@ reference src/lean_explore/search/engine.py:159); sharding is this build's addit
        same total order (score desc, global row asc)  ->  identical to the 1-GPU result, bit for
        bit, for every G.
 
-One process per GPU, launched by torchrun. ``local_search`` / ``merge`` are injectable so that
+One process per GPU, launched by torchrun. (The same partitioning inside ONE process, behind the C
+ABI, is ls_create_sharded / ``FlatIPIndex(devices=[...])``: csrc/ls_shard.hip.) ``local_search`` / ``merge`` are injectable so that
 the collective plumbing is testable with gloo on CPU-only hosts (tests/test_sharded_cpu.py
 injects the CPU oracle there; the defaults below are the HIP kernels and nothing else).
 """
@@ -109,8 +110,10 @@ class ShardedFlatIPIndex:
     # ------------------------------------------------------------------ search
     def search_device(self, q, k: int, *, normalize: bool = False):
         """q: float32 tensor [nq, d] (same on every rank). Returns (scores, rows) [nq, k]
-        tensors, identical on every rank. All work is queued on the current stream; for batched
-        calls (nq > 16, fp16 shards) the result is final after :meth:`finish`."""
+        tensors, identical on every rank. All work is queued on the current stream and the local
+        search is ALWAYS asynchronous: for any batched call (the shards' speculative MFMA paths:
+        nq > 16 on fp16 shards, nq >= 24 on fp32 shards) the tensors are provisional until
+        :meth:`finish`, with one rank as with many (``finish`` then is the local ls_check)."""
         import torch
         import torch.distributed as dist
 

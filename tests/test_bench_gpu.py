@@ -29,7 +29,8 @@ def test_gpus_2_self_spawns_two_ranks():
     """One GPU here: the two ranks share it over gloo (LS_BENCH_SHARE_GPU, a rehearsal of the
     N > 1 code path: row shards, pipelined packed all-gather, strided merge, max-over-ranks)."""
     p, out = run_bench(["--gpus", "2", "--workload", "c1", "--steps", "48", "--warmup", "8",
-                        "--secondary", "none", "--no-host-api", "--no-cpu-baseline"],
+                        "--secondary", "none", "--no-host-api", "--no-cpu-baseline",
+                        "--launcher", "torchrun"],
                        {"LS_BENCH_SHARE_GPU": "1"})
     assert p.returncode == 0, p.stderr[-2000:]
     assert out is not None and out["n_gpus"] == 2 and out["rccl_ranks_seen"] == 2
@@ -41,10 +42,24 @@ def test_gpus_2_batched_exchange_rehearsal():
     """The batched (MFMA) path sharded two ways: async local search, flags shipped with the
     results, finish() after the timed region."""
     p, out = run_bench(["--gpus", "2", "--workload", "c3", "--steps", "6", "--warmup", "2",
-                        "--secondary", "none", "--no-host-api", "--no-cpu-baseline"],
+                        "--secondary", "none", "--no-host-api", "--no-cpu-baseline",
+                        "--launcher", "torchrun"],
                        {"LS_BENCH_SHARE_GPU": "1"})
     assert p.returncode == 0, p.stderr[-2000:]
     assert out["n_gpus"] == 2 and out["recall_at_k"] == 1.0
+
+
+@pytest.mark.parametrize("workload,steps", [("c1", 40), ("c3", 6), ("c4", 3)])
+def test_gpus_n_in_one_process_through_the_sharded_handle(workload, steps):
+    """`bench.py --gpus 3` with no launcher: ONE process, the library's own sharded handle
+    (ls_create_sharded). One GPU here, so the three shards share it (copies instead of RCCL)."""
+    p, out = run_bench(["--gpus", "3", "--workload", workload, "--steps", str(steps), "--warmup", "2",
+                        "--secondary", "none", "--no-host-api", "--no-cpu-baseline",
+                        "--c4-rows", "200000"], {"LS_BENCH_SHARE_GPU": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["n_gpus"] == 3 and out["config"]["parallelism"] == "row-shard x3"
+    assert out["recall_at_k"] == 1.0 and "one process" in out["process_model"]
+    assert "rehearsal" in out and out["devices_seen"] == 1 and out["rccl_ranks_seen"] == 0
 
 
 def test_refuses_rank_count_it_cannot_run():
@@ -61,8 +76,9 @@ def test_refuses_rank_count_it_cannot_run():
 
 
 def test_default_line_carries_both_metric_halves_and_host_api():
-    p, out = run_bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    p, out = run_bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--c4-rows", "2000000"])
     assert p.returncode == 0, p.stderr[-2000:]
+    assert out["secondary"]["c4"]["recall_at_k"] == 1.0 and out["secondary"]["c2p"]["recall_at_k"] == 1.0
     assert out["n_gpus"] == 1 and out["config"]["workload"].startswith("c2:")
     assert out["recall_at_k"] == 1.0 and 0.3 < out["roofline"]["frac"] <= 1.0
     c3 = out["secondary"]["c3"]

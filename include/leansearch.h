@@ -230,6 +230,9 @@ int ls_bm25_create(ls_bm25** out, const int64_t* indptr, const int32_t* indices,
 int ls_bm25_search(ls_bm25* index, const int32_t* token_ids, int32_t n_tokens, int32_t k,
                    float* out_scores, int64_t* out_docs);
 int64_t ls_bm25_ntotal(const ls_bm25* index);
+/* Test hook. counter 0: searches whose selection step left its fast path; counter 1: those that
+ * needed the general select over the score vector. */
+int64_t ls_bm25_debug_counter(ls_bm25* index, int32_t which);
 void ls_bm25_destroy(ls_bm25* index);
 
 const char* ls_last_error(void); /* thread-local; valid until the next call on this thread */

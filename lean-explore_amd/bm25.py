@@ -152,6 +152,10 @@ class BM25Index:
             scores.ctypes.data, docs.ctypes.data))
         return docs, scores
 
+    def debug_counter(self, which: int) -> int:
+        """0: searches whose selection left the fast path; 1: those that took the general select."""
+        return int(native.load().ls_bm25_debug_counter(self._ensure(), which))
+
     def close(self) -> None:
         self._drop()
 

@@ -2,16 +2,22 @@
 // scoring of bm25s (reference src/lean_explore/search/engine.py:192-223 calls
 // `bm25.retrieve([tokens], k=1000)`; indices built at src/lean_explore/extract/index.py:238-266).
 //
-// The index is a CSC matrix, one column per vocabulary token: rows = documents containing the
-// token, data = idf * tf-part - nonoccurrence (float32). A query adds the columns of its tokens
-// into an all-zero score vector IN TOKEN ORDER (one launch per token: a column never repeats a
-// document, so the adds need no atomics and the float32 sum has the same order as bm25s's
-// numpy loop -> bit-identical scores), adds sum(nonoccurrence[tokens]) and selects the top k
-// with the same machinery as the dense path (per-workgroup candidates + bounds -> finalize).
+// bm25s keeps a CSC matrix, one column per vocabulary token (rows = documents containing the
+// token, data = idf * tf-part - nonoccurrence, float32), and scores a query by adding its tokens'
+// columns into a zero vector in token order. The index arrives in that layout (the reference's
+// on-disk files) and is transposed ONCE at creation into a document-major copy in HBM:
+//     doc_ptr[n_docs + 1]  (u32)      entries[nnz] = (token id, value) pairs, 8 B each
+// One launch then scores every document: a lane owns a document, walks the query's tokens IN
+// QUERY ORDER and adds the value of each token the document holds (a document holds a token at
+// most once; a token repeated in the query is added again, as bm25s does) — the same float32
+// additions in the same order as bm25s's numpy loop, hence bit-identical scores — adds the
+// query's non-occurrence sum and feeds the same per-workgroup candidates + bound + finalize_body
+// selection as the dense path. Two launches per query (score + select) instead of one per token
+// plus two.
 //
-// HBM-bound integer/byte work: bytes per query = sum over tokens of 8 B * |column| (row id +
-// value) + 12 B * n_docs (the candidate sweep: read the sums, write the final scores, reset the
-// accumulator to zero for the next query).
+// HBM-bound integer/byte work: bytes per query = 4 B * (n_docs + 1) + 8 B * nnz (the whole index
+// once) + 4 B * n_docs (final scores, kept for the selection's rescue path): 13 MB for 200 k names
+// - a latency-bound problem at this size, which is why the launch count is what matters.
 #include "ls_select_dev.h"
 
 #include <algorithm>
@@ -25,11 +31,10 @@ struct ls_bm25 {
     int64_t n_docs = 0, n_vocab = 0, nnz = 0;
     std::vector<int64_t> h_indptr;   // host copy: column extents are launch parameters
     std::vector<float> h_nonocc;
-    int32_t* d_indices = nullptr;
-    float* d_data = nullptr;
-    float* d_S = nullptr;   // accumulator: all zeros between searches (the candidate sweep resets it)
-    float* d_F = nullptr;   // final scores of the last search (the finalize step's rescue path)
-    bool dirty = false;     // a search failed between its first add and its sweep
+    u32* d_doc_ptr = nullptr;  // document-major copy: entries of document r are [doc_ptr[r], doc_ptr[r+1])
+    uint2* d_entries = nullptr;  // (token id, float bits)
+    float* d_F = nullptr;   // scores of the last search (partial sums between the launches of a
+                            // > LS_BM25_QTOK-token query; the finalize step's rescue path reads it)
     float* h_out_s = nullptr;    // pinned, device-visible: the finalize step writes results here
     int64_t* h_out_i = nullptr;
     u64* d_cand = nullptr;
@@ -40,49 +45,104 @@ struct ls_bm25 {
     std::mutex mu;
 };
 
-__global__ __launch_bounds__(256) void bm25_zero_kernel(float* __restrict__ S, long long n) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        S[i] = 0.0f;
-}
+#define LS_BM25_QTOK 32  // query tokens per launch (kernel arguments; longer queries chain launches)
+#define LS_BM25_REG 8    // document entries kept in registers (names have a handful of tokens)
+struct ls_bm25_query {
+    int32_t tok[LS_BM25_QTOK];
+};
 
-__global__ __launch_bounds__(256) void bm25_add_column_kernel(float* __restrict__ S,
-                                                              const int32_t* __restrict__ rows,
-                                                              const float* __restrict__ vals,
-                                                              long long len) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < len; i += (long long)gridDim.x * 256)
-        S[rows[i]] += vals[i];
-}
-
-// F[r] = S[r] + shift (the query's non-occurrence sum), S[r] = 0 for the next search (no separate
-// zeroing launch), then per-workgroup best kprime keys + bound, exactly what the dense scan emits,
-// so finalize_body can prove / complete the top-k.
-__global__ __launch_bounds__(256) void bm25_candidates_kernel(float* __restrict__ S,
-                                                              float* __restrict__ F, long long n,
-                                                              float shift, u64* __restrict__ cand,
-                                                              u64* __restrict__ bound, int kprime) {
+// One pass over the document-major index. first: partial sums start at 0 (else at F[r]); last: add
+// the non-occurrence shift, store the final score and emit this workgroup's best kprime keys +
+// bound, exactly what the dense scan emits, so finalize_body can prove / complete the top-k.
+//
+// Row -> workgroup mapping. BM25 scores are discrete (few distinct tf / length combinations), so
+// the k-th score is usually shared by thousands of documents and the total order picks the ones
+// with the LOWEST row numbers: with 64-row tiles dealt to waves those all sit in a few workgroups,
+// each of which may emit only k' keys, the selection's proof fails and every query pays the rescue
+// sweep. Rows are therefore dealt in granules of 4: granule j (rows 4j .. 4j+3) belongs to
+// workgroup j mod B, so ANY run of low rows spreads evenly over all B workgroups (a lane quad reads
+// 16 contiguous bytes of doc_ptr; neighbouring quads are 4 B rows apart - an 8x over-fetch of a
+// 0.8 MB array that neighbouring workgroups share in L2).
+#define LS_BM25_U 4  // documents per lane in flight
+#ifndef LS_BM25_ABL
+#define LS_BM25_ABL 0  // timing ablations (wrong results): 1 no candidate emission, 2 also no entry loads
+#endif
+__global__ __launch_bounds__(256) void bm25_score_kernel(
+    const u32* __restrict__ doc_ptr, const uint2* __restrict__ entries, long long n,
+    ls_bm25_query q, int ntok, int first, int last, float shift, float* __restrict__ F,
+    u64* __restrict__ cand, u64* __restrict__ bound, int kprime) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kp = kprime + 1;
-    const long long W = (long long)gridDim.x * 4, gw = (long long)blockIdx.x * 4 + wave;
-    const long long NT = (n + 63) / 64;
+    const long long B = gridDim.x;
+    const long long NG = (n + 3) / 4;                      // granules
+    const long long steps = (NG + 64 * B - 1) / (64 * B);  // 64 granules per workgroup and step
     u64 lst = 0, thr = 0;
-    for (long long t = gw; t < NT; t += W) {
-        const long long row = t * 64 + lane;
-        const bool valid = row < n;
-        float s = 0.0f;
-        if (valid) {
-            s = S[row] + shift;
-            F[row] = s;
-            S[row] = 0.0f;
+    for (long long s0 = 0; s0 < steps; s0 += LS_BM25_U) {
+        long long row[LS_BM25_U];
+        u32 a[LS_BM25_U], b[LS_BM25_U];
+        float sc[LS_BM25_U];
+        bool valid[LS_BM25_U];
+#pragma unroll
+        for (int u = 0; u < LS_BM25_U; ++u) {
+            const long long j = blockIdx.x + B * ((s0 + u) * 64 + (threadIdx.x >> 2));
+            row[u] = 4 * j + (threadIdx.x & 3);
+            valid[u] = (s0 + u) < steps && row[u] < n;
+            a[u] = b[u] = 0;
+            if (valid[u]) {
+                a[u] = doc_ptr[row[u]];
+                b[u] = doc_ptr[row[u] + 1];
+            }
         }
-        const u64 key = valid ? ls_make_key(s, (u32)row) : 0ull;
-        u64 mask = __ballot(key > thr);
-        while (mask) {
-            const int j = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            wave_insert(lst, readlane64(key, j), lane, kp);
-            thr = readlane64(lst, kp - 1);
+        uint2 e[LS_BM25_U][LS_BM25_REG];
+#pragma unroll
+        for (int u = 0; u < LS_BM25_U; ++u) {
+            sc[u] = (valid[u] && !first) ? F[row[u]] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < LS_BM25_REG; ++j)
+                e[u][j] = (LS_BM25_ABL < 2 && a[u] + j < b[u]) ? entries[a[u] + j] : make_uint2(0xffffffffu, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < LS_BM25_U; ++u) {
+            float s = sc[u];
+            for (int qi = 0; qi < ntok; ++qi) {  // query order: the float32 sum is order-sensitive
+                const u32 tok = (u32)q.tok[qi];
+                bool hit = false;
+                u32 bits = 0;
+#pragma unroll
+                for (int j = 0; j < LS_BM25_REG; ++j)
+                    if (e[u][j].x == tok) {
+                        hit = true;
+                        bits = e[u][j].y;
+                    }
+                for (u32 j = a[u] + LS_BM25_REG; j < b[u]; ++j) {  // long documents: the tail from memory
+                    const uint2 x = entries[j];
+                    if (x.x == tok) {
+                        hit = true;
+                        bits = x.y;
+                    }
+                }
+                if (hit) s = s + __uint_as_float(bits);
+            }
+            if (last) s = s + shift;
+            if (valid[u]) F[row[u]] = s;
+            sc[u] = s;
+        }
+        if (!last || LS_BM25_ABL >= 1) continue;
+#pragma unroll
+        for (int u = 0; u < LS_BM25_U; ++u) {
+            const u64 key = valid[u] ? ls_make_key(sc[u], (u32)row[u]) : 0ull;
+            u64 mask = __ballot(key > thr);
+            while (mask) {
+                const int j = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const u64 v = readlane64(key, j);
+                if (v <= thr) continue;  // the ballot is older than the threshold: most of a first tile
+                wave_insert(lst, v, lane, kp);
+                thr = readlane64(lst, kp - 1);
+            }
         }
     }
+    if (!last) return;
     __shared__ u64 sm[4 * LS_KP_MAX];
     if (lane < LS_KP_MAX) sm[wave * LS_KP_MAX + lane] = (lane < kp) ? lst : 0ull;
     __syncthreads();
@@ -105,9 +165,8 @@ void ls_bm25_destroy(ls_bm25* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    (void)hipFree(ix->d_indices);
-    (void)hipFree(ix->d_data);
-    (void)hipFree(ix->d_S);
+    (void)hipFree(ix->d_doc_ptr);
+    (void)hipFree(ix->d_entries);
     (void)hipFree(ix->d_F);
     if (ix->h_out_s) (void)hipHostFree(ix->h_out_s);
     if (ix->h_out_i) (void)hipHostFree(ix->h_out_i);
@@ -158,18 +217,43 @@ int ls_bm25_create(ls_bm25** out, const int64_t* indptr, const int32_t* indices,
     int cu = 0;
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0)
         ix->n_cu = cu;
-    ix->blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_docs + 255) / 256, 2 * ix->n_cu));
+    // one workgroup per CU: with k' <= 15 keys each the selection step sees <= 4 k candidate keys
+    ix->blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_docs + 255) / 256, ix->n_cu));
     auto fail = [&](const char* what) {
         ls_set_error("ls_bm25_create: %s failed", what);
         ls_bm25_destroy(ix);
         return LS_ERR_HIP;
     };
+    if (nnz >= 0xffffffffll) {
+        ls_set_error("ls_bm25_create: %lld postings exceed the 32-bit document offsets", (long long)nnz);
+        ls_bm25_destroy(ix);
+        return LS_ERR_INVALID_ARG;
+    }
+    // transpose CSC -> document-major (counting sort on the document id; columns are visited in
+    // token order, so a document's entries end up sorted by token id)
+    std::vector<u32> doc_ptr((size_t)n_docs + 1, 0u);
+    for (int64_t i = 0; i < nnz; ++i) doc_ptr[(size_t)indices[i] + 1]++;
+    for (int64_t r = 0; r < n_docs; ++r) doc_ptr[(size_t)r + 1] += doc_ptr[(size_t)r];
+    std::vector<uint2> entries((size_t)std::max<int64_t>(nnz, 1));
+    {
+        std::vector<u32> fill(doc_ptr.begin(), doc_ptr.end() - 1);
+        for (int64_t t = 0; t < n_vocab; ++t)
+            for (int64_t i = indptr[t]; i < indptr[t + 1]; ++i) {
+                const size_t r = (size_t)indices[i];
+                u32 bits;
+                memcpy(&bits, &data[i], 4);
+                if (fill[r] > doc_ptr[r] && entries[fill[r] - 1].x == (u32)t) {
+                    ls_set_error("ls_bm25_create: column %lld lists document %zu twice", (long long)t, r);
+                    ls_bm25_destroy(ix);
+                    return LS_ERR_INVALID_ARG;
+                }
+                entries[fill[r]++] = make_uint2((u32)t, bits);
+            }
+    }
     const size_t nz = (size_t)std::max<int64_t>(nnz, 1), nd = (size_t)std::max<int64_t>(n_docs, 1);
-    if (hipMalloc((void**)&ix->d_indices, nz * 4) != hipSuccess) return fail("hipMalloc");
-    if (hipMalloc((void**)&ix->d_data, nz * 4) != hipSuccess) return fail("hipMalloc");
-    if (hipMalloc((void**)&ix->d_S, nd * 4) != hipSuccess) return fail("hipMalloc");
+    if (hipMalloc((void**)&ix->d_doc_ptr, (nd + 1) * 4) != hipSuccess) return fail("hipMalloc");
+    if (hipMalloc((void**)&ix->d_entries, nz * 8) != hipSuccess) return fail("hipMalloc");
     if (hipMalloc((void**)&ix->d_F, nd * 4) != hipSuccess) return fail("hipMalloc");
-    if (hipMemset(ix->d_S, 0, nd * 4) != hipSuccess) return fail("hipMemset");
     if (hipHostMalloc((void**)&ix->h_out_s, LS_MAX_K * 4, hipHostMallocDefault) != hipSuccess)
         return fail("hipHostMalloc");
     if (hipHostMalloc((void**)&ix->h_out_i, LS_MAX_K * 8, hipHostMallocDefault) != hipSuccess)
@@ -178,18 +262,29 @@ int ls_bm25_create(ls_bm25** out, const int64_t* indptr, const int32_t* indices,
     if (hipMalloc((void**)&ix->d_bound, (size_t)ix->blocks * 8) != hipSuccess) return fail("hipMalloc");
     if (hipMalloc((void**)&ix->d_counters, 32) != hipSuccess) return fail("hipMalloc");
     if (hipMemset(ix->d_counters, 0, 32) != hipSuccess) return fail("hipMemset");
-    if (nnz > 0) {
-        if (hipMemcpy(ix->d_indices, indices, (size_t)nnz * 4, hipMemcpyHostToDevice) != hipSuccess)
-            return fail("upload");
-        if (hipMemcpy(ix->d_data, data, (size_t)nnz * 4, hipMemcpyHostToDevice) != hipSuccess)
-            return fail("upload");
-    }
+    if (hipMemcpy(ix->d_doc_ptr, doc_ptr.data(), ((size_t)n_docs + 1) * 4, hipMemcpyHostToDevice) !=
+        hipSuccess)
+        return fail("upload");
+    if (nnz > 0 && hipMemcpy(ix->d_entries, entries.data(), (size_t)nnz * 8, hipMemcpyHostToDevice) !=
+                       hipSuccess)
+        return fail("upload");
     if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
     *out = ix;
     return LS_OK;
 }
 
 int64_t ls_bm25_ntotal(const ls_bm25* ix) { return ix ? ix->n_docs : -1; }
+
+// counter 0: searches whose selection step left the fast path (rescue sweep or general select);
+// counter 1: those that took the general path.
+int64_t ls_bm25_debug_counter(ls_bm25* ix, int32_t which) {
+    if (!ix || which < 0 || which > 7) return -1;  // 2..6: phase ticks of a -DLS_FIN_TIMING build
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (hipSetDevice(ix->device) != hipSuccess) return -1;
+    u32 v = 0;
+    if (hipMemcpy(&v, ix->d_counters + which, sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)v;
+}
 
 // token_ids: host int32 [n_tokens], ids of the query's tokens in query order (duplicates count
 // twice, like bm25s); out_scores host f32 [k], out_docs host i64 [k], (-FLT_MAX, -1) padded.
@@ -232,27 +327,25 @@ int ls_bm25_search(ls_bm25* ix, const int32_t* token_ids, int32_t n_tokens, int3
         return LS_OK;
     }
     if (n > 0) {
-        if (ix->dirty)  // a failed search left partial sums behind
-            hipLaunchKernelGGL(bm25_zero_kernel, dim3(ix->blocks), dim3(256), 0, s, ix->d_S, n);
-        ix->dirty = true;
         float shift = 0.0f;
-        for (int i = 0; i < n_tokens; ++i) {
-            const int64_t a = ix->h_indptr[token_ids[i]], b = ix->h_indptr[token_ids[i] + 1];
+        for (int i = 0; i < n_tokens; ++i)
             shift = shift + ix->h_nonocc[token_ids[i]];  // float32, query order (as bm25s sums)
-            if (b > a) {
-                const int grid = (int)std::min<int64_t>((b - a + 255) / 256, 8 * ix->n_cu);
-                hipLaunchKernelGGL(bm25_add_column_kernel, dim3(grid), dim3(256), 0, s, ix->d_S,
-                                   ix->d_indices + a, ix->d_data + a, (long long)(b - a));
-            }
-        }
         const int keff = (int)std::min<int64_t>(k, n);
         const double lam = (double)keff / ix->blocks;
         int kprime = (int)(lam + 5.0 * __builtin_sqrt(lam) + 3.0);
         kprime = std::max(2, std::min(kprime, LS_KP_MAX - 1));
-        hipLaunchKernelGGL(bm25_candidates_kernel, dim3(ix->blocks), dim3(256), 0, s, ix->d_S, ix->d_F,
-                           n, shift, ix->d_cand, ix->d_bound, kprime);
+        // LS_BM25_QTOK tokens per launch (kernel arguments); only the last launch of a longer
+        // query adds the shift and emits candidates, the ones before leave partial sums in F
+        for (int t0 = 0; t0 < n_tokens || t0 == 0; t0 += LS_BM25_QTOK) {
+            ls_bm25_query q;
+            const int m = std::max(0, std::min(LS_BM25_QTOK, n_tokens - t0));
+            for (int i = 0; i < LS_BM25_QTOK; ++i) q.tok[i] = i < m ? token_ids[t0 + i] : -1;
+            const int last = t0 + LS_BM25_QTOK >= n_tokens;
+            hipLaunchKernelGGL(bm25_score_kernel, dim3(ix->blocks), dim3(256), 0, s, ix->d_doc_ptr,
+                               ix->d_entries, n, q, m, (int)(t0 == 0), last, shift, ix->d_F, ix->d_cand,
+                               ix->d_bound, kprime);
+        }
         LS_HIP(hipGetLastError());
-        ix->dirty = false;
         ls_fin_batch jobs{};
         ls_fin_params& p = jobs.p[0];
         p.S = ix->d_F;

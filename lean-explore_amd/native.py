@@ -68,6 +68,7 @@ SYMBOLS: dict[str, tuple] = {
     "ls_bm25_create": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _i64, _i64, _i32]),
     "ls_bm25_search": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "ls_bm25_ntotal": (_i64, [_vp]),
+    "ls_bm25_debug_counter": (_i64, [_vp, _i32]),
     "ls_bm25_destroy": (None, [_vp]),
     "ls_last_error": (ctypes.c_char_p, []),
     "ls_version": (ctypes.c_char_p, []),

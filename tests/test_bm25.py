@@ -65,6 +65,23 @@ def test_hip_retrieve_bit_exact_vs_oracle():
         dref, sref = R.retrieve(ref, q, k)
         assert np.array_equal(sc, sref), q      # same float32 accumulation order: bit-identical
         assert np.array_equal(docs, dref), q    # ties (thousands) broken by ascending document
+    # tie-heavy queries (discrete BM25 scores: the k-th score is shared by thousands of names) stay
+    # on the selection's fast path: rows are dealt to workgroups in granules of 4
+    assert ix.debug_counter(0) <= 1 and ix.debug_counter(1) == 0
+    # a query of more than 32 tokens is scored by chained launches (partial sums in F), in order
+    long_q = (["nat", "add", "comm", "list", "map", "measure", "theory", "ker"] * 9)[:70]
+    docs, sc = ix.retrieve(long_q, 300)
+    dref, sref = R.retrieve(ref, long_q, 300)
+    assert np.array_equal(sc, sref) and np.array_equal(docs, dref)
+    # documents with more tokens than the 8 entries a lane keeps in registers
+    rng = np.random.default_rng(5)
+    fat = [list(dict.fromkeys(WORDS[j] for j in rng.integers(0, len(WORDS), size=rng.integers(1, 40))))
+           for _ in range(5000)]
+    fx, fref = BM25Index().index(fat), R.build(fat)
+    for q in (WORDS[:5], [WORDS[3]] * 3 + WORDS[10:14]):
+        docs, sc = fx.retrieve(q, 500)
+        dref, sref = R.retrieve(fref, q, 500)
+        assert np.array_equal(sc, sref) and np.array_equal(docs, dref), q
     small = BM25Index().index(corpus[:30])
     docs, sc = small.retrieve(["nat"], 100)     # k > n_docs -> padding
     dref, sref = R.retrieve(R.build(corpus[:30]), ["nat"], 100)

@@ -12,3 +12,6 @@ t0=time.perf_counter(); K=300
 for _ in range(K): ix.retrieve(q,1000)
 dt=(time.perf_counter()-t0)/K
 print(f"bm25 N=200k query={q} postings={nnz}: {dt*1e6:.1f} us/query (host API, sync) {1/dt:.0f} QPS; bytes={nnz*8+200000*12}")
+print("selection left the fast path:", ix.debug_counter(0), "of", 320, "queries; general path:", ix.debug_counter(1))
+ph=[ix.debug_counter(i) for i in range(2,7)]
+if any(ph): print("finalize phases (100 MHz ticks): load", ph[0], "score-radix", ph[1], "row-radix+compact", ph[2], "sort", ph[3], "output", ph[4])

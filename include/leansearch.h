@@ -197,6 +197,9 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * option 5: speculative, verified sample threshold on the batched path (default on; off = the
  * certified k-th sample score); option 6: several queries per corpus pass on the scan path
  * (default on); option 7: force the number of scan workgroups per launch (0 = automatic);
+ * option 9: ordered (non-pipelined) scan-path calls run the selection step inside the scan launch of
+ * its own query, behind an arrival counter of the scan workgroups: 0 never, 1 (default) for launches
+ * of at most 200 scan workgroups (small shards), 2 always;
  * option 8 (sharded handles): exchange step 0 = RCCL all-gather between distinct devices (default),
  * 1 = peer copies into the primary device's gather buffer.
  * counter 9: kernel launches the most recent batched call queued (counted per launch);

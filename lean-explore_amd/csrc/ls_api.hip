@@ -215,6 +215,7 @@ void ls_destroy(ls_index* ix) {
     (void)hipFree(ix->d_out_s);
     (void)hipFree(ix->d_out_i);
     (void)hipFree(ix->d_counters);
+    (void)hipFree(ix->d_arrive);
     (void)hipFree(ix->d_qpad);
     for (auto& st : ix->bc_sets) {
         if (st.lane_stream) {
@@ -389,6 +390,22 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         }
         ls_scan_args a{};
         a.nfin = 0;
+        // Ordered (non-pipelined) calls: the selection jobs of THIS group ride on its own scan
+        // launch and wait inside the kernel for the scan workgroups' arrival counter - one launch
+        // per group instead of scan + selection, no kernel boundary in front of the selection.
+        const int own_keys_cap = std::max(256, blocks * kprime);
+        // Every arriving workgroup pays an agent-scope release (an L2 write-back walk, ~0.07 us each,
+        // serialised per XCD): a win for the few workgroups of a small shard (N = 25 k: 32.6 vs
+        // 35.0 us per synchronous call), a loss for big ones (N = 200 k, 448 workgroups: 86 vs 72 us),
+        // so "auto" stops at LS_SAME_LAUNCH_MAX_BLOCKS.
+        const bool same_launch =
+            !pipeline && ix->n > 0 &&
+            (ix->opt_same_launch == 2 || (ix->opt_same_launch == 1 && blocks <= LS_SAME_LAUNCH_MAX_BLOCKS)) &&
+            ls_fin_lds_bytes_host(own_keys_cap, (int)std::max<int64_t>(keff, 1)) <= LS_PIGGY_LDS_MAX;
+        if (ix->n_pending && same_launch) {  // left by an earlier pipelined call: its own launch
+            rc = ls_i_flush_pending(ix);
+            if (rc != LS_OK) return rc;
+        }
         if (ix->n_pending) {
             const int keff_p = (int)std::min<int64_t>(ix->pending.p[0].k, ix->n);
             if (ls_fin_lds_bytes_host(ix->pending.p[0].keys_cap, keff_p) <= LS_PIGGY_LDS_MAX) {
@@ -422,6 +439,37 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         a.b_stride = ix->max_blocks;
         a.blocks = blocks;
         a.kprime = kprime;
+        ls_fin_batch& jobs = same_launch ? a.fin : ix->pending;
+        if (same_launch) {
+            if (!ix->d_arrive) {
+                LS_HIP(hipMalloc((void**)&ix->d_arrive, sizeof(u32)));
+                LS_HIP(hipMemsetAsync(ix->d_arrive, 0, sizeof(u32), s));
+                ix->arrive_count = 0;
+            }
+            ix->arrive_count += (u32)blocks;
+            a.nfin = real;
+            a.arrive = ix->d_arrive;
+        }
+        for (int i = 0; i < real; ++i) {
+            ls_fin_params& p = jobs.p[i];
+            p.S = st.d_S + (size_t)i * a.s_stride;
+            p.n = ix->n;
+            p.cand = st.d_cand + (size_t)i * a.c_stride;
+            p.bound = st.d_bound + (size_t)i * a.b_stride;
+            p.blocks = blocks;
+            p.kprime = kprime;
+            p.k = k;
+            p.keys_cap = own_keys_cap;
+            p.force_slow = ix->opt_force_slow;
+            p.base = ix->base;
+            p.out_scores = d_out_s + (q0 + i) * k;
+            p.out_indices = (long long*)(d_out_i + (q0 + i) * k);
+            p.counters = ix->d_counters;
+            p.done = ix->done_base ? ix->done_base + (q0 + i) : nullptr;
+            p.done_val = ix->done_seq;
+            p.arrive = same_launch ? ix->d_arrive : nullptr;
+            p.arrive_target = ix->arrive_count;
+        }
         if (prof) LS_HIP(hipEventRecord(pe[0], s));
         rc = ls_launch_scan(ix->d_corpus, ix->n, g, a, s);
         if (rc != LS_OK) return rc;
@@ -430,25 +478,9 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             LS_HIP(hipEventRecord(pe[1], s));
             ix->prof_n++;
         }
-        ix->n_pending = real;
-        ix->pending_stream = s;
-        for (int i = 0; i < real; ++i) {
-            ls_fin_params& p = ix->pending.p[i];
-            p.S = st.d_S + (size_t)i * a.s_stride;
-            p.n = ix->n;
-            p.cand = st.d_cand + (size_t)i * a.c_stride;
-            p.bound = st.d_bound + (size_t)i * a.b_stride;
-            p.blocks = blocks;
-            p.kprime = kprime;
-            p.k = k;
-            p.keys_cap = std::max(256, blocks * kprime);
-            p.force_slow = ix->opt_force_slow;
-            p.base = ix->base;
-            p.out_scores = d_out_s + (q0 + i) * k;
-            p.out_indices = (long long*)(d_out_i + (q0 + i) * k);
-            p.counters = ix->d_counters;
-            p.done = ix->done_base ? ix->done_base + (q0 + i) : nullptr;
-            p.done_val = ix->done_seq;
+        if (!same_launch) {
+            ix->n_pending = real;
+            ix->pending_stream = s;
         }
         ix->last_set = gen;
         q0 += real;
@@ -1156,6 +1188,10 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
     if (ix->group) return ls_group_debug_option(ix, which, value);
     if (which == 0) {  // force k' (0 = automatic)
         ix->opt_kprime = value;
+        return LS_OK;
+    }
+    if (which == 9) {  // ordered calls: selection inside the scan launch of its own query
+        ix->opt_same_launch = value < 0 ? 0 : (value > 2 ? 2 : value);  // 0 never, 1 auto (default), 2 always
         return LS_OK;
     }
     if (which == 7) {  // force the number of scan workgroups per launch (0 = automatic)

@@ -28,6 +28,7 @@ typedef unsigned int u32;
 #define LS_FINAL_THREADS 1024
 #define LS_FINAL_CAP 8192            // keys the finalize workgroup sorts in LDS (64 KiB)
 #define LS_SCAN_MAX_NQ 16            // nq <= this: per-query HBM-bound scan path
+#define LS_SAME_LAUNCH_MAX_BLOCKS 200 // ordered calls with at most this many scan workgroups select inside the scan launch
 #ifndef LS_SCAN_SMALL
 #define LS_SCAN_SMALL 1              // small shards: waves rank their <= 64 keys once instead of inserting row by row
 #endif
@@ -179,6 +180,12 @@ struct ls_fin_params {
     u32* counters;         // [0] left the fast path, [1] took the general path
     u32* done;             // optional: pinned host word that receives done_val once the outputs
     u32 done_val;          //           are visible to the host (the host API spins on it)
+    // Same-launch selection: the job rides on the scan launch of ITS OWN query and must wait for
+    // that launch's scan workgroups: it starts once *arrive has reached arrive_target (the scan
+    // workgroups add 1 each after releasing their stores at agent scope). Null: the candidates
+    // were written by an earlier launch (stream order), nothing to wait for.
+    u32* arrive;
+    u32 arrive_target;
 };
 #define LS_SCAN_NQ_MAX 8
 struct ls_fin_batch {
@@ -213,6 +220,7 @@ struct ls_scan_args {
     int blocks, kprime;
     int nfin;              // selection jobs riding on this launch
     ls_fin_batch fin;
+    u32* arrive;           // non-null: the jobs are this launch's own (see ls_fin_params::arrive)
 };
 int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const ls_scan_args& a,
                    hipStream_t s);

@@ -106,6 +106,9 @@ struct ls_index {
     float* d_qpad = nullptr; size_t qpad_cap = 0;  // padded query group (ragged last group)
     long long s_stride = 0;            // floats between the score vectors of one generation
     int32_t opt_multi_query = 1;       // several queries per corpus pass (groups of 8 / 4)
+    int32_t opt_same_launch = 1;       // ordered calls: the selection rides on its own query's scan launch
+    u32* d_arrive = nullptr;           // arrival counter of the scan workgroups (same-launch selection)
+    u32 arrive_count = 0;              // arrivals queued so far (host mirror; the kernels compare modulo 2^32)
     int32_t max_blocks = 0;
     float* d_out_s = nullptr;  int64_t* d_out_i = nullptr;  size_t out_cap = 0;  // nq*k
     u32* d_counters = nullptr;                        // [0] finalize slow-path count

@@ -170,13 +170,26 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
     const f32x4* __restrict__ corpus, long long n, int chunks, const float* __restrict__ qraw,
     int d, int normalize, int reverse, float* __restrict__ S, long long s_stride,
     u64* __restrict__ cand, long long c_stride, u64* __restrict__ bound, long long b_stride,
-    int kprime, int nfin, ls_fin_batch fin) {
+    int kprime, int nfin, ls_fin_batch fin, u32* __restrict__ arrive) {
     // The first `nfin` workgroups of a launch run the PREVIOUS launch's selection jobs
     // (finalize_body, ls_select_dev.h) while every other workgroup scans for the current queries:
     // selection costs neither a launch nor a kernel boundary and hides under the scan.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     if ((int)blockIdx.x < nfin) {
-        finalize_body<LS_SCAN_THREADS>(fin.p[blockIdx.x], smem_dyn, threadIdx.x);
+        const ls_fin_params& fp = fin.p[blockIdx.x];
+        if (fp.arrive) {
+            // this launch's own scan workgroups produce the job's input: wait until all of them
+            // have arrived (they never wait for anything, so they always get to run: the first
+            // nfin workgroups of the grid may spin here whatever the occupancy), then acquire
+            if (threadIdx.x == 0) {
+                while ((int)(__hip_atomic_load(fp.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                             fp.arrive_target) < 0)
+                    __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        finalize_body<LS_SCAN_THREADS>(fp, smem_dyn, threadIdx.x);
         return;
     }
     const int bid = (int)blockIdx.x - nfin;
@@ -282,7 +295,11 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
                 if (valid) {
-                    S[qi * s_stride + row] = sc[qi];
+                    if (arrive)
+                        __hip_atomic_store(&S[qi * s_stride + row], sc[qi], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        S[qi * s_stride + row] = sc[qi];
                     lst[qi] = ls_make_key(sc[qi], (u32)row);  // this lane's one key of the launch
                 }
             }
@@ -290,7 +307,13 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
         }
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
-            if (valid) S[qi * s_stride + row] = sc[qi];  // TR contiguous floats
+            if (valid) {  // TR contiguous floats
+                if (arrive)  // same-launch selection: write through, nothing left dirty for the release
+                    __hip_atomic_store(&S[qi * s_stride + row], sc[qi], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    S[qi * s_stride + row] = sc[qi];
+            }
             const u64 key = valid ? ls_make_key(sc[qi], (u32)row) : 0ull;
             u64 mask = __ballot(key > thr[qi]);
             while (mask) {  // rare once the threshold has warmed up
@@ -354,6 +377,16 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
         }
         if (rank < kprime) cand[qi * c_stride + (long long)bid * kprime + rank] = mine;
         if (rank == kprime) bound[qi * b_stride + bid] = mine;
+    }
+    if (arrive) {
+        // publish: every wave drains its stores, the workgroup meets, ONE lane releases at agent
+        // scope (the selection workgroup may sit on another XCD, behind another L2) and arrives
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 #ifdef LS_SCAN_TIMING
     LS_SSTAMP(4);
@@ -433,7 +466,7 @@ static int launch_lvq(const void* corpus, int64_t n, const ls_geom& g, const ls_
                            (const f32x4*)corpus, (long long)n, g.chunks, a.d_q, g.d,               \
                            a.normalize ? 1 : 0, a.reverse ? 1 : 0, a.d_S, (long long)a.s_stride,   \
                            a.d_cand, (long long)a.c_stride, a.d_bound, (long long)a.b_stride,      \
-                           a.kprime, a.nfin, a.fin);                                               \
+                           a.kprime, a.nfin, a.fin, a.arrive);                                     \
     }
     if constexpr (NQ == 1) {
         if (small) LS_SCAN_LAUNCH(true) else LS_SCAN_LAUNCH(false)

@@ -433,12 +433,24 @@ def test_launch_counter_counts_and_path_counter():
     if ix.debug_counter(8) == 0:             # (a repaired query would add scan launches)
         assert ix.debug_counter(11) - before == 5
     before = ix.debug_counter(11)
-    ix.search(q[:1], 10)                     # per-query scan path: scan + selection launch
-    assert ix.debug_counter(10) == 1 and ix.debug_counter(11) - before == 2
-    ix.debug_option(4, 0)                    # MFMA path off: 40 queries = 5 groups of 8 + selection
+    ix.debug_option(9, 2)
+    ix.search(q[:1], 10)                     # per-query scan path: ONE launch (selection rides inside)
+    assert ix.debug_counter(10) == 1 and ix.debug_counter(11) - before == 1
+    ix.debug_option(9, 0)                    # selection as its own launch
+    before = ix.debug_counter(11)
+    ix.search(q[:1], 10)
+    assert ix.debug_counter(11) - before == 2
+    ix.debug_option(4, 0)                    # MFMA path off: 40 queries = 5 groups of 8 + 1 selection
     before = ix.debug_counter(11)
     ix.search(q, 10)
     assert ix.debug_counter(10) == 1 and ix.debug_counter(11) - before == 6
+    ix.debug_option(9, 2)                    # same-launch selection: 5 launches
+    before = ix.debug_counter(11)
+    D1, I1 = ix.search(q, 10)
+    assert ix.debug_counter(11) - before == 5
+    ix.debug_option(9, 0)
+    D0, I0 = ix.search(q, 10)
+    assert np.array_equal(D0, D1) and np.array_equal(I0, I1)
     ix.close()
 
 

@@ -25,7 +25,9 @@
  *     <= -FLT_MAX are never returned.
  *   - ls_search / ls_search_device may be called concurrently on one handle, from several threads
  *     and on several streams: calls are serialised inside, and device work that shares the
- *     handle's scratch is fenced across streams by events.
+ *     handle's scratch is fenced across streams by events. Concurrent ls_search calls do not
+ *     queue one behind the other: whichever thread is serving takes every waiting request of the
+ *     same k and flags (up to 16 queries) into ONE corpus pass; waiters sleep, they do not spin.
  *   - there is no CPU fallback: with no usable HIP device every compute entry point fails with
  *     LS_ERR_NO_DEVICE.
  */
@@ -200,6 +202,8 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * option 9: ordered (non-pipelined) scan-path calls run the selection step inside the scan launch of
  * its own query, behind an arrival counter of the scan workgroups: 0 never, 1 (default) for launches
  * of at most 200 scan workgroups (small shards), 2 always;
+ * option 10: synchronous host searches (ls_search) that arrive while another one is running are
+ * served together, up to 16 queries of equal k and flags per corpus pass (default on);
  * option 8 (sharded handles): exchange step 0 = RCCL all-gather between distinct devices (default),
  * 1 = peer copies into the primary device's gather buffer.
  * counter 9: kernel launches the most recent batched call queued (counted per launch);
@@ -208,7 +212,8 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * that were cut into sub-batches because the candidate queues could not hold the whole batch;
  * sharded handles: counter 13 exchange steps run, 14 re-exchanges after a shard repaired a
  * query, 15 exchange transport (0 copies, 1 RCCL selected, 2 RCCL communicators initialised);
- * counters 0, 1, 8, 11, 12 are summed over the shards, 9 and 10 are the primary shard's.
+ * counters 0, 1, 8, 11, 12 are summed over the shards, 9 and 10 are the primary shard's;
+ * counter 16: combined batches ls_search served, 17: the requests they carried.
  * counter 0: searches whose finalize step left the fast path (rescue or general); counter 1:
  * those that took the general path; counter 8: queries of batched calls that were repaired by
  * the exact scan path. */

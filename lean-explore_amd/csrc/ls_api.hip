@@ -835,14 +835,11 @@ int ls_i_check_search_args(const ls_index* ix, const void* q, int64_t nq, int32_
 }
 
 
-extern "C" {
-
-int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flags,
-              float* out_scores, int64_t* out_indices) {
-    int rc = ls_i_check_search_args(ix, q, nq, k, flags & ~(LS_FLAG_ASYNC | LS_FLAG_PIPELINE), out_scores,
-                               out_indices);
-    if (rc != LS_OK) return rc;
-    if (nq == 0) return LS_OK;
+// One synchronous host search with the handle's mutex taken: what ls_search was before calls could
+// be combined (below).
+static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flags,
+                              float* out_scores, int64_t* out_indices) {
+    int rc = LS_OK;
     std::lock_guard<std::mutex> lk(ix->mu);
     if (ix->group)
         return ls_group_search(ix, q, true, nq, k, flags & LS_FLAG_NORMALIZE, out_scores, out_indices,
@@ -914,6 +911,108 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
     memcpy(out_scores, ix->h_out_s, on * sizeof(float));
     memcpy(out_indices, ix->h_out_i, on * sizeof(int64_t));
     return LS_OK;
+}
+
+// ---- combining concurrent callers ---------------------------------------------------------------
+// The reference's event loop makes one blocking index.search per query (search/engine.py:250), but
+// an MCP server with several clients, or a threaded caller, has several of them in flight. The
+// scan path serves up to 8 queries per corpus pass (8 queries: 135 us; 8 passes of one: 8 x 72 us),
+// so requests that arrive while a search is running are not queued behind the mutex one by one:
+// they wait in a queue, and whoever holds the leadership serves ALL compatible waiters (same k, same
+// flags, <= LS_SCAN_MAX_NQ queries in total) as ONE batch, then hands their results back. A lone
+// caller becomes leader at once and pays nothing; waiters sleep on a condition variable (no
+// spinning on the mutex). Results are those of the separate calls: every query's arithmetic is
+// the same whatever group it rides in.
+struct ls_req {
+    const float* q;
+    int64_t nq;
+    int32_t k;
+    uint32_t flags;
+    float* out_s;
+    int64_t* out_i;
+    int rc = LS_OK;
+    bool done = false;
+    char err[256] = "";
+};
+
+static void serve_requests(ls_index* ix, std::vector<ls_req*>& batch) {
+    if (batch.size() == 1) {
+        ls_req* r = batch[0];
+        r->rc = host_search_locked(ix, r->q, r->nq, r->k, r->flags, r->out_s, r->out_i);
+        if (r->rc != LS_OK) snprintf(r->err, sizeof(r->err), "%s", g_err);
+        return;
+    }
+    const int32_t d = ix->g.d, k = batch[0]->k;
+    int64_t total = 0;
+    for (ls_req* r : batch) total += r->nq;
+    ix->comb_q.resize((size_t)total * d);
+    ix->comb_s.resize((size_t)total * k);
+    ix->comb_i.resize((size_t)total * k);
+    int64_t at = 0;
+    for (ls_req* r : batch) {
+        memcpy(ix->comb_q.data() + at * d, r->q, (size_t)r->nq * d * sizeof(float));
+        at += r->nq;
+    }
+    const int rc = host_search_locked(ix, ix->comb_q.data(), total, k, batch[0]->flags,
+                                      ix->comb_s.data(), ix->comb_i.data());
+    at = 0;
+    for (ls_req* r : batch) {
+        r->rc = rc;
+        if (rc == LS_OK) {
+            memcpy(r->out_s, ix->comb_s.data() + at * k, (size_t)r->nq * k * sizeof(float));
+            memcpy(r->out_i, ix->comb_i.data() + at * k, (size_t)r->nq * k * sizeof(int64_t));
+        } else {
+            snprintf(r->err, sizeof(r->err), "%s", g_err);
+        }
+        at += r->nq;
+    }
+    ix->n_combined_batches++;
+    ix->n_combined_requests += batch.size();
+}
+
+extern "C" {
+
+int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flags,
+              float* out_scores, int64_t* out_indices) {
+    int rc = ls_i_check_search_args(ix, q, nq, k, flags & ~(LS_FLAG_ASYNC | LS_FLAG_PIPELINE), out_scores,
+                                    out_indices);
+    if (rc != LS_OK) return rc;
+    if (nq == 0) return LS_OK;
+    flags &= LS_FLAG_NORMALIZE;
+    if (!ix->opt_combine || nq > LS_SCAN_NQ_MAX)  // big batches gain nothing from company
+        return host_search_locked(ix, q, nq, k, flags, out_scores, out_indices);
+    ls_req me{q, nq, k, flags, out_scores, out_indices};
+    std::unique_lock<std::mutex> lk(ix->q_mu);
+    ix->req_q.push_back(&me);
+    std::vector<ls_req*> batch;
+    while (!me.done) {
+        if (ix->leader_active) {
+            ix->q_cv.wait(lk);
+            continue;
+        }
+        ix->leader_active = true;  // serve the queue until this thread's own request is done
+        while (!me.done && !ix->req_q.empty()) {
+            batch.clear();
+            ls_req* head = ix->req_q.front();
+            int64_t total = 0;
+            while (!ix->req_q.empty()) {
+                ls_req* r = ix->req_q.front();
+                if (r->k != head->k || r->flags != head->flags || total + r->nq > LS_SCAN_MAX_NQ) break;
+                batch.push_back(r);
+                total += r->nq;
+                ix->req_q.pop_front();
+            }
+            lk.unlock();
+            serve_requests(ix, batch);
+            lk.lock();
+            for (ls_req* r : batch) r->done = true;
+            ix->q_cv.notify_all();
+        }
+        ix->leader_active = false;
+        ix->q_cv.notify_all();  // a waiter whose request is still queued takes over
+    }
+    if (me.rc != LS_OK && me.err[0]) ls_set_error("%s", me.err);
+    return me.rc;
 }
 
 int ls_search_device(ls_index* ix, const void* d_q, int64_t nq, int32_t k, uint32_t flags,
@@ -1184,6 +1283,11 @@ int ls_last_kernel_ms(ls_index* ix, float* scan_ms, float* total_ms) {
 // test / tuning hooks -------------------------------------------------------------------------
 int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
     if (!ix) return LS_ERR_INVALID_ARG;
+    if (which == 10) {  // combine concurrent synchronous host searches into shared corpus passes (default on)
+        std::lock_guard<std::mutex> ql(ix->q_mu);
+        ix->opt_combine = value != 0;
+        return LS_OK;
+    }
     std::lock_guard<std::mutex> lk(ix->mu);
     if (ix->group) return ls_group_debug_option(ix, which, value);
     if (which == 0) {  // force k' (0 = automatic)
@@ -1261,7 +1365,11 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 15) return -1;
+    if (!ix || which < 0 || which > 17) return -1;
+    if (which >= 16) {
+        std::lock_guard<std::mutex> ql(ix->q_mu);
+        return (int64_t)(which == 16 ? ix->n_combined_batches : ix->n_combined_requests);
+    }
     std::lock_guard<std::mutex> lk(ix->mu);
     if (ix->group) return ls_group_debug_counter(ix, which);
     if (which == 8) return (int64_t)ix->n_batched_fallback;

@@ -3,11 +3,14 @@
 #pragma once
 #include "ls_common.h"
 
+#include <condition_variable>
 #include <cstddef>
+#include <deque>
 #include <mutex>
 #include <vector>
 
 struct ls_shard_group;  // ls_shard.hip
+struct ls_req;          // ls_api.hip: one queued synchronous host search
 
 #define LS_NSETS 2
 #define LS_BC_SLOTS 16
@@ -28,6 +31,15 @@ struct ls_index {
     int64_t cap_rows = 0;  // rows d_corpus has room for (+ LS_CORPUS_PAD_ROWS); >= n
     std::mutex mu;
     hipStream_t own_stream = nullptr;
+    // synchronous host searches that arrive together are served as one batch (ls_search)
+    std::mutex q_mu;
+    std::condition_variable q_cv;
+    std::deque<ls_req*> req_q;
+    bool leader_active = false;
+    std::vector<float> comb_q, comb_s;   // the leader's staging of a combined batch
+    std::vector<int64_t> comb_i;
+    int32_t opt_combine = 1;
+    uint64_t n_combined_batches = 0, n_combined_requests = 0;
     // non-null: this handle is a row-sharded GROUP (ls_create_sharded): `n`, `dtype`, `g` and
     // `device` (the primary shard's) describe the whole index, every other member below is unused
     // and the per-device sub-handles live in the group (ls_shard.hip)

@@ -1,0 +1,90 @@
+"""Concurrent synchronous callers on one handle (an MCP server with several clients; the reference's
+call is one blocking index.search per query, search/engine.py:250): requests that arrive while a
+search is running are served together, up to 16 queries per corpus pass, and every caller gets
+exactly the rows and scores its own separate call would have produced."""
+
+import threading
+
+import numpy as np
+import pytest
+
+from lean_explore_amd.index import FlatIPIndex
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+def test_concurrent_callers_are_combined_and_exact(devices):
+    n, d, T, per = 120_000, 256, 8, 30
+    corpus = H.gauss(81, n, d)
+    pool = H.gauss(82, 64, d, normalize=False)
+    ix = FlatIPIndex.from_array(corpus, devices=devices) if devices else FlatIPIndex.from_array(corpus)
+    try:
+        ix.search(pool[:1], 10)  # build + warm
+        # what each (query, k, normalize) must return: separate calls, combining off
+        ix.debug_option(10, 0)
+        want = {}
+        for qi in range(64):
+            for k, norm in ((50, True), (20, False)):
+                want[(qi, k, norm)] = ix.search(pool[qi:qi + 1], k, normalize=norm)
+        ix.debug_option(10, 1)
+        errors = []
+
+        def worker(t):
+            rng = np.random.default_rng(t)
+            for j in range(per):
+                qi = int(rng.integers(64))
+                k, norm = ((50, True), (20, False))[int(rng.integers(4) == 0)]
+                two = j % 7 == 3  # some callers bring two queries
+                q = pool[[qi, (qi + 1) % 64]] if two else pool[qi:qi + 1]
+                D, I = ix.search(q, k, normalize=norm)
+                for r, qq in enumerate([qi, (qi + 1) % 64][: q.shape[0]]):
+                    Dw, Iw = want[(qq, k, norm)]
+                    if not (np.array_equal(D[r], Dw[0]) and np.array_equal(I[r], Iw[0])):
+                        errors.append((t, j, qq, k, norm))
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors[:5]
+        assert ix.debug_counter(16) >= 1, "8 threads hammering one handle never met in a batch"
+        assert ix.debug_counter(17) >= 2 * ix.debug_counter(16)
+        # and the separate-call results themselves are the oracle's
+        Dr, Ir = oracle.c_search(corpus, pool[:4], 50, normalize=True)
+        _, _, S = oracle.np_search(corpus, oracle.c_normalize_l2(pool[:4]), 50)
+        D = np.concatenate([want[(qi, 50, True)][0] for qi in range(4)])
+        I = np.concatenate([want[(qi, 50, True)][1] for qi in range(4)])
+        assert oracle.compare_topk(D, I, Dr, Ir, S)["recall"] == 1.0
+    finally:
+        ix.close()
+
+
+def test_errors_reach_the_caller_that_made_them():
+    from lean_explore_amd import native
+
+    ix = FlatIPIndex.from_array(H.gauss(83, 5000, 64))
+    try:
+        out = []
+
+        def bad():
+            try:
+                ix.search(H.gauss(84, 1, 64), 5000)  # min(k, ntotal) > LS_MAX_K
+            except native.LeanSearchError as e:
+                out.append(e.code)
+
+        def good():
+            D, I = ix.search(H.gauss(85, 1, 64), 5)
+            out.append(int(I.shape[1]))
+
+        ths = [threading.Thread(target=f) for f in (bad, good, bad, good)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert sorted(out) == sorted([native.LS_ERR_K_TOO_LARGE] * 2 + [5, 5])
+    finally:
+        ix.close()

@@ -1,0 +1,35 @@
+"""Throughput of T threads making synchronous single-query ls_search calls on ONE handle (ctypes
+releases the GIL), with and without combining (debug option 10):
+    gpurun -- 'python tools/concurrent_callers.py'"""
+import sys, threading, time; sys.path.insert(0, '/root/repo')
+import numpy as np
+from lean_explore_amd.index import FlatIPIndex
+from tests import helpers as H
+
+def run(ix, q, k, T, secs=1.0):
+    counts = [0] * T; lats = [[] for _ in range(T)]; stop = time.perf_counter() + secs
+    def w(t):
+        qq = q[t:t + 1]
+        while time.perf_counter() < stop:
+            t0 = time.perf_counter(); ix.search(qq, k, normalize=True); lats[t].append(time.perf_counter() - t0); counts[t] += 1
+    th = [threading.Thread(target=w, args=(t,)) for t in range(T)]
+    t0 = time.perf_counter()
+    for x in th: x.start()
+    for x in th: x.join()
+    dt = time.perf_counter() - t0
+    allat = np.concatenate([np.asarray(l) for l in lats])
+    return sum(counts) / dt, np.median(allat) * 1e6
+
+for n in (200_000, 25_000):
+    c = H.gauss(1234, n, 384); q = H.gauss(5678, 16, 384)
+    ix = FlatIPIndex.from_array(c)
+    for _ in range(50): ix.search(q[:1], 50, normalize=True)
+    for T in (1, 2, 4, 8, 16):
+        row = []
+        for comb in (1, 0):
+            ix.debug_option(10, comb)
+            qps, p50 = run(ix, q, 50, T)
+            row.append(f"{'combined' if comb else 'serialised'} {qps:8.0f} q/s p50 {p50:6.1f} us")
+        print(f"N={n} d=384 f32 k=50, {T:2d} callers: " + " | ".join(row), flush=True)
+    print("   combined batches", ix.debug_counter(16), "requests in them", ix.debug_counter(17), flush=True)
+    ix.close()

@@ -12,10 +12,11 @@
 //     traffic in the loop. For 1.5 KiB rows (config 4) that is 192 of the wave's 256 registers;
 //     the kernel then keeps ONE accumulator set (ONE_ACC).
 //   - A operand (corpus): tiles of TM rows (64, or 32 for long rows) stream HBM/L2 -> LDS by DMA
-//     (global_load_lds, 16 B/lane) into a ring of three buffers, TWO tiles ahead of the MFMAs:
-//     the hand-over waits with a counted vmcnt for the NEXT tile only (loads return in order, so
-//     "at most LOADS outstanding" proves the older tile has landed whatever stores sit between)
-//     and crosses a bare s_barrier; a whole tile time of HBM latency stays hidden.
+//     (global_load_lds, 16 B/lane) into TWO buffers (the shipped default, LS_GEMM_RING3 = 0): the
+//     next tile's DMA pieces are issued one at a time between the current tile's k-steps, the
+//     hand-over waits for them (vmcnt) and crosses one s_barrier per tile. (LS_GEMM_RING3 = 1, a
+//     variant-build knob, keeps a ring of three buffers with the DMA two tiles ahead and a counted
+//     vmcnt; it measured 1-2 % slower and is not what ships.)
 //     LDS rows are XOR-swizzled on the SOURCE address (chunk ^ (row & 15)): conflict-free
 //     ds_read_b128.
 //   - epilogue: lane (query, quarter) holds 4 row scores per accumulator; a score >= tau[query]

@@ -27,7 +27,7 @@ dst.mkdir(parents=True, exist_ok=True)
 
 DOMINANT = {  # substring(s) that must ALL appear in the kernel name
     "c3": ("ls_gemm_filter_kernel", ", false>"), "c4": ("ls_gemm_filter_kernel", ", false>"),
-    "bm25": ("bm25_add_column_kernel",),
+    "bm25": ("bm25_score_kernel",),
 }
 need = DOMINANT.get(wl, ("ls_scan_kernel",))
 

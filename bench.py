@@ -16,8 +16,10 @@ Workloads (BASELINE.json configs):
                 generated on the device per shard (seed 1234+rank); weak scaling
 
 The ONE JSON line rank 0 prints carries the headline workload at the top level and, by default,
-  "secondary": the other half of BASELINE's metric (c3 at N=1; c3 + the weak-scaled c4 shard at N>1),
-               each with its own roofline / recall / cpu_baseline,
+  "secondary": the other half of BASELINE's metric (c3), the reference's real call shape (c2p), config 4's
+               per-GPU shard (c4), each with its own roofline / recall / cpu_baseline, and config 5 (c5: the
+               hybrid pipeline end to end through Service.search(), random-initialised models) at N=1;
+               c3 + the weak-scaled c4 shard at N>1,
   "host_api":  the synchronous host-array call the reference makes (ls_search, nq=1, PCIe and sync
                inclusive; reference search/engine.py:250) for c2 and c2p.
 
@@ -653,6 +655,17 @@ def main():
         st, wu = (1000, 50) if nq <= 16 else ((300, 20) if w == "c3" else (30, 3))
         secondary[w] = run_dense(env, w, st, wu, want_cpu=not args.no_cpu_baseline,
                                  verify=not args.no_verify, c4_rows=args.c4_rows, cpu_budget_s=9.0)
+    if (args.secondary == "auto" and args.workload == "c2" and env.n_gpus == 1) or \
+            "c5" in args.secondary.split(","):
+        # BASELINE config 5: the full hybrid pipeline through Service.search() (embed on PyTorch-ROCm
+        # -> BM25 names + dense top-1000 on the HIP kernels -> RRF -> dependency boost -> cross-encoder
+        # rerank on PyTorch-ROCm), end-to-end queries/s with the dense stage's share
+        try:
+            from tools import hybrid_bench
+
+            secondary["c5"] = hybrid_bench.run(queries=12)
+        except Exception as e:  # the model stack is plumbing around the path: never lose the line to it
+            secondary["c5"] = {"error": repr(e)}
     host_api = None
     if not args.no_host_api and env.n_gpus == 1 and args.workload == "c2" and env.rank == 0:
         host_api = {w: run_host_api(env, w) for w in ("c2", "c2p")}

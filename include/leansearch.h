@@ -213,7 +213,8 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * sharded handles: counter 13 exchange steps run, 14 re-exchanges after a shard repaired a
  * query, 15 exchange transport (0 copies, 1 RCCL selected, 2 RCCL communicators initialised);
  * counters 0, 1, 8, 11, 12 are summed over the shards, 9 and 10 are the primary shard's;
- * counter 16: combined batches ls_search served, 17: the requests they carried.
+ * counter 16: combined batches ls_search served, 17: the requests they carried; counter 18 (sharded
+ * handles): mean host nanoseconds spent queueing one search (every device's work + exchange + merge).
  * counter 0: searches whose finalize step left the fast path (rescue or general); counter 1:
  * those that took the general path; counter 8: queries of batched calls that were repaired by
  * the exact scan path. */

@@ -1365,8 +1365,8 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 17) return -1;
-    if (which >= 16) {
+    if (!ix || which < 0 || which > 18) return -1;
+    if (which == 16 || which == 17) {
         std::lock_guard<std::mutex> ql(ix->q_mu);
         return (int64_t)(which == 16 ? ix->n_combined_batches : ix->n_combined_requests);
     }
@@ -1377,7 +1377,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
     if (which == 10) return (int64_t)ix->last_path;
     if (which == 11) return (int64_t)ix->n_launches_total;
     if (which == 12) return (int64_t)ix->n_chunked_calls;
-    if (which > 9) return 0;  // 13..15 are group counters
+    if (which > 9) return 0;  // 13..15 and 18 are group counters
     if (hipSetDevice(ix->device) != hipSuccess) return -1;
     u32 v = 0;
     if (hipMemcpy(&v, ix->d_counters + which, sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess)

@@ -29,6 +29,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <new>
 
@@ -140,6 +141,7 @@ struct ls_shard_group {
     int64_t* d_out_i = nullptr; size_t d_out_i_cap = 0;
 
     uint64_t n_exchanges = 0, n_reexchanges = 0;
+    uint64_t enqueue_ns = 0, enqueue_calls = 0;  // host time spent queueing searches (debug counter 18)
 };
 
 static inline bool group_uses_rccl(const ls_shard_group* G) {
@@ -308,6 +310,7 @@ int ls_group_search(ls_index* ix, const float* q, bool q_on_host, int64_t nq, in
     const int32_t d = ix->g.d;
     const size_t qn = (size_t)nq * d, on = (size_t)nq * k;
     int rc;
+    const auto t_enq = std::chrono::steady_clock::now();
     bool batched = false;  // does any shard answer speculatively (flags may come back non-zero)?
     for (int g = 0; g < G->G; ++g) batched = batched || ls_i_batched_eligible(G->sub[g], nq, k);
     if (batched && (int)G->pending.size() >= LS_SH_SLOTS) {
@@ -373,7 +376,9 @@ int ls_group_search(ls_index* ix, const float* q, bool q_on_host, int64_t nq, in
         rc = ls_i_search_on_stream(sub, qg, nq, k, f, (float*)pk, (int64_t*)(pk + sbytes), S.stream,
                                    false);
         if (rc != LS_OK) return rc;
-        if ((rc = ls_i_export_flags(sub, pk + sbytes + rbytes, nq, S.stream)) != LS_OK) return rc;
+        // the flags region is only ever read for batched calls (group_check_locked)
+        if (batched && (rc = ls_i_export_flags(sub, pk + sbytes + rbytes, nq, S.stream)) != LS_OK)
+            return rc;
     }
     if ((rc = group_exchange(G, slot, block)) != LS_OK) return rc;
     LS_HIP(hipSetDevice(P));
@@ -381,6 +386,9 @@ int ls_group_search(ls_index* ix, const float* q, bool q_on_host, int64_t nq, in
     LS_HIP(hipEventRecord(G->ev_out, s0));
     G->have_out = true;
     if (batched) G->pending.push_back({slot, nq, k, block, sbytes, rbytes, dst_s, dst_i});
+    G->enqueue_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                         std::chrono::steady_clock::now() - t_enq).count();
+    G->enqueue_calls++;
     if (q_on_host) {
         if (batched) {
             if ((rc = group_check_locked(ix)) != LS_OK) return rc;  // drains, repairs, re-merges
@@ -495,6 +503,7 @@ int ls_group_debug_option(ls_index* ix, int32_t which, int32_t value) {
 
 int64_t ls_group_debug_counter(ls_index* ix, int32_t which) {
     ls_shard_group* G = ix->group;
+    if (which == 18) return G->enqueue_calls ? (int64_t)(G->enqueue_ns / G->enqueue_calls) : 0;
     if (which == 13) return (int64_t)G->n_exchanges;
     if (which == 14) return (int64_t)G->n_reexchanges;
     if (which == 15) return group_uses_rccl(G) ? (G->comms_ready ? 2 : 1) : 0;

@@ -19,6 +19,6 @@ for n, d, k in ((200_000, 384, 50), (200_000, 1024, 1000)):
     row = [f"plain {base:.1f}"]
     for G in (1, 2, 4, 8):
         ix = FlatIPIndex.from_array(c, devices=[0] * G)
-        row.append(f"G={G} {p50(ix, q, k):.1f}")
+        row.append(f"G={G} {p50(ix, q, k):.1f} (host enqueue {ix.debug_counter(18) / 1e3:.1f})")
         ix.close()
     print(f"N={n} d={d} k={k} nq=1 synchronous call, p50 us: " + " | ".join(row), flush=True)

@@ -28,6 +28,11 @@
  *     handle's scratch is fenced across streams by events. Concurrent ls_search calls do not
  *     queue one behind the other: whichever thread is serving takes every waiting request of the
  *     same k and flags (up to 16 queries) into ONE corpus pass; waiters sleep, they do not spin.
+ *   - stream lifetime: a hipStream_t handed to ls_search_device must stay alive until the next
+ *     ls_check (or synchronous call) on that handle has returned, or until ls_destroy: the handle
+ *     remembers the stream of its most recent calls and may synchronise it when a later call
+ *     arrives on a different stream (recording an event behind every call instead would cost
+ *     several microseconds of GPU time per call; the library's own lanes ARE ordered by events).
  *   - there is no CPU fallback: with no usable HIP device every compute entry point fails with
  *     LS_ERR_NO_DEVICE.
  */

@@ -1386,7 +1386,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
 }
 
 const char* ls_last_error(void) { return g_err; }
-const char* ls_version(void) { return "leansearch-mi355x 0.2.0 (gfx950)"; }
+const char* ls_version(void) { return "leansearch-mi355x 0.3.0 (gfx950)"; }
 int32_t ls_device_count(void) {
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;

@@ -32,10 +32,11 @@ WORDS = ("continuous function compact set prime number group ring field ideal mo
 NW = len(WORDS)
 
 
-def run(n=200_000, queries=30, layers=28, rerank_top=50, graphs=1) -> dict:
+def run(n=200_000, queries=30, layers=28, rerank_top=50, graphs=1, rerank_batch=64) -> dict:
     """Build the synthetic deployment and time Service.search() end to end; returns the result block
     (bench.py reports it as `secondary.c5`)."""
-    args = argparse.Namespace(n=n, queries=queries, layers=layers, rerank_top=rerank_top, graphs=graphs)
+    args = argparse.Namespace(n=n, queries=queries, layers=layers, rerank_top=rerank_top, graphs=graphs,
+                              rerank_batch=rerank_batch)
 
     import torch
 
@@ -79,7 +80,7 @@ def run(n=200_000, queries=30, layers=28, rerank_top=50, graphs=1) -> dict:
                                model=random_qwen3(seed=1, dtype=torch.bfloat16, **cfg))
     reranker = RerankerClient("random-init Qwen3-Reranker-0.6B shape", device="cuda",
                               max_length=512, tokenizer=tok, token_true_id=1, token_false_id=2,
-                              use_graphs=bool(args.graphs),
+                              use_graphs=bool(args.graphs), batch_size=args.rerank_batch,
                               model=random_qwen3(causal_lm=True, seed=2, dtype=torch.float16, **cfg))
     engine = S.SearchEngine(db_path=db, embedding_client=embedder, reranker_client=reranker,
                             index=index, ids_map=ids, lexical_retriever=lexical)
@@ -125,7 +126,8 @@ def run(n=200_000, queries=30, layers=28, rerank_top=50, graphs=1) -> dict:
         "hipgraph_replay": bool(args.graphs),
         "config": f"config 5: N={n} d={d} fp32, faiss_k=1000, bm25_k=1000, rerank_top={args.rerank_top}, "
                   f"limit=20; random-init Qwen3-0.6B-shaped embedder (bf16) and reranker (fp16), "
-                  f"{args.layers} layers; synthetic corpus, hashing tokenizer",
+                  f"{args.layers} layers; reranker batch {args.rerank_batch} (the reference's "
+                  f"LEAN_EXPLORE_RERANKER_BATCH_SIZE knob; its CUDA default is 16); synthetic corpus, hashing tokenizer",
         "end_to_end_ms_per_query": round(t_e2e, 2), "end_to_end_qps": round(1e3 / t_e2e, 2),
         "without_rerank_ms_per_query": round(t_norr, 2),
         "stages_ms": {"embed_query (PyTorch-ROCm)": round(t_embed, 3),
@@ -143,8 +145,9 @@ def main():
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--rerank-top", type=int, default=50)
     ap.add_argument("--graphs", type=int, default=1, help="replay the model forwards as hipGraphs")
+    ap.add_argument("--rerank-batch", type=int, default=64)
     a = ap.parse_args()
-    print(json.dumps(run(a.n, a.queries, a.layers, a.rerank_top, a.graphs)))
+    print(json.dumps(run(a.n, a.queries, a.layers, a.rerank_top, a.graphs, a.rerank_batch)))
 
 
 if __name__ == "__main__":

@@ -41,7 +41,7 @@ class EmbeddingResponse(BaseModel):
 class EmbeddingClient:
     def __init__(self, model_name: str, device: str | None = None, max_length: int | None = None,
                  batch_size: int | None = None, *, model: Any = None, tokenizer: Any = None,
-                 dtype: Any = None, query_prompt: str = QUERY_PROMPT, use_graphs: bool = False):
+                 dtype: Any = None, query_prompt: str = QUERY_PROMPT, use_graphs: bool = False, fused_norms: bool = True):
         import torch
 
         self.model_name = model_name
@@ -60,6 +60,10 @@ class EmbeddingClient:
                                                   else torch.float32))
         self.tokenizer = tokenizer
         self.model = model.to(self.device).eval()
+        if fused_norms:
+            from .fused import fuse_rmsnorm
+
+            fuse_rmsnorm(self.model)  # one kernel per RMSNorm instead of six
         from .graphs import GraphRunner
 
         # hipGraph replay per (batch, padded length) bucket; off by default like the reference

@@ -41,7 +41,7 @@ class RerankerClient:
                  max_length: int = 512, instruction: str = DEFAULT_INSTRUCTION,
                  batch_size: int | None = None, *, model: Any = None, tokenizer: Any = None,
                  token_true_id: int | None = None, token_false_id: int | None = None,
-                 dtype: Any = None, use_graphs: bool = False):
+                 dtype: Any = None, use_graphs: bool = False, fused_norms: bool = True):
         import torch
 
         self.model_name = model_name
@@ -61,6 +61,10 @@ class RerankerClient:
                                                   else torch.float32))
         self.tokenizer = tokenizer
         self.model = model.to(self.device).eval()
+        if fused_norms:
+            from .fused import fuse_rmsnorm
+
+            fuse_rmsnorm(self.model)  # one kernel per RMSNorm instead of six
         from .graphs import GraphRunner
 
         self._forward = GraphRunner(self._last_logits, batch_step=self.batch_size,

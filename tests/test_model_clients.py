@@ -78,3 +78,34 @@ def test_graph_replay_matches_eager_on_gpu():
                             tokenizer=tok, token_true_id=5, token_false_id=9)
         scores.append(run(rr.rerank("compact", ["d one", "d two two", "d3", "d 4 4 4", "d5", "d6"])).scores)
     assert np.allclose(scores[0], scores[1], atol=1e-4)
+
+
+def test_fused_rmsnorm_matches_the_eager_modules():
+    """`fuse_rmsnorm` re-points HF's six-kernel RMSNorm at torch.nn.functional.rms_norm: the
+    embeddings / rerank scores must agree with the untouched modules (fp32: to rounding; bf16: to
+    the dtype's resolution), and every RMSNorm of the model must have been switched."""
+    import torch
+
+    from lean_explore_amd.util.fused import fuse_rmsnorm
+
+    texts = ["continuous function on a compact set", "prime number", "a b c d e f g"]
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 3e-2)):
+        plain = EmbeddingClient("t", device="cpu", max_length=32, tokenizer=HashTokenizer(512),
+                                model=random_qwen3(seed=3, dtype=dtype, **TINY), fused_norms=False)
+        fused = EmbeddingClient("t", device="cpu", max_length=32, tokenizer=HashTokenizer(512),
+                                model=random_qwen3(seed=3, dtype=dtype, **TINY), fused_norms=True)
+        a, b = plain.encode(texts, is_query=True), fused.encode(texts, is_query=True)
+        assert np.abs(a - b).max() <= tol, (dtype, np.abs(a - b).max())
+    m = random_qwen3(seed=4, **TINY)
+    n_norms = sum(1 for x in m.modules() if type(x).__name__.endswith("RMSNorm"))
+    assert fuse_rmsnorm(m) == n_norms == 2 * 4 + 1   # 4 per layer (input, post-attn, q, k) + final
+    rr_a = RerankerClient("t", device="cpu", max_length=64, tokenizer=HashTokenizer(512),
+                          token_true_id=1, token_false_id=2, fused_norms=False,
+                          model=random_qwen3(causal_lm=True, seed=5, **TINY))
+    rr_b = RerankerClient("t", device="cpu", max_length=64, tokenizer=HashTokenizer(512),
+                          token_true_id=1, token_false_id=2, fused_norms=True,
+                          model=random_qwen3(causal_lm=True, seed=5, **TINY))
+    docs = ["sum of zero", "unrelated words here", "zero zero sum and more"]
+    sa = rr_a.rerank_sync("sum and zero", docs).scores
+    sb = rr_b.rerank_sync("sum and zero", docs).scores
+    assert np.allclose(sa, sb, atol=1e-5)

@@ -140,6 +140,7 @@ struct ls_shard_group {
     float* d_out_s = nullptr;  size_t d_out_s_cap = 0;
     int64_t* d_out_i = nullptr; size_t d_out_i_cap = 0;
 
+    uint64_t repairs_seen = 0;  // sum of the shards' repair counters when the last check finished
     uint64_t n_exchanges = 0, n_reexchanges = 0;
     uint64_t enqueue_ns = 0, enqueue_calls = 0;  // host time spent queueing searches (debug counter 18)
 };
@@ -264,7 +265,10 @@ static int group_check_locked(ls_index* ix) {
         LS_HIP(hipSetDevice(G->dev[g]));
         LS_HIP(hipStreamSynchronize(G->sh[g].stream));
     }
-    const uint64_t before = group_repairs(G);
+    // (compared with the count at the END of the previous check, not with "now": a sub-handle may
+    // already have repaired calls that are still unchecked here, e.g. when a bigger batch made it
+    // re-slice its flag slots while earlier asynchronous calls were outstanding)
+    const uint64_t before = G->repairs_seen;
     for (int g = 0; g < G->G; ++g) {
         LS_HIP(hipSetDevice(G->dev[g]));
         if ((rc = ls_i_flush_pending(G->sub[g])) != LS_OK) return rc;
@@ -292,6 +296,7 @@ static int group_check_locked(ls_index* ix) {
         }
     }
     G->pending.clear();
+    G->repairs_seen = group_repairs(G);
     LS_HIP(hipSetDevice(G->dev[0]));
     return LS_OK;
 }

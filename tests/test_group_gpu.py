@@ -141,6 +141,33 @@ def test_sharded_handle_repair_after_the_exchange():
         ix.close()
 
 
+def test_sharded_handle_repair_done_early_by_a_shard_is_still_re_merged():
+    """Call A (64 queries, one of them flagged in shard 1) stays unchecked; call B brings a BIGGER
+    batch, which makes the shard re-slice its flag slots and repair A on the spot - after A's
+    provisional rows were already exchanged and merged. The group's next check must notice (it
+    compares the shards' repair counters with their values at the previous check) and merge A again."""
+    import torch
+
+    n, d, k = 120_000, 128, 100
+    rng = np.random.default_rng(4)
+    corpus = H.gauss(33, n, d)
+    q = H.gauss(34, 320, d)
+    rows = 40_000 + rng.choice(40_000, size=6000, replace=False)
+    corpus[rows] = q[5] + 0.01 * rng.standard_normal((6000, d)).astype(np.float32)
+    corpus[rows] /= np.linalg.norm(corpus[rows], axis=1, keepdims=True)
+    ix = FlatIPIndex.from_array(corpus, dtype="f16", devices=[0, 0, 0])
+    try:
+        tq = torch.from_numpy(q).cuda()
+        sA, iA = ix.search_device(tq[:64].contiguous(), k, asynchronous=True)
+        sB, iB = ix.search_device(tq, k, asynchronous=True)
+        ix.check()
+        assert ix.debug_counter(8) >= 1
+        _check(sA.cpu().numpy(), iA.cpu().numpy(), corpus, q[:64], k, True, False)
+        _check(sB.cpu().numpy(), iB.cpu().numpy(), corpus, q, k, True, False)
+    finally:
+        ix.close()
+
+
 def test_sharded_handle_add_reconstruct_base():
     n, d, k = 9_000, 48, 20
     corpus = H.int_corpus(41, n, d)

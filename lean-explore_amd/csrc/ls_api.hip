@@ -1342,6 +1342,11 @@ int ls_debug_read_scores(ls_index* ix, float* out, int64_t count) {
 
 int64_t ls_debug_counter(ls_index* ix, int32_t which) {
 #ifdef LS_GEMM_TIMING
+    if (ix && which >= 3000 && which < 3000 + 4096) {  // sample-pass phase stamps (ls_gemm.hip)
+        static unsigned long long st[4096];
+        if ((which - 3000) == 0 && ls_gemm_read_sample_stamps(st, 4096) != 0) return -1;
+        return (int64_t)st[which - 3000];
+    }
     if (ix && which >= 2000) {  // start / end tick of MFMA-pass workgroup (which - 2000) / 2
         u64 v = 0;
         if (hipMemcpy(&v, reinterpret_cast<const u64*>(ix->bc_sets[ix->bc_last_set].d_sample_top) + (which - 2000),

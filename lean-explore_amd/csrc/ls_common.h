@@ -245,6 +245,9 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
                           bool sample_top2, hipStream_t s);
 int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_pad, int j_rank,
                   float* d_tau, hipStream_t s);
+#ifdef LS_GEMM_TIMING
+int ls_gemm_read_sample_stamps(unsigned long long* out, int count);  // variant builds: sample-pass phase stamps
+#endif
 int ls_gemm_qg(const ls_geom& g);         // query groups of 16 per wave (2, or 1 for 2 KiB rows)
 int ls_gemm_tile_rows(const ls_geom& g);  // corpus rows per LDS tile (64, or 32 for long rows)
 #define LS_BSEL_MAX_KEYS 8192         // candidate keys per query the select kernel can hold in LDS

@@ -41,6 +41,15 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 #define LS_GEMM_LDS_BYTES (160 * 1024)  // the whole LDS of a CU: one workgroup per CU
+#ifdef LS_GEMM_TIMING  // phase stamps (100 MHz) of the SAMPLE pass's workgroups: start, loads landed, tiles done, end
+__device__ unsigned long long g_sample_stamps[1024 * 4];
+int ls_gemm_read_sample_stamps(unsigned long long* out, int count) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sample_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : -1;
+}
+#define LS_SSTAMP_S(i) do { if (SAMPLE && tid == 0 && blockIdx.x < 1024) g_sample_stamps[blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define LS_SSTAMP_S(i) do {} while (0)
+#endif
 
 // ---- static geometry of one instantiation ------------------------------------------------------
 __host__ __device__ constexpr int gemm_qg(int chunks) { return chunks <= LS_GEMM_QG2_MAX_CHUNKS ? 2 : 1; }
@@ -194,6 +203,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
 #ifdef LS_GEMM_TIMING  // developer instrumentation: start / end tick (100 MHz) of every workgroup
     const unsigned long long t_start = wall_clock64();
 #endif
+    LS_SSTAMP_S(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar DMA addressing
     const int qd = lane >> 4, li = lane & 15;  // quarter (k-chunk / row group), index in group
     int split, qt;
@@ -484,6 +494,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     if constexpr (SAMPLE) {
         if (sample_upfront) {
             first_hand_over();
+            LS_SSTAMP_S(1);
             if constexpr (ONE_ACC) {
                 for (int i = 0; i < nt; ++i)
                     run_tile(accA, accA, i > 0, tile_row0(i - 1), tile_row0(i), i * TILE_BYTES);
@@ -494,10 +505,12 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                 if (nt > 2) run_tile(accA, accB, true, tile_row0(1), 0, 2 * TILE_BYTES);
                 if ((nt - 1) & 1) flush_last(accB); else flush_last(accA);
             }
+            LS_SSTAMP_S(2);
 #pragma unroll
             for (int g2 = 0; g2 < QG; ++g2)
                 reinterpret_cast<uint4*>(out.sample_top)[queue_id(qj[g2], split, qd, nsplits)] =
                     top4_keys(top[g2]);
+            LS_SSTAMP_S(3);
             return;
         }
     }

@@ -29,6 +29,9 @@ typedef unsigned int u32;
 #define LS_FINAL_CAP 8192            // keys the finalize workgroup sorts in LDS (64 KiB)
 #define LS_SCAN_MAX_NQ 16            // nq <= this: per-query HBM-bound scan path
 #define LS_SAME_LAUNCH_MAX_BLOCKS 200 // ordered calls with at most this many scan workgroups select inside the scan launch
+#ifndef LS_SCAN_MQ_SCATTER
+#define LS_SCAN_MQ_SCATTER 1          // multi-query scan launches: reduce-scatter of the partial sums (0: one butterfly per pair)
+#endif
 #ifndef LS_SCAN_SMALL
 #define LS_SCAN_SMALL 1              // small shards: waves rank their <= 64 keys once instead of inserting row by row
 #endif

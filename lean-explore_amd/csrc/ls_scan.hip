@@ -144,6 +144,48 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// ---- several queries per corpus pass: reduce-SCATTER instead of U*NQ full reductions ------------
+// A lane holds P = U*NQ partial dot products (row step u, query qi), pair index j = u*NQ + qi. The
+// single-query path sums each of them over the L lanes of a row with its own butterfly (5-6
+// cross-lane adds per pair, every lane ends with every sum) and then picks the lane that keeps it:
+// ~13 VALU instructions per pair, more than the 12 FMAs that produced it. Here each butterfly step
+// HALVES the live pairs instead: at bit b a lane keeps the pairs whose bit b equals its own and
+// hands the others to its partner (lane ^ (1 << b)), so P pairs cost P - 1 cross-lane adds in
+// total and lane `sub` ends with pair j = sub (P == L). The steps run over the same bits in the
+// same order (1, 2, 4, .., L/2) and add the same two operands as group_sum, so every sum is
+// BIT-IDENTICAL to the one the single-query kernel computes: a query's scores do not depend on
+// the group it rides in.
+template <int B>
+__device__ __forceinline__ float xor_lane(float v) {  // value of lane ^ B
+    if constexpr (B == 1)
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    else if constexpr (B == 2)
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    else
+        return __shfl_xor(v, B, 64);  // few of these per tile (the live pairs are down to <= P/4)
+}
+template <int L, int B, int LIVE, int P>
+struct rs_step {
+    static __device__ __forceinline__ void run(float (&p)[P], int sub) {
+        if constexpr (B < L) {
+            if constexpr (LIVE > 1) {
+                const bool hi = (sub & B) != 0;
+#pragma unroll
+                for (int c = 0; c < LIVE / 2; ++c) {
+                    const float lo_v = p[2 * c], hi_v = p[2 * c + 1];
+                    const float keep = hi ? hi_v : lo_v, send = hi ? lo_v : hi_v;
+                    p[c] = keep + xor_lane<B>(send);
+                }
+                rs_step<L, 2 * B, LIVE / 2, P>::run(p, sub);
+            } else {  // one pair left but lanes to spare: plain butterfly, both partners keep the sum
+                p[0] = p[0] + xor_lane<B>(p[0]);
+                rs_step<L, 2 * B, 1, P>::run(p, sub);
+            }
+        }
+    }
+};
+__host__ __device__ constexpr int ls_ilog2(int v) { return v <= 1 ? 0 : 1 + ls_ilog2(v / 2); }
+
 // value of group (lane % R) delivered to every lane: R scalar reads + a select chain, no LDS
 template <int L>
 __device__ __forceinline__ float pick_group(float s, int lane) {
@@ -271,6 +313,54 @@ __global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
     int ti = 0;  // SMALL: tiles this wave has seen
     auto tile_step = [&](f32x4 (&x)[U][V]) {  // tile t sits in buffer x
         if (t >= NT) return;
+        if constexpr (NQ > 1 && LS_SCAN_MQ_SCATTER) {
+            // ---- several queries: all U*NQ partial sums, one reduce-scatter, one score per lane --
+            constexpr int P = U * NQ;
+            constexpr int NSC = ls_ilog2(L) < ls_ilog2(P) ? ls_ilog2(L) : ls_ilog2(P);  // scatter steps
+            constexpr int NRES = P >> NSC;                                               // results per lane
+            float p[P];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) p[u * NQ + qi] = qr[qi].dot(x[u]);
+            const long long tt = reverse ? NT - 1 - t : t;
+            t += W;
+            if (t + (PF - 1) * W < NT) issue_loads(x, t + (PF - 1) * W);  // overlaps everything below
+            rs_step<L, 1, P, P>::run(p, sub);
+            // lane `sub` now holds pairs j = (c << NSC) | (sub & (2^NSC - 1)), c < NRES; with lanes
+            // to spare (L > P) the copies in lanes sub >= P are ignored
+            const bool holder = (sub >> NSC) == 0 || NSC == ls_ilog2(L);
+            u64 key[NRES];
+            int myq[NRES];
+#pragma unroll
+            for (int c = 0; c < NRES; ++c) {
+                const int j = (c << NSC) | (sub & ((1 << NSC) - 1));
+                const int qi = j % NQ, u = j / NQ;
+                const long long row = tt * TR + u * R + grp;
+                const bool valid = holder && row < n;
+                if (valid) S[qi * s_stride + row] = p[c];
+                key[c] = valid ? ls_make_key(p[c], (u32)row) : 0ull;
+                myq[c] = qi;
+            }
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+#pragma unroll
+                for (int c = 0; c < NRES; ++c) {
+                    const u64 kq = myq[c] == qi ? key[c] : 0ull;
+                    u64 mask = __ballot(kq > thr[qi]);
+                    while (mask) {  // rare once the threshold has warmed up
+                        const int j = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const u64 v = readlane64(kq, j);
+                        if (v <= thr[qi]) continue;  // the ballot is older than the threshold
+                        wave_insert(lst[qi], v, lane, kp);
+                        thr[qi] = readlane64(lst[qi], kp - 1);
+                    }
+                }
+            }
+            ++ti;
+            return;
+        }
         // lane i < TR collects the score of tile row i, per query (SMALL: lane ti*TR + i)
         float sc[NQ];
 #pragma unroll

@@ -1,7 +1,9 @@
 """Randomised parity sweep: random (n, d, k, nq, storage, normalise, data kind) against the
 oracle. Integer-valued data makes every product and partial sum exact in fp32 and fp16, so those
 cases are compared bit for bit (scores AND tie order); Gaussian data goes through compare_topk.
-Seeded and bounded (LS_FUZZ_SECONDS, default 45 s of cases) so the GPU suite stays short."""
+Every third case goes through the pipelined device API, every fourth through the in-library
+sharded handle. Seeded and bounded (LS_FUZZ_SECONDS, default 30 s of cases per seed) so the GPU
+suite stays short."""
 
 import os
 import time
@@ -49,7 +51,12 @@ def test_random_parity_sweep(default_seed):
             corpus = (base + 1e-3 * H.gauss(seed + 2, n, d, normalize=False)).astype(np.float32)
             q = H.gauss(seed + 1, nq, d)
         label = f"{kind} {dtype} n={n} d={d} nq={nq} k={k} norm={normalize} seed={seed}"
-        ix = FlatIPIndex.from_array(corpus, dtype=dtype)
+        # every fourth case runs on the in-library sharded handle (2-4 row blocks rehearsed on this GPU)
+        shards = int(rng.integers(2, 5)) if cases % 4 == 1 else 0
+        if shards:
+            label += f" shards={shards}"
+        ix = FlatIPIndex.from_array(corpus, dtype=dtype, devices=[0] * shards) if shards \
+            else FlatIPIndex.from_array(corpus, dtype=dtype)
         try:
             if min(k, n) > 2048:
                 continue

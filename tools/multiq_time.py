@@ -1,0 +1,25 @@
+"""Scan-path launches that serve several queries per corpus pass (groups of 4 / 8): kernel time per launch
+(hipEvents around every launch) and per query, pipelined device API:
+    gpurun -- 'python tools/multiq_time.py'      (LEANSEARCH_LIB selects a variant build)"""
+import sys; sys.path.insert(0, '/root/repo')
+import torch
+from lean_explore_amd.index import FlatIPIndex
+from tests import helpers as H
+
+for (n, d, dt) in ((200_000, 384, 'f32'), (200_000, 1024, 'f32'), (200_000, 384, 'f16'), (25_000, 384, 'f32')):
+    c = H.gauss(1234, n, d)
+    ix = FlatIPIndex.from_array(c, dtype=dt)
+    row = []
+    for nq in (1, 2, 4, 8, 16):
+        q = torch.from_numpy(H.gauss(5678, nq, d)).cuda()
+        for _ in range(30): ix.search_device(q, 50, pipeline=True)
+        ix.check()
+        ix.set_profiling(True)
+        for _ in range(200): ix.search_device(q, 50, pipeline=True)
+        ix.check()
+        ms, _ = ix.last_kernel_ms()
+        ix.set_profiling(False)
+        launches = -(-nq // 8) if nq > 4 else 1
+        row.append(f"nq={nq}: {ms * 1e3:.1f} us/launch, {ms * 1e3 * launches / nq:.1f} us/query")
+    print(f"N={n} d={d} {dt} k=50: " + " | ".join(row), flush=True)
+    ix.close()

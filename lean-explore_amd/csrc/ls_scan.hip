@@ -200,6 +200,14 @@ __device__ __forceinline__ float pick_group(float s, int lane) {
     return out;
 }
 
+// Waves per SIMD the register allocation must leave room for. The 8-query fp16 kernel of 3-chunk
+// lanes (d = 384 fp16) would take 271 VGPRs, i.e. ONE wave per SIMD; held to 256 it spills 19
+// registers outside the tile loop and runs two. (4-chunk lanes at 8 queries would spill 80-180:
+// they stay at one wave.)
+__host__ __device__ constexpr int scan_min_waves(bool f16, int V, int NQ) {
+    return (f16 && V == 3 && NQ == 8) ? 2 : 1;
+}
+
 // SMALL: a wave sees at most 64 rows in the whole launch (small shards: a few tiles per wave).
 // The running sorted list is then the wrong tool - nearly every row of a wave's first tiles
 // enters it, one serial insert (~0.2 us) per row: 3.5 of the 10.3 us of a scan-only launch at
@@ -208,7 +216,7 @@ __device__ __forceinline__ float pick_group(float s, int lane) {
 // SMALL also keeps PF = 4 tiles in flight per wave: with a handful of tiles per wave each HBM round
 // trip would otherwise be paid in sequence (1.0-1.4 us per tile of a 4-tile wave).
 template <bool F16, int L, int V, int U, int NQ, bool SMALL>
-__global__ __launch_bounds__(LS_SCAN_THREADS) void ls_scan_kernel(
+__global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void ls_scan_kernel(
     const f32x4* __restrict__ corpus, long long n, int chunks, const float* __restrict__ qraw,
     int d, int normalize, int reverse, float* __restrict__ S, long long s_stride,
     u64* __restrict__ cand, long long c_stride, u64* __restrict__ bound, long long b_stride,

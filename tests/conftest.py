@@ -4,6 +4,13 @@ from pathlib import Path
 
 import pytest
 
+# The checkers (OpenMP C oracle, float64 numpy twin on OpenBLAS) would each start one thread per
+# core of a 256-core GPU box and leave them spinning: two oversubscribed pools starving each other
+# turned a 2 s test into 270 s on a busy box. Bounded, passive pools; must be set before numpy loads.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("OMP_NUM_THREADS", str(min(32, os.cpu_count() or 1)))
+os.environ.setdefault("OPENBLAS_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))

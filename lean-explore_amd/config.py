@@ -90,3 +90,28 @@ def sqlite_path_from_url(db_url: str) -> Path:
                              "files (sqlite+aiosqlite:///<path>)")
         return Path(db_url)
     return Path(m.group(2))
+
+
+class _ConfigMeta(type):
+    """Attribute names of the reference's `Config` (reference config.py:109-196), resolved at access
+    time from the same environment variables: code written against `Config.ACTIVE_CACHE_PATH`,
+    `Config.DATABASE_URL`, ... keeps working."""
+
+    CACHE_DIRECTORY = property(lambda cls: cache_directory())
+    DATA_DIRECTORY = property(lambda cls: data_directory())
+    ACTIVE_VERSION = property(lambda cls: active_version())
+    ACTIVE_CACHE_PATH = property(lambda cls: resolve(False).base_path)
+    ACTIVE_DATA_PATH = property(lambda cls: resolve(True).base_path)
+    DATABASE_PATH = property(lambda cls: resolve(False).database_path)
+    DATABASE_URL = property(lambda cls: resolve(False).database_url)
+    EXTRACTION_DATABASE_PATH = property(lambda cls: resolve(True).database_path)
+    EXTRACTION_DATABASE_URL = property(lambda cls: resolve(True).database_url)
+    FAISS_INDEX_PATH = property(lambda cls: resolve(False).base_path / FAISS_INDEX_FILE)
+    FAISS_IDS_MAP_PATH = property(lambda cls: resolve(False).base_path / FAISS_IDS_MAP_FILE)
+    BM25_SPACED_PATH = property(lambda cls: resolve(False).base_path / BM25_SPACED_DIR)
+    BM25_RAW_PATH = property(lambda cls: resolve(False).base_path / BM25_RAW_DIR)
+    BM25_IDS_MAP_PATH = property(lambda cls: resolve(False).base_path / BM25_IDS_MAP_FILE)
+
+
+class Config(metaclass=_ConfigMeta):
+    DEFAULT_LEAN_VERSION = "4.24.0"  # reference config.py:131

@@ -32,9 +32,6 @@ typedef unsigned int u32;
 #ifndef LS_SCAN_MQ_SCATTER
 #define LS_SCAN_MQ_SCATTER 1          // multi-query scan launches: reduce-scatter of the partial sums (0: one butterfly per pair)
 #endif
-#ifndef LS_SCAN_XOR_DPP
-#define LS_SCAN_XOR_DPP 1             // reduce-scatter partners beyond the quad by DPP / permlane swaps (0: ds_bpermute)
-#endif
 #ifndef LS_SCAN_SMALL
 #define LS_SCAN_SMALL 1              // small shards: waves rank their <= 64 keys once instead of inserting row by row
 #endif

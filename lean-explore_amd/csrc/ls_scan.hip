@@ -156,49 +156,17 @@ __device__ __forceinline__ float group_sum(float v) {
 // BIT-IDENTICAL to the one the single-query kernel computes: a query's scores do not depend on
 // the group it rides in.
 template <int B>
-__device__ __forceinline__ float xor_lane(float v, int lane) {  // value of lane ^ B, pure VALU
-    const int iv = __builtin_bit_cast(int, v);
-    if constexpr (B == 1) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xf, 0xf, true));
-    } else if constexpr (B == 2) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xf, 0xf, true));
-    } else if constexpr (B == 4) {
-#if LS_SCAN_XOR_DPP
-        // banks (groups of 4 lanes) 0 and 2 of every row read 4 lanes up (row_shl:4), banks 1 and 3
-        // read 4 lanes down (row_shr:4): together lane ^ 4
-        int t = __builtin_amdgcn_update_dpp(0, iv, 0x104, 0xf, 0x5, false);
-        t = __builtin_amdgcn_update_dpp(t, iv, 0x114, 0xf, 0xA, false);
-        return __builtin_bit_cast(float, t);
-#else
-        return __shfl_xor(v, 4, 64);
-#endif
-    } else if constexpr (B == 8) {
-#if LS_SCAN_XOR_DPP
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xf, 0xf, true));  // row_ror:8
-#else
-        return __shfl_xor(v, 8, 64);
-#endif
-    } else if constexpr (B == 16) {
-#if LS_SCAN_XOR_DPP
-        const unsigned u = (unsigned)iv;
-        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // r[0]: even rows' value, r[1]: odd rows'
-        return __builtin_bit_cast(float, (lane & 16) ? (unsigned)r[0] : (unsigned)r[1]);
-#else
-        return __shfl_xor(v, 16, 64);
-#endif
-    } else {
-#if LS_SCAN_XOR_DPP
-        const unsigned u = (unsigned)iv;
-        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // r[0]: lanes 0-31's value, r[1]: 32-63's
-        return __builtin_bit_cast(float, (lane & 32) ? (unsigned)r[0] : (unsigned)r[1]);
-#else
-        return __shfl_xor(v, 32, 64);
-#endif
-    }
+__device__ __forceinline__ float xor_lane(float v) {  // value of lane ^ B
+    if constexpr (B == 1)
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    else if constexpr (B == 2)
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    else
+        return __shfl_xor(v, B, 64);  // few of these per tile (the live pairs are down to <= P/4)
 }
 template <int L, int B, int LIVE, int P>
 struct rs_step {
-    static __device__ __forceinline__ void run(float (&p)[P], int sub, int lane) {
+    static __device__ __forceinline__ void run(float (&p)[P], int sub) {
         if constexpr (B < L) {
             if constexpr (LIVE > 1) {
                 const bool hi = (sub & B) != 0;
@@ -206,12 +174,12 @@ struct rs_step {
                 for (int c = 0; c < LIVE / 2; ++c) {
                     const float lo_v = p[2 * c], hi_v = p[2 * c + 1];
                     const float keep = hi ? hi_v : lo_v, send = hi ? lo_v : hi_v;
-                    p[c] = keep + xor_lane<B>(send, lane);
+                    p[c] = keep + xor_lane<B>(send);
                 }
-                rs_step<L, 2 * B, LIVE / 2, P>::run(p, sub, lane);
+                rs_step<L, 2 * B, LIVE / 2, P>::run(p, sub);
             } else {  // one pair left but lanes to spare: plain butterfly, both partners keep the sum
-                p[0] = p[0] + xor_lane<B>(p[0], lane);
-                rs_step<L, 2 * B, 1, P>::run(p, sub, lane);
+                p[0] = p[0] + xor_lane<B>(p[0]);
+                rs_step<L, 2 * B, 1, P>::run(p, sub);
             }
         }
     }
@@ -366,7 +334,7 @@ __global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void l
             const long long tt = reverse ? NT - 1 - t : t;
             t += W;
             if (t + (PF - 1) * W < NT) issue_loads(x, t + (PF - 1) * W);  // overlaps everything below
-            rs_step<L, 1, P, P>::run(p, sub, lane);
+            rs_step<L, 1, P, P>::run(p, sub);
             // lane `sub` now holds pairs j = (c << NSC) | (sub & (2^NSC - 1)), c < NRES; with lanes
             // to spare (L > P) the copies in lanes sub >= P are ignored
             const bool holder = (sub >> NSC) == 0 || NSC == ls_ilog2(L);

@@ -6,7 +6,7 @@ from tests import helpers as H
 for (n, d, k) in [(200000, 1024, 1000), (200000, 384, 100)]:
     c = H.gauss(1234, n, d)
     ix = FlatIPIndex.from_array(c, dtype="f32")
-    for nq in (24, 64, 256, 1024):
+    for nq in (24, 32, 48, 64, 256):
         tq = torch.from_numpy(H.gauss(5678, nq, d)).cuda()
         row = []
         for opt in (1, 0):

@@ -152,6 +152,21 @@ class BM25Index:
             scores.ctypes.data, docs.ctypes.data))
         return docs, scores
 
+    def get_scores_host(self, query_tokens: list[str]) -> np.ndarray:
+        """bm25s `get_scores`: the score of EVERY document, float32, accumulated column by column in
+        query-token order on the host — the same additions in the same order as the GPU kernel
+        (and as bm25s). For the throw-away index over the <= 50 rerank candidates (reference
+        search/engine.py:418-448, computed with bm25s on the CPU there as well): creating a GPU handle
+        for 50 documents cost 1.6 ms per query, this costs ~0.1 ms. The name indices (200 k documents,
+        top-1000 selection) stay on the GPU."""
+        s = np.zeros(self.num_docs, dtype=np.float32)
+        shift = np.float32(0.0)
+        for t in self.token_ids(query_tokens).tolist():
+            a, b = int(self.indptr[t]), int(self.indptr[t + 1])
+            s[self.indices[a:b]] += self.data[a:b]   # a column lists a document at most once
+            shift = np.float32(shift + self.nonoccurrence[t])
+        return s + shift
+
     def debug_counter(self, which: int) -> int:
         """0: searches whose selection left the fast path; 1: those that took the general select."""
         return int(native.load().ls_bm25_debug_counter(self._ensure(), which))

@@ -53,6 +53,15 @@ def test_host_builder_equals_oracle_and_roundtrips(tmp_path):
     assert json.loads((tmp_path / "bm25_name_spaced" / "params.index.json").read_text())["method"] == "bm25+"
 
 
+def test_host_scores_of_a_small_index_equal_the_oracle():
+    """`get_scores_host` (the throw-away index over the rerank candidates, reference
+    search/engine.py:418-448) = bm25s's get_scores: bit-identical to the oracle's sequential sums."""
+    corpus = [tokenize_spaced(n) for n in synth_names(60, 7)]
+    ref, ix = R.build(corpus), BM25Index().index(corpus)
+    for q in (["nat", "add"], ["list", "map", "list"], ["nope"], []):
+        assert np.array_equal(ix.get_scores_host(q), R.scores(ref, R.token_ids(ref, q))), q
+
+
 @pytest.mark.gpu
 def test_hip_retrieve_bit_exact_vs_oracle():
     names = synth_names(200_000, 3)
@@ -82,6 +91,11 @@ def test_hip_retrieve_bit_exact_vs_oracle():
         docs, sc = fx.retrieve(q, 500)
         dref, sref = R.retrieve(fref, q, 500)
         assert np.array_equal(sc, sref) and np.array_equal(docs, dref), q
+    # the host scorer of small throw-away indices returns the very bits the GPU path returns
+    tiny = BM25Index().index(corpus[:50])
+    docs, sc = tiny.retrieve(["nat", "add", "comm"], 50)
+    host = tiny.get_scores_host(["nat", "add", "comm"])
+    assert np.array_equal(host[docs], sc)
     small = BM25Index().index(corpus[:30])
     docs, sc = small.retrieve(["nat"], 100)     # k > n_docs -> padding
     dref, sref = R.retrieve(R.build(corpus[:30]), ["nat"], 100)

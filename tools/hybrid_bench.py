@@ -111,6 +111,10 @@ def run(n=200_000, queries=30, layers=28, rerank_top=50, graphs=1, rerank_batch=
     docs = [" ".join(WORDS[(i * (j + 3)) % NW] for j in range(48)) for i in range(args.rerank_top)]
     t_rerank = timed(lambda i: loop.run_until_complete(reranker.rerank(queries[i], docs)),
                      min(10, len(queries)))
+    from types import SimpleNamespace
+    cands = [(SimpleNamespace(name=f"n{i}", informalization=dd, dependencies=None), 0.0) for i, dd in enumerate(docs)]
+    t_bm25_inf = timed(lambda i: engine._compute_bm25_on_informalizations(queries[i], cands), len(queries))
+    t_fetch = timed(lambda i: engine._fetch_declarations(ids[i * 37: i * 37 + 500]), len(queries))
     index.close()
     import shutil
 
@@ -133,7 +137,9 @@ def run(n=200_000, queries=30, layers=28, rerank_top=50, graphs=1, rerank_batch=
         "stages_ms": {"embed_query (PyTorch-ROCm)": round(t_embed, 3),
                       "dense top-1000 (HIP, host API incl. PCIe)": round(t_dense, 3),
                       "bm25 names x2 top-1000 (HIP, host API)": round(t_bm25, 3),
-                      f"rerank {args.rerank_top} docs (PyTorch-ROCm)": round(t_rerank, 3)},
+                      f"rerank {args.rerank_top} docs (PyTorch-ROCm)": round(t_rerank, 3),
+                      f"bm25 over the {args.rerank_top} candidates' informalizations": round(t_bm25_inf, 3),
+                      "fetch 500 declarations (sqlite)": round(t_fetch, 3)},
         "dense_share_of_end_to_end": round(t_dense / t_e2e, 4),
         "index_build_s": round(dt_build, 2)}
 

@@ -332,6 +332,10 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
                                            device=env.device_index, base=lo)
         tq = torch.from_numpy(queries).to(dev)
     index = None if inlib else ShardedFlatIPIndex(local, n)
+    if inlib and env.share_gpu:
+        # rehearsal on fewer GPUs than shards: the per-shard enqueue workers are off by default when
+        # shards share a device; force them so the real node's host path is what gets rehearsed
+        local.debug_option(11, 1)
 
     # nq <= 16 is the per-query HBM-bound scan path: consecutive steps are pipelined
     # (LS_FLAG_PIPELINE: launch i = scan of step i + one workgroup finalising step i-1, all on
@@ -474,6 +478,8 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         # used; 0 = copies (shards sharing a device cannot form a communicator)
         env.rccl_in_library = local.debug_counter(15) == 2
         env.shards_seen = local.shards()
+        # transport, RCCL version / failure text, enqueue workers, hipDeviceCanAccessPeer matrix
+        env.exchange_info = local.exchange_info()
     ev_ms = scan_ms_avg
     roof_src = "mean of hipEvent pairs bracketing each launch (second pass of the same steps)"
     if pipelined and nq == 1:
@@ -535,7 +541,10 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         "config": {"workload": f"{workload}: N={n} d={d} {dtype} nq={nq} k={k}",
                    "rows_per_gpu": n_local, "parallelism": f"row-shard x{G}",
                    "process_model": ("one process, sharded handle (ls_create_sharded)" if inlib
-                                     else "one process per GPU (torch.distributed)"),
+                                     else "one process per GPU (torch.distributed)" if world > 1
+                                     else ("one process, one GPU; the exchange code path is forced "
+                                           "over a one-rank process group (rehearsal)" if env.rehearse
+                                           else "one process, one GPU (no process group)")),
                    "exchange": ("one in-library all-gather + merge per step" if inlib else
                                 f"pipelined: one packed all-gather + merge per {EXCHANGE_EVERY} "
                                 "steps, overlapping the next scans"
@@ -703,11 +712,14 @@ def main():
         if host_api:
             out["host_api"] = host_api
         if env.inlib:
+            info = getattr(env, "exchange_info", {}) or {}
+            exch = info.get("exchange", "unknown")
+            if info.get("rccl_error"):  # RCCL could not be used on this node: the handle fell back
+                exch += f" ({info['rccl_error']})"
             out["process_model"] = ("one process: ls_create_sharded over devices "
-                                    f"{env.shard_devices}; exchange = "
-                                    + ("RCCL all-gather inside the library"
-                                       if getattr(env, "rccl_in_library", False)
-                                       else "device-to-device copies (shards share a device)"))
+                                    f"{env.shard_devices}; exchange = {exch}")
+            out["exchange"] = exch
+            out["exchange_info"] = info
             if not env.share_gpu and out["devices_seen"] != env.n_gpus:
                 raise SystemExit("bench.py: the sharded handle did not land on N distinct devices")
         if env.share_gpu:

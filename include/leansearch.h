@@ -108,6 +108,15 @@ int32_t ls_shard_count(const ls_index* index);
 int ls_shard_info(const ls_index* index, int32_t shard, int32_t* device, int64_t* row0,
                   int64_t* rows);
 
+/* What the exchange step of a sharded handle does on THIS node, as one JSON object in `buf`
+ * (NUL-terminated, truncated to `cap`): "exchange" ("rccl all-gather" | "peer-copy (RCCL failed)" |
+ * "device-to-device copies (shards share a device)" ...), "rccl_version", "rccl_error" (why RCCL
+ * could not be used: the handle then falls back to peer copies instead of failing every search),
+ * "rccl_communicators", "enqueue_workers" (one host thread per shard queues that shard's work),
+ * "devices" and the hipDeviceCanAccessPeer matrix "peer_access". Returns the length of the full
+ * text, or a negative LS_ERR_* code. */
+int32_t ls_shard_exchange_info(ls_index* index, char* buf, int32_t cap);
+
 /* As ls_create, but `d_corpus` is device memory on `device`, row-major float32 [n, d]
  * (used to build multi-GB synthetic shards without a host round trip). */
 int ls_create_from_device(ls_index** out, const void* d_corpus, int64_t n, int32_t d,
@@ -210,13 +219,17 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * option 10: synchronous host searches (ls_search) that arrive while another one is running are
  * served together, up to 16 queries of equal k and flags per corpus pass (default on);
  * option 8 (sharded handles): exchange step 0 = RCCL all-gather between distinct devices (default),
- * 1 = peer copies into the primary device's gather buffer.
+ * 1 = peer copies into the primary device's gather buffer; option 11 (sharded handles): one host
+ * thread per shard queues that shard's work: -1 automatic (on when the device ids are distinct,
+ * default), 0 off, 1 on; option 12 (sharded handles, test hook): make the next RCCL exchange fail
+ * (the handle must fall back to peer copies and keep answering).
  * counter 9: kernel launches the most recent batched call queued (counted per launch);
  * counter 10: path of the most recent search (1 per-query scan, 2 fp16 MFMA, 3 fp32 MFMA);
  * counter 11: kernel launches queued by searches on this handle so far; counter 12: batched calls
  * that were cut into sub-batches because the candidate queues could not hold the whole batch;
  * sharded handles: counter 13 exchange steps run, 14 re-exchanges after a shard repaired a
- * query, 15 exchange transport (0 copies, 1 RCCL selected, 2 RCCL communicators initialised);
+ * query, 15 exchange transport (0 copies, 1 RCCL selected, 2 RCCL communicators initialised, 3 RCCL failed
+ * on this node: fell back to peer copies), 19 calls whose shards were queued by the enqueue workers;
  * counters 0, 1, 8, 11, 12 are summed over the shards, 9 and 10 are the primary shard's;
  * counter 16: combined batches ls_search served, 17: the requests they carried; counter 18 (sharded
  * handles): mean host nanoseconds spent queueing one search (every device's work + exchange + merge).

@@ -92,11 +92,11 @@ static int alloc_rows(ls_index* ix, int64_t new_n, bool amortise) {
         // ls_scan_blocks() <= 2 workgroups per CU; room for the tuning hook (debug option 7) to
         // force up to 4 per CU
         ix->max_blocks = 4 * ix->n_cu;
-        for (auto& st : ix->sets) {  // room for LS_SCAN_NQ_MAX queries per generation
+        for (auto& st : ix->sets) {  // room for LS_QUERIES_PER_LAUNCH_MAX queries per generation
             LS_HIP(hipMalloc((void**)&st.d_cand,
-                             sizeof(u64) * (size_t)ix->max_blocks * LS_KP_MAX * LS_SCAN_NQ_MAX));
+                             sizeof(u64) * (size_t)ix->max_blocks * LS_KP_MAX * LS_QUERIES_PER_LAUNCH_MAX));
             LS_HIP(hipMalloc((void**)&st.d_bound,
-                             sizeof(u64) * (size_t)ix->max_blocks * LS_SCAN_NQ_MAX));
+                             sizeof(u64) * (size_t)ix->max_blocks * LS_QUERIES_PER_LAUNCH_MAX));
         }
     }
     if (new_n > ix->cap_rows || !ix->sets[0].d_S) {
@@ -111,7 +111,7 @@ static int alloc_rows(ls_index* ix, int64_t new_n, bool amortise) {
             bool ok = new_n == 0 ||
                       hipMalloc(&d_new, (size_t)(want + LS_CORPUS_PAD_ROWS) * row_bytes) == hipSuccess;
             for (int i = 0; ok && i < LS_NSETS; ++i)
-                ok = hipMalloc((void**)&S_new[i], sizeof(float) * (size_t)stride * LS_SCAN_NQ_MAX) ==
+                ok = hipMalloc((void**)&S_new[i], sizeof(float) * (size_t)stride * LS_QUERIES_PER_LAUNCH_MAX) ==
                      hipSuccess;
             if (ok) break;
             (void)hipGetLastError();
@@ -419,7 +419,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         // padded query slots re-read the last real query (their results are never finalised)
         const float* qsrc = d_q + q0 * g.d;
         if (real < NQ) {
-            rc = ls_grow(&ix->d_qpad, &ix->qpad_cap, (size_t)LS_SCAN_NQ_MAX * g.d);
+            rc = ls_grow(&ix->d_qpad, &ix->qpad_cap, (size_t)LS_QUERIES_PER_LAUNCH_MAX * g.d);
             if (rc != LS_OK) return rc;
             for (int i = 0; i < NQ; ++i)
                 LS_HIP(hipMemcpyAsync(ix->d_qpad + (size_t)i * g.d,
@@ -495,7 +495,7 @@ bool ls_i_batched_eligible(const ls_index* ix, int64_t nq, int32_t k) {
     const bool big = ix->n >= LS_GEMM_MIN_ROWS ||
                      (ix->n >= LS_GEMM_MIN_ROWS_BIGNQ && nq >= LS_GEMM_BIGNQ);
     if (ix->dtype == LS_DTYPE_F16)
-        return nq > LS_SCAN_MAX_NQ && ix->g.chunks <= LS_GEMM_MAX_CHUNKS && big;
+        return nq > LS_SCAN_PATH_MAX_NQ && ix->g.chunks <= LS_GEMM_MAX_CHUNKS && big;
     return nq >= LS_GEMM32_MIN_NQ && big;  // fp32: exact f32 MFMA (ls_gemm32.hip), any row length
 }
 
@@ -864,7 +864,7 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
     // Pinned host buffers are device-visible: kernels read the queries from h_q and write the
     // results into h_out_* over PCIe themselves, which saves the copy commands' serial latency
     // (measured in tools/hostapi_time.py).
-    const bool in_direct = nq <= LS_SCAN_MAX_NQ;    // big batches: one bulk copy is better
+    const bool in_direct = nq <= LS_SCAN_PATH_MAX_NQ;    // big batches: one bulk copy is better
     const bool out_direct = on <= (size_t)(1 << 16);
     // Small scan-path calls: the finalize workgroup of every query publishes a completion word
     // in pinned host memory once its (pinned) output rows are visible; the host spins on those
@@ -872,8 +872,8 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
     // 47 us scan's launch). Falls back to the stream sync after 2 ms.
     const bool spin = in_direct && out_direct && !ls_i_batched_eligible(ix, nq, k) && ix->n > 0;
     if (spin && !ix->h_done) {
-        LS_HIP(hipHostMalloc((void**)&ix->h_done, sizeof(u32) * LS_SCAN_MAX_NQ, hipHostMallocDefault));
-        memset(ix->h_done, 0, sizeof(u32) * LS_SCAN_MAX_NQ);
+        LS_HIP(hipHostMalloc((void**)&ix->h_done, sizeof(u32) * LS_SCAN_PATH_MAX_NQ, hipHostMallocDefault));
+        memset(ix->h_done, 0, sizeof(u32) * LS_SCAN_PATH_MAX_NQ);
     }
     memcpy(ix->h_q, q, qn * sizeof(float));
     if (!in_direct)
@@ -919,7 +919,7 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
 // scan path serves up to 8 queries per corpus pass (8 queries: 135 us; 8 passes of one: 8 x 72 us),
 // so requests that arrive while a search is running are not queued behind the mutex one by one:
 // they wait in a queue, and whoever holds the leadership serves ALL compatible waiters (same k, same
-// flags, <= LS_SCAN_MAX_NQ queries in total) as ONE batch, then hands their results back. A lone
+// flags, <= LS_SCAN_PATH_MAX_NQ queries in total) as ONE batch, then hands their results back. A lone
 // caller becomes leader at once and pays nothing; waiters sleep on a condition variable (no
 // spinning on the mutex). Results are those of the separate calls: every query's arithmetic is
 // the same whatever group it rides in.
@@ -979,7 +979,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
     if (rc != LS_OK) return rc;
     if (nq == 0) return LS_OK;
     flags &= LS_FLAG_NORMALIZE;
-    if (!ix->opt_combine || nq > LS_SCAN_NQ_MAX)  // big batches gain nothing from company
+    if (!ix->opt_combine || nq > LS_QUERIES_PER_LAUNCH_MAX)  // big batches gain nothing from company
         return host_search_locked(ix, q, nq, k, flags, out_scores, out_indices);
     ls_req me{q, nq, k, flags, out_scores, out_indices};
     std::unique_lock<std::mutex> lk(ix->q_mu);
@@ -997,7 +997,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             int64_t total = 0;
             while (!ix->req_q.empty()) {
                 ls_req* r = ix->req_q.front();
-                if (r->k != head->k || r->flags != head->flags || total + r->nq > LS_SCAN_MAX_NQ) break;
+                if (r->k != head->k || r->flags != head->flags || total + r->nq > LS_SCAN_PATH_MAX_NQ) break;
                 batch.push_back(r);
                 total += r->nq;
                 ix->req_q.pop_front();
@@ -1370,7 +1370,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 18) return -1;
+    if (!ix || which < 0 || which > 19) return -1;
     if (which == 16 || which == 17) {
         std::lock_guard<std::mutex> ql(ix->q_mu);
         return (int64_t)(which == 16 ? ix->n_combined_batches : ix->n_combined_requests);
@@ -1382,7 +1382,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
     if (which == 10) return (int64_t)ix->last_path;
     if (which == 11) return (int64_t)ix->n_launches_total;
     if (which == 12) return (int64_t)ix->n_chunked_calls;
-    if (which > 9) return 0;  // 13..15 and 18 are group counters
+    if (which > 9) return 0;  // 13..15, 18 and 19 are group counters
     if (hipSetDevice(ix->device) != hipSuccess) return -1;
     u32 v = 0;
     if (hipMemcpy(&v, ix->d_counters + which, sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess)

@@ -27,7 +27,7 @@ typedef unsigned int u32;
 #define LS_KP_MAX 16                 // per-workgroup emitted candidates (k') + 1 bound
 #define LS_FINAL_THREADS 1024
 #define LS_FINAL_CAP 8192            // keys the finalize workgroup sorts in LDS (64 KiB)
-#define LS_SCAN_MAX_NQ 16            // nq <= this: per-query HBM-bound scan path
+#define LS_SCAN_PATH_MAX_NQ 16            // nq <= this: per-query HBM-bound scan path
 #define LS_SAME_LAUNCH_MAX_BLOCKS 200 // ordered calls with at most this many scan workgroups select inside the scan launch
 #ifndef LS_SCAN_MQ_SCATTER
 #define LS_SCAN_MQ_SCATTER 1          // multi-query scan launches: reduce-scatter of the partial sums (0: one butterfly per pair)
@@ -190,9 +190,9 @@ struct ls_fin_params {
     u32* arrive;
     u32 arrive_target;
 };
-#define LS_SCAN_NQ_MAX 8
+#define LS_QUERIES_PER_LAUNCH_MAX 8
 struct ls_fin_batch {
-    ls_fin_params p[LS_SCAN_NQ_MAX];
+    ls_fin_params p[LS_QUERIES_PER_LAUNCH_MAX];
 };
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
@@ -208,7 +208,7 @@ int ls_launch_unconvert(const void* d_src, float* d_dst, int64_t n, const ls_geo
 // + per-workgroup best kprime keys and bound
 int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu);
 // One scan launch: `nq` (1, 4 or 8) queries share one pass over the corpus; the launch may carry
-// up to LS_SCAN_NQ_MAX selection jobs of the PREVIOUS launch, each executed by one extra
+// up to LS_QUERIES_PER_LAUNCH_MAX selection jobs of the PREVIOUS launch, each executed by one extra
 // workgroup, so that selection costs neither a launch nor a kernel boundary.
 struct ls_scan_args {
     const float* d_q;      // nq raw queries, d floats apart (normalisation / fp16 rounding fused in)

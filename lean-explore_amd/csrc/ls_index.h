@@ -124,7 +124,7 @@ struct ls_index {
     int32_t max_blocks = 0;
     float* d_out_s = nullptr;  int64_t* d_out_i = nullptr;  size_t out_cap = 0;  // nq*k
     u32* d_counters = nullptr;                        // [0] finalize slow-path count
-    u32* h_done = nullptr;     // pinned [LS_SCAN_MAX_NQ]: completion words of the host API
+    u32* h_done = nullptr;     // pinned [LS_SCAN_PATH_MAX_NQ]: completion words of the host API
     u32 done_seq = 0;
     u32* done_base = nullptr;  // set by ls_search around its scan-path call, else null
     float* h_q = nullptr;      size_t h_q_cap = 0;    // pinned

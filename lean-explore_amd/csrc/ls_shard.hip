@@ -22,16 +22,34 @@
 //
 // Duplicate device ids (a rehearsal of G shards on fewer GPUs, e.g. {0,0,0}) cannot form an RCCL
 // communicator; they, and handles switched with ls_debug_option(8, 1), exchange by plain
-// device-to-device / peer copies into the primary's gather buffer instead.
+// device-to-device / peer copies into the primary's gather buffer instead. The same copies are the
+// FALLBACK when RCCL cannot be bound or ncclCommInitAll / the all-gather fails on the node: the
+// handle keeps answering (ls_shard_exchange_info says why), it does not fail every search.
+//
+// Host side: queueing one shard's work costs ~11-12 us of host time (stream waits, query copy, the
+// sub-search's launches); from one thread that is ~90 us for 8 shards, more than the whole 1-GPU
+// call. With distinct devices every shard therefore has an ENQUEUE WORKER (a thread bound to that
+// device; it spins briefly between back-to-back calls, then sleeps) and the caller's thread only
+// posts the jobs, waits, and queues the exchange + merge. Shards that share a device (rehearsals)
+// are queued from the caller's thread: one device's queues are serialised by the runtime anyway
+// (measured: no gain, profiles/ab/r03_group_host_overhead.txt). ls_debug_option(11, 0/1) forces it.
 #include "ls_index.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <immintrin.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <cstdio>
 #include <cstring>
+#include <functional>
 #include <new>
+#include <string>
+#include <thread>
 
 #define LS_SH_SLOTS 8  // batched calls that may be outstanding before the group checks itself
 #define LS_SH_SCAN_SLOT LS_SH_SLOTS  // exact (scan-path) calls are ordered by events: one slot
@@ -95,6 +113,81 @@ int rccl_bind() {
         }                                                                                    \
     } while (0)
 
+// Restores the calling thread's current HIP device on every exit path: the group entry points hop
+// over the shards' devices, and PyTorch shares this per-thread state with us.
+struct ls_device_guard {
+    int prev = -1;
+    ls_device_guard() {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    }
+    ~ls_device_guard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// One enqueue worker per shard (see the file header). post() hands it a job; wait() returns the
+// job's return code (the worker's thread-local error text is copied into `err`).
+struct ls_shard_worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    std::atomic<uint32_t> posted{0}, done{0};
+    bool stop = false;
+    int device = 0;
+    int rc = LS_OK;
+    char err[256] = "";
+
+    void run() {
+        (void)hipSetDevice(device);
+        uint32_t seen = 0;
+        for (;;) {
+            bool got = false;
+            for (int i = 0; i < 3000 && !got; ++i) {  // calls come back to back: spin ~50 us first
+                if (posted.load(std::memory_order_acquire) != seen) got = true;
+                else _mm_pause();
+            }
+            if (!got) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || posted.load(std::memory_order_acquire) != seen; });
+            }
+            if (posted.load(std::memory_order_acquire) == seen) {
+                if (stop) return;
+                continue;
+            }
+            seen = posted.load(std::memory_order_acquire);
+            rc = job();
+            if (rc != LS_OK) snprintf(err, sizeof(err), "%s", ls_last_error());
+            done.store(seen, std::memory_order_release);
+        }
+    }
+    void post(std::function<int()> j) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = std::move(j);
+            posted.fetch_add(1, std::memory_order_release);
+        }
+        cv.notify_one();
+    }
+    int wait() {  // the job is ~10 us of launches: spinning is cheaper than a wake-up
+        const uint32_t want = posted.load(std::memory_order_relaxed);
+        for (unsigned it = 0; done.load(std::memory_order_acquire) != want; ++it) {
+            if ((it & 4095) == 4095) std::this_thread::yield();
+            else _mm_pause();
+        }
+        return rc;
+    }
+    void shutdown() {
+        if (!th.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_one();
+        th.join();
+    }
+};
+
 struct ls_shard_group {
     int G = 0;
     std::vector<ls_index*> sub;  // one single-device handle per shard
@@ -104,6 +197,13 @@ struct ls_shard_group {
     int exchange_mode = 0;       // 0: RCCL all-gather when `distinct`; 1: peer copies to the primary
     std::vector<ncclComm_t> comms;
     bool comms_ready = false;
+    bool debug_fail_rccl = false;  // test hook (debug option 12): pretend the collective failed
+    bool rccl_failed = false;    // RCCL could not be used on this node: the handle fell back to copies
+    char rccl_error[256] = "";
+    int rccl_version = 0;
+    int opt_workers = -1;        // -1 auto (on when the device ids are distinct), 0 off, 1 on
+    std::vector<ls_shard_worker*> workers;
+    std::vector<int> peer;       // G x G: hipDeviceCanAccessPeer(dev[a], dev[b]) as seen at creation (-1: same device)
 
     struct buf {
         char* p = nullptr;
@@ -141,7 +241,7 @@ struct ls_shard_group {
     int64_t* d_out_i = nullptr; size_t d_out_i_cap = 0;
 
     uint64_t repairs_seen = 0;  // sum of the shards' repair counters when the last check finished
-    uint64_t n_exchanges = 0, n_reexchanges = 0;
+    uint64_t n_exchanges = 0, n_reexchanges = 0, n_worker_calls = 0;
     uint64_t enqueue_ns = 0, enqueue_calls = 0;  // host time spent queueing searches (debug counter 18)
 };
 
@@ -155,6 +255,7 @@ static int group_init_comms(ls_shard_group* G) {
     if (G->comms_ready) return LS_OK;
     int rc = rccl_bind();
     if (rc != LS_OK) return rc;
+    (void)g_rccl.GetVersion(&G->rccl_version);
     G->comms.assign(G->G, nullptr);
     LS_NCCL(g_rccl.CommInitAll(G->comms.data(), G->G, G->dev.data()));
     G->comms_ready = true;
@@ -163,27 +264,44 @@ static int group_init_comms(ls_shard_group* G) {
 
 // One exchange step of slot `slot`: afterwards (in the order of the primary's stream) the primary's
 // gather buffer holds the G packed blocks, block g at offset g * block.
+static int group_exchange_rccl(ls_shard_group* G, int slot, size_t block) {
+    int rc;
+    if ((rc = group_init_comms(G)) != LS_OK) return rc;
+    for (int g = 0; g < G->G; ++g) {
+        LS_HIP(hipSetDevice(G->dev[g]));
+        if ((rc = group_grow(&G->sh[g].gathered[slot], block * G->G)) != LS_OK) return rc;
+    }
+    LS_NCCL(g_rccl.GroupStart());
+    for (int g = 0; g < G->G; ++g) {
+        ncclResult_t r = g_rccl.AllGather(G->sh[g].packed[slot].p, G->sh[g].gathered[slot].p,
+                                          block, ncclUint8, G->comms[g], G->sh[g].stream);
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            ls_set_error("ncclAllGather failed: %s", g_rccl.GetErrorString(r));
+            return LS_ERR_HIP;
+        }
+    }
+    LS_NCCL(g_rccl.GroupEnd());
+    return LS_OK;
+}
+
 static int group_exchange(ls_shard_group* G, int slot, size_t block) {
     int rc;
     G->n_exchanges++;
     if (group_uses_rccl(G)) {
-        if ((rc = group_init_comms(G)) != LS_OK) return rc;
-        for (int g = 0; g < G->G; ++g) {
-            LS_HIP(hipSetDevice(G->dev[g]));
-            if ((rc = group_grow(&G->sh[g].gathered[slot], block * G->G)) != LS_OK) return rc;
+        if (G->debug_fail_rccl) {
+            ls_set_error("RCCL failure injected by ls_debug_option(12, 1)");
+            rc = LS_ERR_HIP;
+        } else {
+            rc = group_exchange_rccl(G, slot, block);
         }
-        LS_NCCL(g_rccl.GroupStart());
-        for (int g = 0; g < G->G; ++g) {
-            ncclResult_t r = g_rccl.AllGather(G->sh[g].packed[slot].p, G->sh[g].gathered[slot].p,
-                                              block, ncclUint8, G->comms[g], G->sh[g].stream);
-            if (r != ncclSuccess) {
-                (void)g_rccl.GroupEnd();
-                ls_set_error("ncclAllGather failed: %s", g_rccl.GetErrorString(r));
-                return LS_ERR_HIP;
-            }
-        }
-        LS_NCCL(g_rccl.GroupEnd());
-        return LS_OK;
+        if (rc == LS_OK) return LS_OK;
+        // RCCL is not usable here (library missing, ncclCommInitAll or the collective failed): the
+        // peer-copy exchange below gives the same gather buffer on the primary. Keep answering;
+        // ls_shard_exchange_info / debug counter 15 (= 3) report what happened.
+        G->rccl_failed = true;
+        snprintf(G->rccl_error, sizeof(G->rccl_error), "%s", ls_last_error());
+        G->exchange_mode = 1;
     }
     // copy mode: every shard writes its block into the primary's gather buffer (a peer write over
     // xGMI, or a plain device-to-device copy when the shards share a device)
@@ -250,6 +368,30 @@ static int group_merge(ls_shard_group* G, int slot, size_t block, size_t sbytes,
     return LS_OK;
 }
 
+static int group_start_workers(ls_shard_group* G) {
+    if (!G->workers.empty()) return LS_OK;
+    G->workers.assign(G->G, nullptr);
+    for (int g = 1; g < G->G; ++g) {  // shard 0 is queued from the calling thread
+        ls_shard_worker* w = new (std::nothrow) ls_shard_worker();
+        if (!w) {
+            ls_set_error("sharded index: out of host memory for the enqueue workers");
+            return LS_ERR_INVALID_ARG;
+        }
+        w->device = G->dev[g];
+        w->th = std::thread([w] { w->run(); });
+        G->workers[g] = w;
+    }
+    return LS_OK;
+}
+static void group_stop_workers(ls_shard_group* G) {
+    for (ls_shard_worker* w : G->workers) {
+        if (!w) continue;
+        w->shutdown();
+        delete w;
+    }
+    G->workers.clear();
+}
+
 static uint64_t group_repairs(const ls_shard_group* G) {
     uint64_t t = 0;
     for (const ls_index* s : G->sub) t += s->n_batched_fallback;
@@ -302,6 +444,7 @@ static int group_check_locked(ls_index* ix) {
 }
 
 int ls_group_check(ls_index* ix, hipStream_t s) {
+    ls_device_guard guard;
     int rc = group_check_locked(ix);
     if (rc != LS_OK) return rc;
     LS_HIP(hipStreamSynchronize(s));
@@ -310,6 +453,7 @@ int ls_group_check(ls_index* ix, hipStream_t s) {
 
 int ls_group_search(ls_index* ix, const float* q, bool q_on_host, int64_t nq, int32_t k,
                     uint32_t flags, float* out_s, int64_t* out_i, hipStream_t s) {
+    ls_device_guard guard;  // every exit (errors included) leaves the caller's device current
     ls_shard_group* G = ix->group;
     const int P = G->dev[0];
     const int32_t d = ix->g.d;
@@ -328,7 +472,7 @@ int ls_group_search(ls_index* ix, const float* q, bool q_on_host, int64_t nq, in
 
     LS_HIP(hipSetDevice(P));
     hipStream_t s0 = G->sh[0].stream;
-    const bool q_direct = q_on_host && nq <= LS_SCAN_MAX_NQ;  // kernels read the pinned buffer
+    const bool q_direct = q_on_host && nq <= LS_SCAN_PATH_MAX_NQ;  // kernels read the pinned buffer
     const bool out_direct = q_on_host && on <= (size_t)(1 << 16);
     float* dst_s = out_s;
     int64_t* dst_i = out_i;
@@ -351,7 +495,10 @@ int ls_group_search(ls_index* ix, const float* q, bool q_on_host, int64_t nq, in
     } else {
         LS_HIP(hipEventRecord(G->ev_in, s));
     }
-    for (int g = 0; g < G->G; ++g) {
+    // one shard's share of the call, queued on that shard's stream (runs on the shard's enqueue
+    // worker when the handle has them, else right here)
+    auto enqueue_shard = [&](int g) -> int {
+        int rc2;
         ls_shard_group::shard& S = G->sh[g];
         ls_index* sub = G->sub[g];
         LS_HIP(hipSetDevice(G->dev[g]));
@@ -362,28 +509,48 @@ int ls_group_search(ls_index* ix, const float* q, bool q_on_host, int64_t nq, in
         if (q_direct) {
             qg = G->h_q;
         } else if (q_on_host) {
-            if ((rc = ls_grow(&S.d_q, &S.q_cap, qn)) != LS_OK) return rc;
+            if ((rc2 = ls_grow(&S.d_q, &S.q_cap, qn)) != LS_OK) return rc2;
             LS_HIP(hipMemcpyAsync(S.d_q, G->h_q, qn * sizeof(float), hipMemcpyHostToDevice, S.stream));
             qg = S.d_q;
         } else if (G->dev[g] != P) {
-            if ((rc = ls_grow(&S.d_q, &S.q_cap, qn)) != LS_OK) return rc;
+            if ((rc2 = ls_grow(&S.d_q, &S.q_cap, qn)) != LS_OK) return rc2;
             LS_HIP(hipMemcpyPeerAsync(S.d_q, G->dev[g], q, P, qn * sizeof(float), S.stream));
             qg = S.d_q;
         }
-        if ((rc = group_grow(&S.packed[slot], block)) != LS_OK) return rc;
+        if ((rc2 = group_grow(&S.packed[slot], block)) != LS_OK) return rc2;
         char* pk = S.packed[slot].p;
         // Sub-searches are always queued asynchronously. LS_FLAG_PIPELINE reaches the batched path
-        // only (its two lanes); on the scan path it would leave the last selection step pending in
-        // the sub-handle, and the exchange needs the shard's rows now.
+        // only (its internal streams); on the scan path it would leave the last selection step
+        // pending in the sub-handle, and the exchange needs the shard's rows now.
         const bool sub_batched = ls_i_batched_eligible(sub, nq, k);
         const uint32_t f = (flags & LS_FLAG_NORMALIZE) | LS_FLAG_ASYNC |
                            ((sub_batched && !q_on_host) ? (flags & LS_FLAG_PIPELINE) : 0u);
-        rc = ls_i_search_on_stream(sub, qg, nq, k, f, (float*)pk, (int64_t*)(pk + sbytes), S.stream,
-                                   false);
+        rc2 = ls_i_search_on_stream(sub, qg, nq, k, f, (float*)pk, (int64_t*)(pk + sbytes), S.stream,
+                                    false);
+        if (rc2 != LS_OK) return rc2;
+        // orders S.stream behind the sub-handle's internal streams (and ships the flags: whether a
+        // call is re-merged is decided from the shards' repair counters, group_check_locked)
+        if (batched && (rc2 = ls_i_export_flags(sub, pk + sbytes + rbytes, nq, S.stream)) != LS_OK)
+            return rc2;
+        return LS_OK;
+    };
+    const bool use_workers = G->G > 1 && (G->opt_workers == 1 || (G->opt_workers < 0 && G->distinct));
+    if (use_workers) {
+        if ((rc = group_start_workers(G)) != LS_OK) return rc;
+        for (int g = 1; g < G->G; ++g) G->workers[g]->post([&enqueue_shard, g] { return enqueue_shard(g); });
+        rc = enqueue_shard(0);  // the primary's share from this thread, concurrently with the workers
+        for (int g = 1; g < G->G; ++g) {
+            const int rg = G->workers[g]->wait();
+            if (rg != LS_OK && rc == LS_OK) {
+                rc = rg;
+                ls_set_error("%s", G->workers[g]->err);
+            }
+        }
         if (rc != LS_OK) return rc;
-        // the flags region is only ever read for batched calls (group_check_locked)
-        if (batched && (rc = ls_i_export_flags(sub, pk + sbytes + rbytes, nq, S.stream)) != LS_OK)
-            return rc;
+        G->n_worker_calls++;
+    } else {
+        for (int g = 0; g < G->G; ++g)
+            if ((rc = enqueue_shard(g)) != LS_OK) return rc;
     }
     if ((rc = group_exchange(G, slot, block)) != LS_OK) return rc;
     LS_HIP(hipSetDevice(P));
@@ -420,8 +587,10 @@ int ls_group_search(ls_index* ix, const float* q, bool q_on_host, int64_t nq, in
 }
 
 void ls_group_destroy(ls_index* ix) {
+    ls_device_guard guard;
     ls_shard_group* G = ix->group;
     if (!G) return;
+    group_stop_workers(G);
     for (int g = 0; g < (int)G->sh.size(); ++g) {
         (void)hipSetDevice(G->dev[g]);
         ls_shard_group::shard& S = G->sh[g];
@@ -455,6 +624,7 @@ void ls_group_destroy(ls_index* ix) {
 }
 
 int ls_group_set_base(ls_index* ix, int64_t base) {
+    ls_device_guard guard;
     ls_shard_group* G = ix->group;
     ix->base = base;
     for (int g = 0; g < G->G; ++g) {
@@ -467,7 +637,13 @@ int ls_group_set_base(ls_index* ix, int64_t base) {
 // index.add on a sharded index: the new rows extend the LAST shard (row blocks stay contiguous and
 // every global row keeps its number; rebuild the index to rebalance).
 int ls_group_add(ls_index* ix, const float* rows, int64_t n_add) {
+    ls_device_guard guard;
     ls_shard_group* G = ix->group;
+    if (ix->n + n_add >= 0xffffffffll) {  // result keys and the merge carry 32-bit GLOBAL rows
+        ls_set_error("ls_add: %lld rows exceed the 2^32-1 rows the result keys can index",
+                     (long long)(ix->n + n_add));
+        return LS_ERR_INVALID_ARG;
+    }
     int rc = group_check_locked(ix);
     if (rc != LS_OK) return rc;
     rc = ls_add(G->sub[G->G - 1], rows, n_add);
@@ -476,6 +652,7 @@ int ls_group_add(ls_index* ix, const float* rows, int64_t n_add) {
 }
 
 int ls_group_reconstruct(ls_index* ix, int64_t row0, int64_t count, float* out) {
+    ls_device_guard guard;
     ls_shard_group* G = ix->group;
     for (int g = 0; g < G->G && count > 0; ++g) {
         const int64_t lo = G->lo[g], hi = lo + G->sub[g]->n;
@@ -488,6 +665,7 @@ int ls_group_reconstruct(ls_index* ix, int64_t row0, int64_t count, float* out) 
 }
 
 int ls_group_debug_option(ls_index* ix, int32_t which, int32_t value) {
+    ls_device_guard guard;
     ls_shard_group* G = ix->group;
     if (which == 8) {  // 0: RCCL all-gather between distinct devices (default); 1: peer copies
         if (value != 0 && value != 1) {
@@ -499,6 +677,14 @@ int ls_group_debug_option(ls_index* ix, int32_t which, int32_t value) {
         G->exchange_mode = value;
         return LS_OK;
     }
+    if (which == 11) {  // per-shard enqueue workers: -1 auto (distinct devices), 0 off, 1 on
+        G->opt_workers = value < 0 ? -1 : (value ? 1 : 0);
+        return LS_OK;
+    }
+    if (which == 12) {  // test hook: the next RCCL exchange fails (exercises the copy fallback)
+        G->debug_fail_rccl = value != 0;
+        return LS_OK;
+    }
     for (ls_index* s : G->sub) {
         int rc = ls_debug_option(s, which, value);
         if (rc != LS_OK) return rc;
@@ -507,11 +693,15 @@ int ls_group_debug_option(ls_index* ix, int32_t which, int32_t value) {
 }
 
 int64_t ls_group_debug_counter(ls_index* ix, int32_t which) {
+    ls_device_guard guard;
     ls_shard_group* G = ix->group;
     if (which == 18) return G->enqueue_calls ? (int64_t)(G->enqueue_ns / G->enqueue_calls) : 0;
     if (which == 13) return (int64_t)G->n_exchanges;
     if (which == 14) return (int64_t)G->n_reexchanges;
-    if (which == 15) return group_uses_rccl(G) ? (G->comms_ready ? 2 : 1) : 0;
+    // 0: copies (shards share a device, or debug option 8); 1: RCCL selected, not yet used;
+    // 2: RCCL communicators initialised and in use; 3: RCCL failed on this node, fell back to copies
+    if (which == 15) return G->rccl_failed ? 3 : (group_uses_rccl(G) ? (G->comms_ready ? 2 : 1) : 0);
+    if (which == 19) return (int64_t)G->n_worker_calls;
     if (which == 9 || which == 10) return ls_debug_counter(G->sub[0], which);
     int64_t t = 0;
     for (ls_index* s : G->sub) {
@@ -524,9 +714,11 @@ int64_t ls_group_debug_counter(ls_index* ix, int32_t which) {
 
 // Kernel timing is the primary shard's (every shard runs the same kernels on an equal row block).
 int ls_group_set_profiling(ls_index* ix, int32_t enabled) {
+    ls_device_guard guard;
     return ls_set_profiling(ix->group->sub[0], enabled);
 }
 int ls_group_last_kernel_ms(ls_index* ix, float* scan_ms, float* total_ms) {
+    ls_device_guard guard;
     return ls_last_kernel_ms(ix->group->sub[0], scan_ms, total_ms);
 }
 
@@ -590,6 +782,7 @@ static int group_begin(ls_index** out, int64_t n, int32_t d, int32_t dtype, cons
 static int group_finish(ls_index* ix) {
     ls_shard_group* G = ix->group;
     G->sh.resize(G->G);
+    G->peer.assign((size_t)G->G * G->G, -1);
     for (int g = 0; g < G->G; ++g) {
         LS_HIP(hipSetDevice(G->dev[g]));
         LS_HIP(hipStreamCreateWithFlags(&G->sh[g].stream, hipStreamNonBlocking));
@@ -598,7 +791,9 @@ static int group_finish(ls_index* ix) {
         for (int h = 0; h < G->G; ++h) {
             if (G->dev[h] == G->dev[g]) continue;
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, G->dev[g], G->dev[h]) == hipSuccess && can) {
+            const bool asked = hipDeviceCanAccessPeer(&can, G->dev[g], G->dev[h]) == hipSuccess;
+            G->peer[(size_t)g * G->G + h] = asked ? (can ? 1 : 0) : -2;
+            if (asked && can) {
                 hipError_t e = hipDeviceEnablePeerAccess(G->dev[h], 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
                 if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
@@ -679,6 +874,48 @@ int ls_create_sharded_from_device(ls_index** out, const void* const* d_blocks, c
     }
     *out = ix;
     return LS_OK;
+}
+
+// What the exchange of a sharded handle really does on this node, as one JSON object (for bench
+// records and bug reports): exchange mode, RCCL version / failure text, enqueue workers, and the
+// hipDeviceCanAccessPeer matrix seen at creation (-1 on the diagonal and between shards that share a
+// device). Returns the number of bytes the full text needs (excluding the terminator).
+int32_t ls_shard_exchange_info(ls_index* ix, char* buf, int32_t cap) {
+    if (!ix || !ix->group) {
+        ls_set_error("ls_shard_exchange_info: not a sharded handle");
+        return LS_ERR_INVALID_ARG;
+    }
+    std::lock_guard<std::mutex> lk(ix->mu);
+    const ls_shard_group* G = ix->group;
+    std::string o = "{\"exchange\": \"";
+    o += G->rccl_failed ? "peer-copy (RCCL failed)"
+         : group_uses_rccl(G) ? (G->comms_ready ? "rccl all-gather" : "rccl all-gather (not used yet)")
+         : (G->distinct ? "peer-copy (selected)" : "device-to-device copies (shards share a device)");
+    o += "\", \"rccl_version\": " + std::to_string(G->rccl_version);
+    std::string err = G->rccl_error;
+    for (char& c : err)
+        if (c == '"' || c == '\\' || (unsigned char)c < 32) c = ' ';
+    o += ", \"rccl_error\": \"" + err + "\"";
+    o += ", \"rccl_communicators\": " + std::to_string(G->comms_ready ? G->G : 0);
+    const bool workers = G->G > 1 && (G->opt_workers == 1 || (G->opt_workers < 0 && G->distinct));
+    o += std::string(", \"enqueue_workers\": ") + (workers ? "true" : "false");
+    o += ", \"worker_calls\": " + std::to_string(G->n_worker_calls);
+    o += ", \"devices\": [";
+    for (int g = 0; g < G->G; ++g) o += (g ? ", " : "") + std::to_string(G->dev[g]);
+    o += "], \"peer_access\": [";
+    for (int a = 0; a < G->G; ++a) {
+        o += a ? ", [" : "[";
+        for (int b = 0; b < G->G; ++b)
+            o += (b ? ", " : "") + std::to_string(G->peer.empty() ? -1 : G->peer[(size_t)a * G->G + b]);
+        o += "]";
+    }
+    o += "]}";
+    if (buf && cap > 0) {
+        const size_t m = std::min<size_t>(o.size(), (size_t)cap - 1);
+        memcpy(buf, o.data(), m);
+        buf[m] = 0;
+    }
+    return (int32_t)o.size();
 }
 
 int32_t ls_shard_count(const ls_index* ix) { return ix ? (ix->group ? ix->group->G : 0) : -1; }

@@ -172,31 +172,3 @@ def _read_ivf_flat(f) -> tuple[int, np.ndarray]:
     if not seen.all():
         raise ValueError("IVF index: inverted lists do not cover every row")
     return d, corpus
-
-
-def write_ivf_flat_for_tests(path, corpus: np.ndarray, assign: np.ndarray, nlist: int) -> None:
-    """Write an ``IwFl`` file with the given row -> list assignment (test helper: exercises the
-    reader on the layout the reference ships; not a trained IVF)."""
-    corpus = np.ascontiguousarray(corpus, dtype="<f4")
-    n, d = corpus.shape
-    with open(path, "wb") as f:
-        f.write(struct.pack("<I", _fourcc("IwFl")))
-        _write_header(f, d, n, METRIC_INNER_PRODUCT)
-        f.write(struct.pack("<QQ", nlist, 1))
-        f.write(struct.pack("<I", _fourcc("IxFI")))           # quantizer: nlist zero centroids
-        _write_header(f, d, nlist, METRIC_INNER_PRODUCT)
-        f.write(struct.pack("<Q", nlist * d))
-        f.write(np.zeros(nlist * d, "<f4").tobytes())
-        f.write(struct.pack("<b", 0))                         # no direct map
-        f.write(struct.pack("<Q", 0))
-        f.write(struct.pack("<I", _fourcc("ilar")))
-        f.write(struct.pack("<QQ", nlist, 4 * d))
-        f.write(struct.pack("<I", _fourcc("full")))
-        sizes = np.bincount(assign, minlength=nlist).astype("<u8")
-        f.write(struct.pack("<Q", nlist))
-        f.write(sizes.tobytes())
-        for li in range(nlist):
-            ids = np.nonzero(assign == li)[0].astype("<i8")
-            if ids.size:
-                f.write(corpus[ids].tobytes())
-                f.write(ids.tobytes())

@@ -161,6 +161,22 @@ class FlatIPIndex:
             out.append((dev.value, row0.value, rows.value))
         return out
 
+    def exchange_info(self) -> dict:
+        """What the exchange step of a sharded handle does on this node (ls_shard_exchange_info):
+        transport, RCCL version / failure text, enqueue workers, peer-access matrix. {} for a
+        single-device index."""
+        import json
+
+        h = self._ensure_built()
+        lib = native.load()
+        if int(lib.ls_shard_count(h)) == 0:
+            return {}
+        buf = ctypes.create_string_buffer(8192)
+        need = int(lib.ls_shard_exchange_info(h, buf, len(buf)))
+        if need < 0:
+            native.check(need)
+        return json.loads(buf.value.decode())
+
     def add(self, x: np.ndarray) -> None:
         """index.add(x) (reference extract/index.py:116): append float32 rows. On a built index
         the stored rows stay in HBM and only the new ones are uploaded (ls_add)."""

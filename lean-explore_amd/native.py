@@ -45,6 +45,7 @@ SYMBOLS: dict[str, tuple] = {
                                                      _i32]),
     "ls_shard_count": (_i32, [_vp]),
     "ls_shard_info": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_i32), _i64p, _i64p]),
+    "ls_shard_exchange_info": (_i32, [_vp, ctypes.c_char_p, _i32]),
     "ls_add": (ctypes.c_int, [_vp, _vp, _i64]),
     "ls_reconstruct": (ctypes.c_int, [_vp, _i64, _i64, _vp]),
     "ls_destroy": (None, [_vp]),

@@ -41,7 +41,7 @@ class EmbeddingResponse(BaseModel):
 class EmbeddingClient:
     def __init__(self, model_name: str, device: str | None = None, max_length: int | None = None,
                  batch_size: int | None = None, *, model: Any = None, tokenizer: Any = None,
-                 dtype: Any = None, query_prompt: str = QUERY_PROMPT, use_graphs: bool = False, fused_norms: bool = True):
+                 dtype: Any = None, query_prompt: str = QUERY_PROMPT, use_graphs: bool = False, fused_norms: bool = False):
         import torch
 
         self.model_name = model_name

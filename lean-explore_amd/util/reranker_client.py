@@ -41,7 +41,7 @@ class RerankerClient:
                  max_length: int = 512, instruction: str = DEFAULT_INSTRUCTION,
                  batch_size: int | None = None, *, model: Any = None, tokenizer: Any = None,
                  token_true_id: int | None = None, token_false_id: int | None = None,
-                 dtype: Any = None, use_graphs: bool = False, fused_norms: bool = True):
+                 dtype: Any = None, use_graphs: bool = False, fused_norms: bool = False):
         import torch
 
         self.model_name = model_name

@@ -44,3 +44,36 @@ def kat_inputs(seed: int):
     q = np.zeros((1, 768), np.float32)
     q[0, 0] = 1.0
     return emb, q
+
+
+def write_ivf_flat(path, corpus: np.ndarray, assign: np.ndarray, nlist: int) -> None:
+    """Write an ``IwFl`` file with the given row -> list assignment: exercises
+    lean_explore_amd.faiss_compat.read_index on the container layout the reference ships
+    (reference extract/index.py:103-104,173). Not a trained IVF; test infrastructure only."""
+    import struct
+
+    from lean_explore_amd import faiss_compat as fc
+
+    corpus = np.ascontiguousarray(corpus, dtype="<f4")
+    n, d = corpus.shape
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", fc._fourcc("IwFl")))
+        fc._write_header(f, d, n, fc.METRIC_INNER_PRODUCT)
+        f.write(struct.pack("<QQ", nlist, 1))
+        f.write(struct.pack("<I", fc._fourcc("IxFI")))           # quantizer: nlist zero centroids
+        fc._write_header(f, d, nlist, fc.METRIC_INNER_PRODUCT)
+        f.write(struct.pack("<Q", nlist * d))
+        f.write(np.zeros(nlist * d, "<f4").tobytes())
+        f.write(struct.pack("<b", 0))                         # no direct map
+        f.write(struct.pack("<Q", 0))
+        f.write(struct.pack("<I", fc._fourcc("ilar")))
+        f.write(struct.pack("<QQ", nlist, 4 * d))
+        f.write(struct.pack("<I", fc._fourcc("full")))
+        sizes = np.bincount(assign, minlength=nlist).astype("<u8")
+        f.write(struct.pack("<Q", nlist))
+        f.write(sizes.tobytes())
+        for li in range(nlist):
+            ids = np.nonzero(assign == li)[0].astype("<i8")
+            if ids.size:
+                f.write(corpus[ids].tobytes())
+                f.write(ids.tobytes())

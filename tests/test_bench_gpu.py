@@ -62,6 +62,35 @@ def test_gpus_n_in_one_process_through_the_sharded_handle(workload, steps):
     assert "rehearsal" in out and out["devices_seen"] == 1 and out["rccl_ranks_seen"] == 0
 
 
+@pytest.mark.parametrize("workload,steps", [("c2", 24), ("c4", 3)])
+def test_gpus_8_in_library_rehearsal(workload, steps):
+    """The shape of the one-shot 8-GPU run, rehearsed on this box's single GPU: eight shards behind
+    one handle, forced enqueue workers, exchange + merge, the JSON line with the exchange record."""
+    p, out = run_bench(["--gpus", "8", "--workload", workload, "--steps", str(steps), "--warmup", "2",
+                        "--secondary", "none", "--no-host-api", "--no-cpu-baseline",
+                        "--c4-rows", "100000"], {"LS_BENCH_SHARE_GPU": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "row-shard x8"
+    assert out["recall_at_k"] == 1.0 and "rehearsal" in out
+    info = out["exchange_info"]
+    assert len(info["devices"]) == 8 and len(info["peer_access"]) == 8
+    assert "copies" in out["exchange"] and out["rccl_ranks_seen"] == 0
+
+
+def test_gpus_8_torchrun_rehearsal():
+    """The driver's own N = 8 command (`python -m torch.distributed.run --nproc-per-node 8 bench.py
+    --gpus 8`), eight ranks sharing this box's GPU over gloo: c2 as the headline plus the c3 / c4
+    secondaries the default line carries at N > 1 (c4 reduced to 100 k rows per rank)."""
+    p, out = run_bench(["--gpus", "8", "--steps", "16", "--warmup", "4", "--no-host-api",
+                        "--no-cpu-baseline", "--c4-rows", "100000", "--launcher", "torchrun"],
+                       {"LS_BENCH_SHARE_GPU": "1"}, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert out["n_gpus"] == 8 and out["rccl_ranks_seen"] == 8 and "rehearsal" in out
+    assert out["recall_at_k"] == 1.0 and out["config"]["rows_per_gpu"] == 25000
+    assert out["secondary"]["c3"]["recall_at_k"] == 1.0 and out["secondary"]["c4"]["recall_at_k"] == 1.0
+    assert out["secondary"]["c4"]["scaling"] == "weak"
+
+
 def test_refuses_rank_count_it_cannot_run():
     import torch
 

@@ -36,7 +36,7 @@ def test_service_search_drop_in(tmp_path, container):
         faiss_compat.write_index(ix, index_path)
     else:  # the container the reference ships (IVF-flat), searched exactly
         assign = np.random.default_rng(3).integers(0, 256, size=n)
-        faiss_compat.write_ivf_flat_for_tests(index_path, loaded, assign, 256)
+        H.write_ivf_flat(index_path, loaded, assign, 256)
 
     qvec = corpus[123] * 3.0 + 0.01 * H.gauss(5, 1, d)[0]
     hip = S.SearchEngine(base_path=tmp_path, embedding_client=FakeEmbed(qvec), lexical_retriever=False)

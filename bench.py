@@ -332,6 +332,9 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
                                            device=env.device_index, base=lo)
         tq = torch.from_numpy(queries).to(dev)
     index = None if inlib else ShardedFlatIPIndex(local, n)
+    for ov in getattr(env.args, "lib_option", []):
+        which, value = ov.split("=")
+        local.debug_option(int(which), int(value))
     if inlib and env.share_gpu:
         # rehearsal on fewer GPUs than shards: the per-shard enqueue workers are off by default when
         # shards share a device; force them so the real node's host path is what gets rehearsed
@@ -635,6 +638,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--c4-rows", type=int, default=0, help="rows per GPU for c4 (default 12.5M)")
+    ap.add_argument("--lib-option", action="append", default=[], metavar="WHICH=VALUE",
+                    help="developer A/B: ls_debug_option(which, value) on every index the run builds")
     ap.add_argument("--launcher", default="inlib", choices=["inlib", "torchrun"],
                     help="--gpus N without a launcher: 'inlib' = one process drives the N GPUs through "
                          "the library's sharded handle; 'torchrun' = re-execute under "

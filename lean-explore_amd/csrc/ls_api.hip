@@ -217,14 +217,12 @@ void ls_destroy(ls_index* ix) {
     (void)hipFree(ix->d_counters);
     (void)hipFree(ix->d_arrive);
     (void)hipFree(ix->d_qpad);
+    for (hipStream_t cs : {ix->chain_prep, ix->chain_main, ix->chain_sel})
+        if (cs) (void)hipStreamSynchronize(cs);
     for (auto& st : ix->bc_sets) {
-        if (st.lane_stream) {
-            (void)hipStreamSynchronize(st.lane_stream);
-            (void)hipStreamDestroy(st.lane_stream);
-        }
-        if (st.lane_in) (void)hipEventDestroy(st.lane_in);
-        if (st.lane_q) (void)hipEventDestroy(st.lane_q);
-        if (st.lane_out) (void)hipEventDestroy(st.lane_out);
+        if (st.ev_prep) (void)hipEventDestroy(st.ev_prep);
+        if (st.ev_pass) (void)hipEventDestroy(st.ev_pass);
+        if (st.ev_sel) (void)hipEventDestroy(st.ev_sel);
         if (st.done) (void)hipEventDestroy(st.done);
         (void)hipFree(st.d_qh);
         (void)hipFree(st.d_queues);
@@ -240,6 +238,9 @@ void ls_destroy(ls_index* ix) {
     if (ix->h_out_s) (void)hipHostFree(ix->h_out_s);
     if (ix->h_out_i) (void)hipHostFree(ix->h_out_i);
     for (hipEvent_t e : ix->prof_ev) (void)hipEventDestroy(e);
+    for (hipStream_t cs : {ix->chain_prep, ix->chain_main, ix->chain_sel})
+        if (cs) (void)hipStreamDestroy(cs);
+    if (ix->chain_in) (void)hipEventDestroy(ix->chain_in);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     delete ix;
 }
@@ -390,17 +391,19 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         }
         ls_scan_args a{};
         a.nfin = 0;
-        // Ordered (non-pipelined) calls: the selection jobs of THIS group ride on its own scan
-        // launch and wait inside the kernel for the scan workgroups' arrival counter - one launch
-        // per group instead of scan + selection, no kernel boundary in front of the selection.
+        // Synchronous host-API calls (ls_search: the reference's call, search/engine.py:250): the
+        // selection jobs of THIS group ride on its own scan launch and wait inside the kernel for
+        // the scan workgroups' arrival counter - one launch per group instead of scan + selection,
+        // no kernel boundary and no second launch latency in front of the selection. The hand-off
+        // is fence-free (write-through keys, drained, relaxed counter: ls_fin_params::arrive); a job
+        // whose emitted keys cannot be proven complete answers LS_DONE_RETRY in its completion word
+        // and the host launches the stand-alone finalize behind the scan (host_search_locked).
+        // Only on the library's own stream and only with completion words to answer through: a
+        // caller's stream may be CU-masked, and device-output calls have no way to ask for a retry.
         const int own_keys_cap = std::max(256, blocks * kprime);
-        // Every arriving workgroup pays an agent-scope release (an L2 write-back walk, ~0.07 us each,
-        // serialised per XCD): a win for the few workgroups of a small shard (N = 25 k: 32.6 vs
-        // 35.0 us per synchronous call), a loss for big ones (N = 200 k, 448 workgroups: 86 vs 72 us),
-        // so "auto" stops at LS_SAME_LAUNCH_MAX_BLOCKS.
         const bool same_launch =
-            !pipeline && ix->n > 0 &&
-            (ix->opt_same_launch == 2 || (ix->opt_same_launch == 1 && blocks <= LS_SAME_LAUNCH_MAX_BLOCKS)) &&
+            !pipeline && ix->n > 0 && ix->opt_same_launch != 0 && ix->done_base != nullptr &&
+            s == ix->own_stream &&
             ls_fin_lds_bytes_host(own_keys_cap, (int)std::max<int64_t>(keff, 1)) <= LS_PIGGY_LDS_MAX;
         if (ix->n_pending && same_launch) {  // left by an earlier pipelined call: its own launch
             rc = ls_i_flush_pending(ix);
@@ -440,13 +443,15 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         a.blocks = blocks;
         a.kprime = kprime;
         ls_fin_batch& jobs = same_launch ? a.fin : ix->pending;
+        // the device counter only moves when a launch runs: the host mirror follows it AFTER the
+        // launch call succeeded (a failed launch must not leave the target ahead of the counter)
+        const u32 arrive_target = ix->arrive_count + (u32)blocks;
         if (same_launch) {
             if (!ix->d_arrive) {
                 LS_HIP(hipMalloc((void**)&ix->d_arrive, sizeof(u32)));
                 LS_HIP(hipMemsetAsync(ix->d_arrive, 0, sizeof(u32), s));
                 ix->arrive_count = 0;
             }
-            ix->arrive_count += (u32)blocks;
             a.nfin = real;
             a.arrive = ix->d_arrive;
         }
@@ -468,11 +473,13 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             p.done = ix->done_base ? ix->done_base + (q0 + i) : nullptr;
             p.done_val = ix->done_seq;
             p.arrive = same_launch ? ix->d_arrive : nullptr;
-            p.arrive_target = ix->arrive_count;
+            p.arrive_target = same_launch ? ix->arrive_count + (u32)blocks : 0u;
+            if (same_launch) ix->retry_jobs.push_back(p);  // kept until the host has seen the answers
         }
         if (prof) LS_HIP(hipEventRecord(pe[0], s));
         rc = ls_launch_scan(ix->d_corpus, ix->n, g, a, s);
         if (rc != LS_OK) return rc;
+        if (same_launch) ix->arrive_count = arrive_target;
         ix->n_launches_total++;
         if (prof) {
             LS_HIP(hipEventRecord(pe[1], s));
@@ -502,6 +509,7 @@ bool ls_i_batched_eligible(const ls_index* ix, int64_t nq, int32_t k) {
 // Re-run the queries of the pending batched calls whose candidate queues overflowed (or were
 // short) through the exact per-query scan path, from the calls' OWN query copies. Synchronises.
 int ls_i_batched_repair(ls_index* ix) {
+    if (int rc = ls_i_flush_deferred(ix)) return rc;
     if (ix->bc_pending.empty()) return LS_OK;
     std::vector<ls_index::batched_call> pend;
     pend.swap(ix->bc_pending);
@@ -631,6 +639,117 @@ static int64_t bc_chunk(const ls_index* ix, int64_t nq, int32_t k) {
     return 0;
 }
 
+// ---- one batched call ------------------------------------------------------------------------------
+// Kernels of a batch: query prep -> sample pass -> tau -> MFMA pass -> select. Plain calls queue all
+// of it on the caller's stream.
+//
+// LS_FLAG_PIPELINE calls go through the handle's three-stream CHAIN (round 4):
+//   prep stream   : prep(i)            behind the caller's stream (chain_in) and behind the previous
+//                                      readers of the scratch set's prepared queries; a one-wave,
+//                                      37-register kernel that runs INSIDE whatever pass is resident
+//   main stream   : ... pass(i-1)+sample(i) -> tau(i) -> pass(i)+sample(i+1) -> tau(i+1) ...
+//                                      The sample phase of batch i rides at the end of pass i-1's
+//                                      launch (LS_GEMM_FUSED): between two passes remain the tau kernel
+//                                      and two kernel boundaries. For that, batch i's pass is queued
+//                                      when call i+1 arrives (or at the next flush: ls_check, a call
+//                                      of another shape, ls_export_flags, ls_add ...): results of
+//                                      pipelined calls are defined to be valid after ls_check anyway.
+//                                      The main stream waits for prep(i+1) and select(i-2): events that
+//                                      completed long before (a wait on such an event costs nothing)
+//   select stream : select(i)          behind pass(i): the one-wave select kernel (<= 48 VGPRs,
+//                                      ls_wsel.hip) runs INSIDE pass(i+1), in the registers and LDS
+//                                      the pass leaves free, instead of between two passes
+// An event that the critical stream's successor waits for is attached to the dispatch itself
+// (hipExtLaunchKernelGGL): no extra packet between two passes (tools/coresidency_probe.hip: 101.2
+// us per 100 us kernel with or without, 104.3 with hipEventRecord). Cross-stream dependencies take
+// ~15 us to resolve on this runtime (tools/c3_timeline.sh), which is why none of them sits between
+// two passes. Four scratch sets rotate (LS_BC_LANES). Round 3 rotated whole batches over two "lanes": every
+// batch's sample pass, tau kernel and select then sat between two MFMA passes (~25 us).
+static int bc_launch_select(ls_index* ix, const ls_index::bc_stage& b, hipStream_t ss) {
+    ls_index::bc_set& st = ix->bc_sets[b.set_id];
+    ls_gemm_bufs bufs;
+    bufs.d_queues = st.d_queues;
+    bufs.d_counts = st.d_counts;
+    bufs.d_overflow = b.d_flags;
+    bufs.d_sample_top = st.d_sample_top;
+    if (ix->opt_wave_select && !b.f32 && ls_wave_select_ok(b.nsplits, b.k, b.keys_need))
+        return ls_launch_wave_select(bufs, b.nsplits, b.nq, b.k, ix->base, ix->n, b.rps, b.d_out_s,
+                                     b.d_out_i, ss, nullptr);
+    return ls_launch_batch_select(bufs, b.nsplits, b.nq, b.k, b.keys_need, ix->base, ix->n, b.rps,
+                                  b.d_out_s, b.d_out_i, ss);
+}
+
+// Queue the MFMA pass and the select of batch `b` (its sample pass and tau are already queued on
+// `sm`). `next` non-null: the pass launch also runs the sample phase of that batch (same plan).
+static int bc_launch_pass_select(ls_index* ix, const ls_index::bc_stage& b, const ls_index::bc_stage* next,
+                                 hipStream_t sm, hipStream_t ss, bool chain) {
+    ls_index::bc_set& st = ix->bc_sets[b.set_id];
+    const ls_geom& g = ix->g;
+    int rc;
+    ls_gemm_bufs bufs;
+    bufs.d_queues = st.d_queues;
+    bufs.d_counts = st.d_counts;
+    bufs.d_overflow = b.d_flags;
+    bufs.d_sample_top = st.d_sample_top;
+    const bool prof = ix->profiling && ix->prof_n < LS_PROF_MAX;
+    hipEvent_t* pe = nullptr;
+    if (prof) {
+        while (ix->prof_ev.size() < 2 * (ix->prof_n + 1)) {
+            hipEvent_t e;
+            LS_HIP(hipEventCreate(&e));
+            ix->prof_ev.push_back(e);
+        }
+        pe = &ix->prof_ev[2 * ix->prof_n];
+    }
+    // the pass's events ride on its dispatch: completion for the select stream, and - while
+    // profiling - a timing pair that brackets exactly the kernel
+    hipEvent_t const ev_start = prof ? pe[0] : nullptr;
+    hipEvent_t const ev_stop = prof ? pe[1] : (chain ? st.ev_pass : nullptr);
+    // the set's previous select has read the queues this pass refills
+    if (chain && st.sel_recorded && !(ix->opt_chain_abl & 1)) LS_HIP(hipStreamWaitEvent(sm, st.ev_sel, 0));
+    if (b.f32) {
+        rc = ls_launch_gemm32_filter(ix->d_corpus, ix->n, g, (const float*)st.d_qh, b.nq, b.nq_pad,
+                                     st.d_tau, b.nsplits, b.rps, 1, bufs, sm, ev_start, ev_stop);
+    } else if (next) {
+        ls_index::bc_set& sn = ix->bc_sets[next->set_id];
+        ls_gemm_fuse fz;
+        fz.d_qh_next = sn.d_qh;
+        fz.nq_next = next->nq;
+        fz.d_sample_top_next = sn.d_sample_top;
+        fz.sample_stride = next->sample_stride;
+        rc = ls_launch_gemm_filter(ix->d_corpus, ix->n, g, st.d_qh, b.nq, b.nq_pad, st.d_tau, b.nsplits,
+                                   b.rps, 1, bufs, b.top2, sm, &fz, ev_start, ev_stop);
+    } else {
+        rc = ls_launch_gemm_filter(ix->d_corpus, ix->n, g, st.d_qh, b.nq, b.nq_pad, st.d_tau, b.nsplits,
+                                   b.rps, 1, bufs, b.top2, sm, nullptr, ev_start, ev_stop);
+    }
+    if (rc != LS_OK) return rc;
+    ix->n_launches_total++;
+    if (prof) {
+        if (chain) LS_HIP(hipEventRecord(st.ev_pass, sm));  // (profiling pass only: its own packet)
+        ix->prof_n++;
+    }
+    if (chain) {
+        st.pass_recorded = true;
+        LS_HIP(hipStreamWaitEvent(ss, st.ev_pass, 0));
+    }
+    if ((rc = bc_launch_select(ix, b, ss)) != LS_OK) return rc;
+    ix->n_launches_total++;
+    if (chain) {
+        LS_HIP(hipEventRecord(st.ev_sel, ss));
+        st.sel_recorded = true;
+    }
+    if (st.multi_stream) LS_HIP(hipEventRecord(st.done, ss));
+    return LS_OK;
+}
+
+// The pipelined batch whose pass is still held back (see above): queue its pass and select now.
+int ls_i_flush_deferred(ls_index* ix) {
+    if (!ix->defer.active) return LS_OK;
+    ix->defer.active = false;
+    return bc_launch_pass_select(ix, ix->defer, nullptr, ix->chain_main, ix->chain_sel, true);
+}
+
 static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k,
                                     uint32_t flags, float* d_out_s, int64_t* d_out_i,
                                     hipStream_t s) {
@@ -648,20 +767,36 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         rc = ls_i_batched_repair(ix);  // slots exhausted (or too small): check what is pending
         if (rc != LS_OK) return rc;
     }
-    const bool lanes = (flags & LS_FLAG_PIPELINE) != 0;
-    const int set_id = lanes ? 1 + (int)(ix->bc_lane_rr++ % LS_BC_LANES) : 0;
+    const bool chain = (flags & LS_FLAG_PIPELINE) != 0;
+    if (!chain && (rc = ls_i_flush_deferred(ix)) != LS_OK) return rc;
+    const int set_id = chain ? 1 + (int)(ix->bc_lane_rr++ % LS_BC_LANES) : 0;
     ls_index::bc_set& st = ix->bc_sets[set_id];
     hipStream_t const caller = s;
-    if (lanes) {
-        // the lane's kernels run behind everything the caller has queued so far (its queries)
-        if (!st.lane_stream) {
-            LS_HIP(hipStreamCreateWithFlags(&st.lane_stream, hipStreamNonBlocking));
-            LS_HIP(hipEventCreateWithFlags(&st.lane_in, hipEventDisableTiming));
-            LS_HIP(hipEventCreateWithFlags(&st.lane_q, hipEventDisableTiming));
+    hipStream_t sp = s, sm = s, ss = s;  // prep / sample, tau, pass / select
+    if (chain) {
+        if (!ix->chain_prep) {
+            // Three streams that must NOT share a hardware queue: the runtime multiplexes a process's
+            // streams over four queues per priority class in creation order, and two of the chain's
+            // streams on one queue run in submission order - select(i), which waits for pass(i), then
+            // holds back tau(i+1) and pass(i+1) behind it (seen in a kernel trace: main and select
+            // stream both on queue 4, 76 us between two passes). One stream per priority class gets
+            // each its own queue, and the order is the useful one: passes first, selects last.
+            int least = 0, greatest = 0;
+            LS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            LS_HIP(hipStreamCreateWithPriority(&ix->chain_main, hipStreamNonBlocking, greatest));
+            LS_HIP(hipStreamCreateWithPriority(&ix->chain_prep, hipStreamNonBlocking,
+                                               (least + greatest) / 2));
+            LS_HIP(hipStreamCreateWithPriority(&ix->chain_sel, hipStreamNonBlocking, least));
+            LS_HIP(hipEventCreateWithFlags(&ix->chain_in, hipEventDisableTiming));
         }
-        LS_HIP(hipEventRecord(st.lane_in, caller));
-        LS_HIP(hipStreamWaitEvent(st.lane_stream, st.lane_in, 0));
-        s = st.lane_stream;
+        if (!st.ev_prep) {
+            LS_HIP(hipEventCreateWithFlags(&st.ev_prep, hipEventDisableTiming));
+            LS_HIP(hipEventCreateWithFlags(&st.ev_pass, hipEventDisableTiming));
+            LS_HIP(hipEventCreateWithFlags(&st.ev_sel, hipEventDisableTiming));
+        }
+        sp = ix->chain_prep;
+        sm = ix->chain_main;
+        ss = ix->chain_sel;
     } else if (st.used && st.last_stream != s) {
         // set 0 is shared by plain calls: a call on another stream waits for the previous one
         if (!st.multi_stream) {
@@ -673,11 +808,10 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         }
     }
     const bc_plan plan = bc_make_plan(ix, nq, k);
-    const int nsplits = plan.nsplits, sample_stride = plan.sample_stride, jrank = plan.jrank;
-    const int keys_need = plan.keys_need;
-    const int64_t rps = plan.rps;
+    const int nsplits = plan.nsplits;
     const size_t nrec = (size_t)nq_pad * nsplits;
 
+    // (growing a buffer frees it first: hipFree drains the device, whatever stream still uses it)
     size_t c;
     c = st.qh_cap;
     if ((rc = ls_grow((unsigned char**)&st.d_qh, &c, (size_t)nq_pad * g.d_pad * (f32 ? 4 : 2))) != LS_OK)
@@ -703,68 +837,93 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     if ((rc = ls_grow_pinned(&ix->h_overflow, &ix->h_overflow_cap,
                           (size_t)ix->bc_slot_stride * LS_BC_SLOTS)) != LS_OK)
         return rc;
+
+    ls_index::bc_stage b;
+    b.active = true;
+    b.set_id = set_id;
+    b.f32 = f32;
+    b.nq = nq;
+    b.nq_pad = nq_pad;
+    b.k = k;
+    b.nsplits = nsplits;
+    b.sample_stride = plan.sample_stride;
+    b.jrank = plan.jrank;
+    b.keys_need = plan.keys_need;
+    b.rps = plan.rps;
+    // two kept sample scores per lane are enough when a query has >= 4 j lanes (two of its best
+    // j sample scores then share a lane with probability ~1/8 each)
+    b.top2 = LS_GEMM_SAMPLE_TOP2 && (long long)nsplits * 4 >= 4ll * plan.jrank;
+    b.d_flags = d_flags;
+    b.d_out_s = d_out_s;
+    b.d_out_i = d_out_i;
     ls_gemm_bufs bufs;
     bufs.d_queues = st.d_queues;
     bufs.d_counts = st.d_counts;
     bufs.d_overflow = d_flags;
     bufs.d_sample_top = st.d_sample_top;
 
-    const bool prof = ix->profiling && ix->prof_n < LS_PROF_MAX;
-    hipEvent_t* pe = nullptr;
-    if (prof) {
-        while (ix->prof_ev.size() < 2 * (ix->prof_n + 1)) {
-            hipEvent_t e;
-            LS_HIP(hipEventCreate(&e));
-            ix->prof_ev.push_back(e);
-        }
-        pe = &ix->prof_ev[2 * ix->prof_n];
+    // ---- prep -------------------------------------------------------------------------------------
+    if (chain) {
+        // behind everything the caller has queued so far (its queries) ...
+        LS_HIP(hipEventRecord(ix->chain_in, caller));
+        LS_HIP(hipStreamWaitEvent(sp, ix->chain_in, 0));
+        // ... and behind the passes that read the set's prepared queries: the set's own previous
+        // pass (four batches ago), and - its fused sample phase - the pass queued just before that
+        // one on the same stream. The held-back batch's pass is not queued yet; it reads another set.
+        if (st.pass_recorded) LS_HIP(hipStreamWaitEvent(sp, st.ev_pass, 0));
     }
-    // two kept sample scores per lane are enough when a query has >= 4 j lanes (two of its best
-    // j sample scores then share a lane with probability ~1/8 each)
-    const bool top2 = LS_GEMM_SAMPLE_TOP2 && (long long)nsplits * 4 >= 4ll * jrank;
-    auto pass = [&](const float* tau, int stride) {  // sample pass (tau == null) or full pass
-        return f32 ? ls_launch_gemm32_filter(ix->d_corpus, ix->n, g, (const float*)st.d_qh, nq,
-                                             nq_pad, tau, nsplits, rps, stride, bufs, s)
-                   : ls_launch_gemm_filter(ix->d_corpus, ix->n, g, st.d_qh, nq, nq_pad, tau,
-                                           nsplits, rps, stride, bufs, top2, s);
-    };
     rc = f32 ? ls_launch_prep_f32(d_q, (float*)st.d_qh, d_qkeep, nq, nq_pad, g,
-                                  (flags & LS_FLAG_NORMALIZE) != 0, d_flags, s)
+                                  (flags & LS_FLAG_NORMALIZE) != 0, d_flags, sp)
              : ls_launch_prep_f16(d_q, st.d_qh, d_qkeep, nq, nq_pad, g,
-                                  (flags & LS_FLAG_NORMALIZE) != 0, d_flags, s);
+                                  (flags & LS_FLAG_NORMALIZE) != 0, d_flags, sp);
     if (rc != LS_OK) return rc;
     int launches = 1;  // counted, not assumed: debug counter 9
-    if (lanes) {
+    if (chain) {
         // the prep kernel was the only reader of the caller's query buffer (it also took the
         // repair copy): work the caller queues on its stream from here on may overwrite it
-        LS_HIP(hipEventRecord(st.lane_q, s));
-        LS_HIP(hipStreamWaitEvent(caller, st.lane_q, 0));
+        LS_HIP(hipEventRecord(st.ev_prep, sp));
+        LS_HIP(hipStreamWaitEvent(caller, st.ev_prep, 0));
+        if (!(ix->opt_chain_abl & 2)) LS_HIP(hipStreamWaitEvent(sm, st.ev_prep, 0));
     }
-    // sample pass: a few tiles of every slice, spread over the slice
-    rc = pass(nullptr, sample_stride);
-    if (rc != LS_OK) return rc;
-    ++launches;
-    rc = ls_launch_tau(st.d_sample_top, nsplits, nq, nq_pad, jrank, st.d_tau, s);
-    if (rc != LS_OK) return rc;
-    ++launches;
-    // full pass
-    if (prof) LS_HIP(hipEventRecord(pe[0], s));
-    rc = pass(st.d_tau, 1);
-    if (rc != LS_OK) return rc;
-    ++launches;
-    if (prof) {
-        LS_HIP(hipEventRecord(pe[1], s));
-        ix->prof_n++;
+    // ---- sample pass: a few tiles of every slice, spread over the slice ------------------------------
+    // Pipelined fp16 batches of one plan: the sample phase rides on the held-back batch's pass launch
+    // (the register-starved geometries - config 4's 1.5 KiB rows - spend ~1 % of a multi-millisecond
+    // batch between passes and keep their own sample launch)
+    const bool fuse_ok = chain && !f32 && (ix->opt_fused == 2 || (ix->opt_fused == 1 && g.chunks <= 48));
+    const ls_index::bc_stage& d = ix->defer;
+    const bool ride = fuse_ok && d.active && !d.f32 && d.nq_pad == nq_pad && d.k == k &&
+                      d.nsplits == nsplits && d.rps == b.rps && d.sample_stride == b.sample_stride &&
+                      d.jrank == b.jrank && d.top2 == b.top2 && d.set_id != set_id;
+    if (ride) {
+        ix->defer.active = false;
+        if ((rc = bc_launch_pass_select(ix, d, &b, sm, ss, true)) != LS_OK) return rc;
+    } else {
+        if ((rc = ls_i_flush_deferred(ix)) != LS_OK) return rc;
+        rc = f32 ? ls_launch_gemm32_filter(ix->d_corpus, ix->n, g, (const float*)st.d_qh, nq, nq_pad,
+                                           nullptr, nsplits, b.rps, b.sample_stride, bufs, sm)
+                 : ls_launch_gemm_filter(ix->d_corpus, ix->n, g, st.d_qh, nq, nq_pad, nullptr, nsplits,
+                                         b.rps, b.sample_stride, bufs, b.top2, sm);
+        if (rc != LS_OK) return rc;
+        ++launches;
     }
-    rc = ls_launch_batch_select(bufs, nsplits, nq, k, keys_need, ix->base, ix->n, rps, d_out_s, d_out_i,
-                                s);
-    if (rc != LS_OK) return rc;
+    if ((rc = ls_launch_tau(st.d_sample_top, nsplits, nq, nq_pad, b.jrank, st.d_tau, sm)) != LS_OK)
+        return rc;
     ++launches;
-    if (st.multi_stream) LS_HIP(hipEventRecord(st.done, s));
+    // ---- pass + select: now, or (pipelined fp16 batches) with the next call / the next flush ---------
+    const bool hold = fuse_ok;
+    if (hold) {
+        ix->defer = b;
+    } else {
+        const uint64_t before = ix->n_launches_total;
+        if ((rc = bc_launch_pass_select(ix, b, nullptr, sm, ss, chain)) != LS_OK) return rc;
+        launches += (int)(ix->n_launches_total - before);
+        ix->n_launches_total = before;
+    }
     st.used = true;
-    st.last_stream = s;
+    st.chain = chain;
+    st.last_stream = ss;
     ix->bc_last_set = set_id;
-    ix->n_batched_launches = launches;
+    ix->n_batched_launches = launches + (hold ? 2 : 0);  // (a held-back batch: its pass and select follow)
     ix->n_launches_total += (uint64_t)launches;
     ix->last_path = f32 ? 3 : 2;
     ix->d_last_flags = d_flags;
@@ -775,7 +934,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     bc.flags = flags;
     bc.d_out_s = d_out_s;
     bc.d_out_i = d_out_i;
-    bc.stream = s;
+    bc.stream = ss;
     bc.slot = slot;
     ix->bc_pending.push_back(bc);
     if (!(flags & (LS_FLAG_ASYNC | LS_FLAG_PIPELINE))) return ls_i_batched_repair(ix);
@@ -878,8 +1037,9 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
     memcpy(ix->h_q, q, qn * sizeof(float));
     if (!in_direct)
         LS_HIP(hipMemcpyAsync(ix->d_qraw, ix->h_q, qn * sizeof(float), hipMemcpyHostToDevice, s));
+    ix->retry_jobs.clear();
     if (spin) {
-        if (++ix->done_seq == 0) ix->done_seq = 1;
+        if (++ix->done_seq >= LS_DONE_RETRY) ix->done_seq = 1;  // the top bit is the retry answer
         ix->done_base = ix->h_done;
     }
     rc = ls_i_search_on_stream(ix, in_direct ? ix->h_q : ix->d_qraw, nq, k, flags & LS_FLAG_NORMALIZE,
@@ -891,22 +1051,67 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
         LS_HIP(hipMemcpyAsync(ix->h_out_s, ix->d_out_s, on * sizeof(float), hipMemcpyDeviceToHost, s));
         LS_HIP(hipMemcpyAsync(ix->h_out_i, ix->d_out_i, on * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     }
-    bool done = false;
-    if (spin) {
+    // spin until every completion word is final (the call's sequence number, or - if accepted -
+    // the retry answer); gives up after 2 ms and lets the caller sleep in hipStreamSynchronize
+    auto wait_words = [&](bool accept_retry, bool* retry) -> bool {
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned it = 0;; ++it) {
+            bool any_retry = false;
             int64_t i = 0;
-            while (i < nq && __atomic_load_n(&ix->h_done[i], __ATOMIC_ACQUIRE) == ix->done_seq) ++i;
-            if (i == nq) {
-                done = true;
+            for (; i < nq; ++i) {
+                const u32 w = __atomic_load_n(&ix->h_done[i], __ATOMIC_ACQUIRE);
+                if (w == ix->done_seq) continue;
+                if (accept_retry && w == (ix->done_seq | LS_DONE_RETRY)) {
+                    any_retry = true;
+                    continue;
+                }
                 break;
+            }
+            if (i == nq) {
+                if (retry) *retry = any_retry;
+                return true;
             }
             _mm_pause();
             if ((it & 1023) == 1023 &&
                 std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
-                break;
+                return false;
+        }
+    };
+    bool done = false;
+    if (spin) {
+        bool retry = false;
+        done = wait_words(true, &retry);
+        if (!done) {  // slow launch: sleep until the stream has drained, then every word is final
+            LS_HIP(hipStreamSynchronize(s));
+            done = wait_words(true, &retry);
+        }
+        if (done && retry) {
+            // Same-launch selection jobs that could not prove their emitted keys complete (clustered
+            // rows, ties) or gave up waiting: the stand-alone finalize behind the scan - the kernel
+            // boundary makes the score vector visible - answering through the same completion words.
+            ls_fin_batch jobs{};
+            int nj = 0;
+            auto flush = [&]() -> int {
+                if (!nj) return LS_OK;
+                const int r = ls_launch_finalize(jobs, nj, s);
+                ix->n_launches_total++;
+                nj = 0;
+                return r;
+            };
+            for (const ls_fin_params& p : ix->retry_jobs) {
+                const int64_t qi = p.done - ix->h_done;
+                if (qi < 0 || qi >= nq || ix->h_done[qi] != (ix->done_seq | LS_DONE_RETRY)) continue;
+                jobs.p[nj] = p;
+                jobs.p[nj].arrive = nullptr;
+                jobs.p[nj].keys_cap = LS_FINAL_CAP;
+                if (++nj == LS_QUERIES_PER_LAUNCH_MAX && (rc = flush()) != LS_OK) return rc;
+            }
+            if ((rc = flush()) != LS_OK) return rc;
+            ix->n_same_launch_retries++;
+            done = wait_words(false, nullptr);
         }
     }
+    ix->retry_jobs.clear();
     if (!done) LS_HIP(hipStreamSynchronize(s));
     memcpy(out_scores, ix->h_out_s, on * sizeof(float));
     memcpy(out_indices, ix->h_out_i, on * sizeof(int64_t));
@@ -1190,14 +1395,13 @@ int ls_export_flags(ls_index* ix, void* d_dst, int64_t nq, void* stream) {
 }  // extern "C"
 
 int ls_i_export_flags(ls_index* ix, void* d_dst, int64_t nq, hipStream_t s) {
+    if (int rc = ls_i_flush_deferred(ix)) return rc;  // the flags are final behind the batch's select
     if (ix->d_last_flags && ix->last_flags_n == nq) {
         ls_index::bc_set& st = ix->bc_sets[ix->bc_last_set];
-        if (st.last_stream != s) {  // flags are written on the search's stream (or lane)
-            if (st.lane_stream) {
-                // a lane is the library's own stream: order `s` behind it with an event
-                if (!st.lane_out) LS_HIP(hipEventCreateWithFlags(&st.lane_out, hipEventDisableTiming));
-                LS_HIP(hipEventRecord(st.lane_out, st.lane_stream));
-                LS_HIP(hipStreamWaitEvent(s, st.lane_out, 0));
+        if (st.last_stream != s) {  // flags are final on the stream the select ran on
+            if (st.chain) {
+                // the chain's select stream is the library's own: order `s` behind the set's select
+                LS_HIP(hipStreamWaitEvent(s, st.ev_sel, 0));
             } else if (st.multi_stream) {
                 LS_HIP(hipStreamWaitEvent(s, st.done, 0));
             } else {
@@ -1294,8 +1498,20 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->opt_kprime = value;
         return LS_OK;
     }
-    if (which == 9) {  // ordered calls: selection inside the scan launch of its own query
-        ix->opt_same_launch = value < 0 ? 0 : (value > 2 ? 2 : value);  // 0 never, 1 auto (default), 2 always
+    if (which == 13) {  // fused filter launch (sample phase + tau + MFMA pass): 0 off, 1 where it pays (default), 2 always
+        ix->opt_fused = value < 0 ? 0 : (value > 2 ? 2 : value);
+        return LS_OK;
+    }
+    if (which == 15) {  // timing ablation (results may be wrong): bit 0 / 1 drop the main stream's waits for select / prep
+        ix->opt_chain_abl = value;
+        return LS_OK;
+    }
+    if (which == 14) {  // one-wave select kernel (co-resident with a running pass): default on
+        ix->opt_wave_select = value != 0;
+        return LS_OK;
+    }
+    if (which == 9) {  // synchronous host calls: selection inside the scan launch of its own query (default on)
+        ix->opt_same_launch = value != 0;
         return LS_OK;
     }
     if (which == 7) {  // force the number of scan workgroups per launch (0 = automatic)
@@ -1370,7 +1586,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 19) return -1;
+    if (!ix || which < 0 || which > 20) return -1;
     if (which == 16 || which == 17) {
         std::lock_guard<std::mutex> ql(ix->q_mu);
         return (int64_t)(which == 16 ? ix->n_combined_batches : ix->n_combined_requests);
@@ -1382,6 +1598,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
     if (which == 10) return (int64_t)ix->last_path;
     if (which == 11) return (int64_t)ix->n_launches_total;
     if (which == 12) return (int64_t)ix->n_chunked_calls;
+    if (which == 20) return (int64_t)ix->n_same_launch_retries;
     if (which > 9) return 0;  // 13..15, 18 and 19 are group counters
     if (hipSetDevice(ix->device) != hipSuccess) return -1;
     u32 v = 0;

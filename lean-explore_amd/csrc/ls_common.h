@@ -28,7 +28,6 @@ typedef unsigned int u32;
 #define LS_FINAL_THREADS 1024
 #define LS_FINAL_CAP 8192            // keys the finalize workgroup sorts in LDS (64 KiB)
 #define LS_SCAN_PATH_MAX_NQ 16            // nq <= this: per-query HBM-bound scan path
-#define LS_SAME_LAUNCH_MAX_BLOCKS 200 // ordered calls with at most this many scan workgroups select inside the scan launch
 #ifndef LS_SCAN_MQ_SCATTER
 #define LS_SCAN_MQ_SCATTER 1          // multi-query scan launches: reduce-scatter of the partial sums (0: one butterfly per pair)
 #endif
@@ -86,6 +85,9 @@ typedef unsigned int u32;
 #endif
 #ifndef LS_GEMM_SAMPLE_TOP2
 #define LS_GEMM_SAMPLE_TOP2 1        // 0: the sample pass always keeps four scores per lane
+#endif
+#ifndef LS_GEMM_APPEND_SC1
+#define LS_GEMM_APPEND_SC1 0         // 1: candidate appends written through (sc1) instead of left dirty in L2
 #endif
 #ifndef LS_GEMM_RING3
 #define LS_GEMM_RING3 0              // 1: three tile buffers, DMA two tiles ahead (measured 1-2 % slower than two)
@@ -183,13 +185,20 @@ struct ls_fin_params {
     u32* counters;         // [0] left the fast path, [1] took the general path
     u32* done;             // optional: pinned host word that receives done_val once the outputs
     u32 done_val;          //           are visible to the host (the host API spins on it)
-    // Same-launch selection: the job rides on the scan launch of ITS OWN query and must wait for
-    // that launch's scan workgroups: it starts once *arrive has reached arrive_target (the scan
-    // workgroups add 1 each after releasing their stores at agent scope). Null: the candidates
-    // were written by an earlier launch (stream order), nothing to wait for.
+    // Same-launch selection (synchronous host API only): the job rides on the scan launch of ITS
+    // OWN query and waits until *arrive has reached arrive_target. The scan workgroups publish
+    // their k' keys + bound with write-through (sc1) stores, drain them (s_waitcnt vmcnt(0)) and
+    // add 1 - no release fence: nothing else has to become visible, because the score vector S is
+    // NOT part of the hand-off (plain stores, possibly still dirty in another XCD's L2). If the
+    // emitted keys cannot be proven complete (or the wait times out), the job does not fall back
+    // to S inside the launch: it publishes done_val | LS_DONE_RETRY and the host launches the
+    // stand-alone finalize behind the scan (a kernel boundary makes S visible). Null: the
+    // candidates were written by an earlier launch (stream order), nothing to wait for.
     u32* arrive;
     u32 arrive_target;
 };
+#define LS_DONE_RETRY 0x80000000u        // completion word: "run the stand-alone finalize for this query"
+#define LS_ARRIVE_TIMEOUT_TICKS 20000000ull  // 200 ms of the 100 MHz clock: give up waiting, ask for a retry
 #define LS_QUERIES_PER_LAUNCH_MAX 8
 struct ls_fin_batch {
     ls_fin_params p[LS_QUERIES_PER_LAUNCH_MAX];
@@ -242,10 +251,19 @@ struct ls_gemm_bufs {
 };
 int ls_launch_prep_f16(const float* d_q, void* d_qh, float* d_qkeep, int64_t nq, int64_t nq_pad,
                        const ls_geom& g, bool normalize, u32* d_overflow, hipStream_t s);
+// a fused launch (this batch's full pass, then the NEXT batch's sample phase; ls_gemm.hip) also needs:
+struct ls_gemm_fuse {
+    const void* d_qh_next;     // the next batch's prepared queries (same plan as this batch)
+    int64_t nq_next;
+    u32* d_sample_top_next;    // where the next batch's sample scores go
+    int sample_stride;
+};
+
 int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, const void* d_qh,
                           int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
                           int64_t rows_per_split, int tile_stride, const ls_gemm_bufs& b,
-                          bool sample_top2, hipStream_t s);
+                          bool sample_top2, hipStream_t s, const ls_gemm_fuse* fz = nullptr,
+                          hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_pad, int j_rank,
                   float* d_tau, hipStream_t s);
 #ifdef LS_GEMM_TIMING
@@ -258,13 +276,19 @@ int ls_launch_batch_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k
                            int64_t base,
                            int64_t n, int64_t rows_per_split, float* d_out_scores,
                            int64_t* d_out_indices, hipStream_t s);
+// one wave per query in <= 48 VGPRs (ls_wsel.hip): co-resident with a running MFMA pass. `done_event`
+// (may be null) is attached to the dispatch itself (no extra packet on the stream).
+bool ls_wave_select_ok(int nsplits, int k, int keys_need);
+int ls_launch_wave_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k, int64_t base, int64_t n,
+                          int64_t rows_per_split, float* d_out_scores, int64_t* d_out_indices,
+                          hipStream_t s, hipEvent_t done_event);
 // fp32 batched path (ls_gemm32.hip): exact f32 MFMA, shares tau / select with the fp16 path
 int ls_launch_prep_f32(const float* d_q, float* d_qp, float* d_qkeep, int64_t nq, int64_t nq_pad,
                        const ls_geom& g, bool normalize, u32* d_overflow, hipStream_t s);
 int ls_launch_gemm32_filter(const void* d_corpus, int64_t n, const ls_geom& g, const float* d_qp,
                             int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
                             int64_t rows_per_split, int tile_stride, const ls_gemm_bufs& b,
-                            hipStream_t s);
+                            hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // merge of per-shard lists
 int ls_launch_merge(const float* d_scores_in, const int64_t* d_indices_in, int64_t stride_s_bytes,
                     int64_t stride_i_bytes, int32_t n_lists, int64_t nq, int32_t k,

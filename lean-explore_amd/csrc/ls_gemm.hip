@@ -34,6 +34,8 @@
 // path, so the result is always exact.
 #include "ls_select_dev.h"
 
+#include <hip/hip_ext.h>
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -47,8 +49,13 @@ int ls_gemm_read_sample_stamps(unsigned long long* out, int count) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sample_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : -1;
 }
 #define LS_SSTAMP_S(i) do { if (SAMPLE && tid == 0 && blockIdx.x < 1024) g_sample_stamps[blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
+// fused launches: 8 stamp slots per workgroup (0 start, 2 full pass done, 7 end)
+#define LS_SSTAMP_F(i) do { if (FUSED && tid == 0 && blockIdx.x < 512) g_sample_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define LS_SSTAMP_F2(i) do { if (FUSED && tid == 0 && blockIdx.x < 256) g_sample_stamps[2048 + blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define LS_SSTAMP_S(i) do {} while (0)
+#define LS_SSTAMP_F(i) do {} while (0)
+#define LS_SSTAMP_F2(i) do {} while (0)
 #endif
 
 // ---- static geometry of one instantiation ------------------------------------------------------
@@ -59,6 +66,11 @@ __host__ __device__ constexpr int gemm_tile_bytes(int chunks) { return gemm_tm(c
 __host__ __device__ constexpr int gemm_nbuf(int chunks) {
     return (LS_GEMM_RING3 && 3 * gemm_tile_bytes(chunks) <= LS_GEMM_LDS_BYTES) ? 3 : 2;
 }
+
+// Register budget (a build-time fact, checked by tests/test_abi.py): the full pass and the fused
+// launch of the two-accumulator geometries (rows <= 768 bytes) need <= 232 registers, so two waves per
+// SIMD leave 48 of its 512 for a third, small wave - the one-wave select kernel (ls_wsel.hip) then
+// runs INSIDE a resident pass (tools/coresidency_probe.hip).
 
 // ---- queries -> fp16 MFMA B fragments, normalised if asked, zero padded ---------------------------
 // Output layout = the order in which ls_gemm_filter_kernel consumes it: the 16-byte chunk c of
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(256) void ls_prep_f16_kernel(const float* __restric
                                                           int nq_pad, int d, int d_pad, int QG,
                                                           int normalize, u32* __restrict__ overflow) {
     const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (qi >= nq_pad) return;
     const int KS = d_pad / 32, chunks = d_pad / 8;
     if (lane == 0) overflow[qi] = 0u;  // per-query repair flag, cleared for this batch
@@ -106,7 +118,9 @@ __global__ __launch_bounds__(256) void ls_prep_f16_kernel(const float* __restric
 
 int ls_launch_prep_f16(const float* d_q, void* d_qh, float* d_qkeep, int64_t nq, int64_t nq_pad,
                        const ls_geom& g, bool normalize, u32* d_overflow, hipStream_t s) {
-    hipLaunchKernelGGL(ls_prep_f16_kernel, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, s, d_q,
+    // one-wave workgroups: 37 registers and no LDS, i.e. a wave that fits beside a resident MFMA pass
+    // (tools/coresidency_probe.hip), whatever SIMD has room for it
+    hipLaunchKernelGGL(ls_prep_f16_kernel, dim3((unsigned)nq_pad), dim3(64), 0, s, d_q,
                        (u32x4*)d_qh, d_qkeep, (int)nq, (int)nq_pad, g.d, g.d_pad, ls_gemm_qg(g),
                        normalize ? 1 : 0, d_overflow);
     LS_HIP(hipGetLastError());
@@ -162,6 +176,11 @@ struct ls_gemm_out {
     u32* counts;       // [nq_pad][nsplits][4]
     u32* overflow;     // [nq_pad] per-query repair flag
     u32* sample_top;   // [nq_pad][nsplits][4][4] (sample pass)
+    // fused launches only (LS_GEMM_FUSED): behind its own full pass the launch runs the sample
+    // phase of the NEXT batch (sample_top is then the next batch's buffer)
+    const u32x4* qh_next;  // the next batch's prepared queries (same geometry as this batch)
+    int nq_next;
+    int sample_stride;     // the sample phase visits every sample_stride-th tile of a slice
 };
 
 // "at most n vector-memory operations outstanding" (gfx9 encoding: vmcnt in bits 3:0 and 15:14;
@@ -172,15 +191,36 @@ __device__ __forceinline__ void wait_vmcnt() {
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
-// TOPN: sample scores kept per lane. SAMPLE stays the last parameter: the profile tooling tells
-// the two passes apart by the ", true>" / ", false>" tail of the kernel name.
+// compile-time phase tags for the generic lambdas below
+struct phase_sample { static constexpr bool value = true; };
+struct phase_full { static constexpr bool value = false; };
+
+#define LS_GEMM_PASS 0    // full pass against a given tau
+#define LS_GEMM_SAMPLE 1  // sample pass: best sample scores per lane
+#define LS_GEMM_FUSED 2   // full pass of this batch, then the sample phase of the NEXT batch
+
+// TOPN: sample scores kept per lane. MODE stays the last parameter: the profile tooling tells the
+// launches apart by the ", 0>" / ", 1>" / ", 2>" tail of the kernel name.
 // NT: the tile DMA carries the non-temporal hint. Right when ONE workgroup reads each corpus slice
 // once (a single query tile, config 4: -1.5 %); wrong when the query tiles of a slice share it
 // through their XCD's L2 (config 3: +3.8 %).
-template <int CHUNKS, int QG, int TOPN, bool NT, bool SAMPLE>
-__global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_gemm_filter_kernel(
+//
+// LS_GEMM_FUSED (round 4): this batch's full pass, then the NEXT batch's sample phase in the same
+// launch. Under LS_FLAG_PIPELINE the sample pass of batch i+1 used to sit between the passes of
+// batches i and i+1 - the same 8-wave, 96 KB kernel, so it could only start on CUs pass i had left,
+// and it paid its own launch, B-fragment loads and boundary. Folded behind pass i it costs its tiles
+// only; between two passes remain the tau kernel and two kernel boundaries. No workgroup ever waits
+// for another one (an earlier form of this launch ran the sample phase FIRST and met the tile's
+// workgroups on arrival counters inside the kernel: 28 us of start-up, waits and cross-XCD reads of
+// freshly written-through scores per launch against 23 us for the two kernels it replaced -
+// tools/fused_phases.py, profiles/ab/r04_c3_fused_forms.txt).
+template <int CHUNKS, int QG, int TOPN, bool NT, int MODE>
+__device__ __forceinline__ void gemm_filter_body(
     const u32x4* __restrict__ corpus, long long n, const u32x4* __restrict__ qh, int nq, int nqt,
-    const float* __restrict__ tau, long long rows_per_split, int tile_stride, ls_gemm_out out) {
+    const float* __restrict__ tau, long long rows_per_split, int tile_stride_arg, const ls_gemm_out& out) {
+    // (nq is re-pointed at the next batch's query count by a fused launch's second phase)
+    constexpr bool SAMPLE = MODE == LS_GEMM_SAMPLE;
+    constexpr bool FUSED = MODE == LS_GEMM_FUSED;
     constexpr int TM = gemm_tm(CHUNKS);    // corpus rows per LDS tile
     constexpr int NRB = TM / 16;           // 16-row MFMA blocks per tile
     constexpr int KS = CHUNKS / 4;         // k-steps: 32 fp16 = 4 chunks each
@@ -204,6 +244,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     const unsigned long long t_start = wall_clock64();
 #endif
     LS_SSTAMP_S(0);
+    LS_SSTAMP_F(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar DMA addressing
     const int qd = lane >> 4, li = lane & 15;  // quarter (k-chunk / row group), index in group
     int split, qt;
@@ -213,7 +254,10 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     long long r_end = r_begin + rows_per_split;
     if (r_end > n) r_end = n;
     const int ntiles_all = r_begin < r_end ? (int)((r_end - r_begin + TM - 1) / TM) : 0;
-    const int nt = (ntiles_all + tile_stride - 1) / tile_stride;  // tiles this launch visits
+    // the phase being run: every tile_stride-th tile of the slice, nt of them (a fused launch runs
+    // the sample phase first and resets both for the full pass)
+    int tile_stride = tile_stride_arg;
+    int nt = (ntiles_all + tile_stride - 1) / tile_stride;
 
     // ---- corpus tiles: HBM/L2 -> LDS by DMA (global_load_lds, 16 B per lane) ------------------
     // Wave w, load j fills the 64 consecutive LDS chunks starting at (w*LOADS + j)*64: chunk Lc
@@ -307,13 +351,17 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // then overlaps the (L2-resident) query loads instead of queueing behind them.
     constexpr int NB_ALL = LS_GEMM_LDS_BYTES / TILE_BYTES;  // tiles that fit in LDS together
     const bool sample_upfront = SAMPLE && nt > 0 && nt <= NB_ALL && nt <= 3;
-    if (nt > 0) stage(0, 0);
-    if (sample_upfront) {
-        if (nt > 1) stage(tile_stride, TILE_BYTES);
-        if (nt > 2) stage(2 * tile_stride, 2 * TILE_BYTES);
-    } else if (NBUF == 3 && nt > 1) {
-        stage(tile_stride, TILE_BYTES);
-    }
+    // the tiles a phase requests before its first hand-over
+    auto phase_prologue = [&]() {
+        if (nt > 0) stage(0, 0);
+        if (sample_upfront) {
+            if (nt > 1) stage(tile_stride, TILE_BYTES);
+            if (nt > 2) stage(2 * tile_stride, 2 * TILE_BYTES);
+        } else if (NBUF == 3 && nt > 1) {
+            stage(tile_stride, TILE_BYTES);
+        }
+    };
+    phase_prologue();
 
     // B fragments: group qg holds query qt*8*QPW + wave*QPW + qg*16 + li; k-step kk -> chunk 4kk+qd.
     half8 bq[QG][KS];
@@ -333,16 +381,24 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
         for (int g2 = 0; g2 < QG; ++g2) bq[g2][kk] = __builtin_bit_cast(half8, qfrag[g2][kk << 6]);
     // private queues of this lane (one per query group), contiguous per lane
     // entry = {score bits, row relative to the slice}; the select kernel turns it into a key
-    uint2* myq[QG];
+    // (kept as 32-bit entry offsets from out.queues - the whole queue array is nq_pad * nsplits KiB,
+    // far below 2^32 entries - so that the append is base (scalar) + offset: two registers less than
+    // two pointers, which is what keeps a fused launch inside 232 registers)
+    u32 myq[QG];
     int cnt[QG];
     float top[QG][TOPN];  // sample scores kept per lane and query group
+    auto init_full_state = [&]() {  // (a fused launch sets these up only after its sample phase)
 #pragma unroll
-    for (int g2 = 0; g2 < QG; ++g2) {
-        myq[g2] = out.queues + queue_id(qj[g2], split, qd, nsplits) * cap;
-        cnt[g2] = 0;
+        for (int g2 = 0; g2 < QG; ++g2) {
+            myq[g2] = (u32)(queue_id(qj[g2], split, qd, nsplits) * cap);
+            cnt[g2] = 0;
+        }
+    };
+    init_full_state();
+#pragma unroll
+    for (int g2 = 0; g2 < QG; ++g2)
 #pragma unroll
         for (int e = 0; e < TOPN; ++e) top[g2][e] = -FLT_MAX;
-    }
 
     // A fragment of k-step kk, row block rb: tile row rb*16 + li, chunk (4kk + qd) ^ li.
     // (4kk + qd) & 15 takes 4 values per lane: 4 precomputed byte offsets + immediates.
@@ -357,24 +413,33 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     };
 
     // ---- one score of a finished tile -------------------------------------------------------------
+    // `ph` (phase_sample / phase_full) selects at compile time what happens to a score.
     // The append is the hot slow path (a wave enters it for ~1 check in 5): no key building, no
     // bounds logic here. Padded queries carry tau = FLT_MAX and never pass; zero-pad rows past n
     // are dropped by the select kernel; a full queue keeps overwriting its last slot while the
     // count runs on, which is how the overflow is seen at the end.
-    auto check1 = [&](float s, int g2, int lrow) {
-        if (SAMPLE) {
+    auto check1 = [&](auto ph, float s, int g2, int lrow) {
+        if constexpr (decltype(ph)::value) {
             // NaN never enters (fmaxf/fminf drop it); padded queries and zero-pad rows are masked
             top4_insert(top[g2], (qj[g2] < nq && r_begin + lrow < r_end) ? s : -FLT_MAX);
-        } else if (s >= tauv[g2]) {
-            const int slot = cnt[g2] < cap ? cnt[g2] : cap - 1;
-            uint2* qp = LEAN ? out.queues + queue_id(qj[g2], split, qd, nsplits) * cap : myq[g2];
-            qp[slot] = make_uint2(__float_as_uint(s), (u32)lrow);
-            ++cnt[g2];
+        } else {
+            if (s >= tauv[g2]) {
+                const int slot = cnt[g2] < cap ? cnt[g2] : cap - 1;
+                const u32 qo = LEAN ? (u32)(queue_id(qj[g2], split, qd, nsplits) * cap) : myq[g2];
+#if LS_GEMM_APPEND_SC1  // variant builds: write-through appends (nothing dirty in L2 at the kernel's end)
+                __hip_atomic_store(reinterpret_cast<u64*>(out.queues) + (qo + (u32)slot),
+                                   ((u64)(u32)lrow << 32) | __float_as_uint(s), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+#else
+                out.queues[qo + (u32)slot] = make_uint2(__float_as_uint(s), (u32)lrow);
+#endif
+                ++cnt[g2];
+            }
         }
     };
-    auto check = [&](const f32x4v (&acc)[NRB][QG], int e, int lrow0) {  // e -> (block, group, reg)
+    auto check = [&](auto ph, const f32x4v (&acc)[NRB][QG], int e, int lrow0) {  // e -> (block, group, reg)
         const int rb = e / (QG * 4), g2 = (e / 4) % QG, reg = e % 4;
-        check1(acc[rb][g2][reg], g2, lrow0 + rb * 16 + reg);  // lrow0 already includes 4*qd
+        check1(ph, acc[rb][g2][reg], g2, lrow0 + rb * 16 + reg);  // lrow0 already includes 4*qd
     };
 
     // One tile: NRB*QG independent accumulator chains advance together, one k-step at a time.
@@ -391,16 +456,45 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     // SEQ_RB also spreads the DMA pieces of the tile that is fetched next over the first row
     // block's k-steps (one piece every other k-step) instead of issuing all of them right behind
     // the barrier, where both waves of a SIMD would do so at once with the matrix pipe idle.
-    auto run_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], bool have_prev,
+    auto run_tile = [&](auto ph, f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], bool have_prev,
                         int prev_row0, int cur_row0, int bufoff, bool stage_more = false,
                         int stage_ti = 0, int stage_buf = 0) {
+        constexpr bool SMP = decltype(ph)::value;
+        if constexpr (SMP && FUSED) {
+            // The sample phase of a fused launch is a handful of tiles, and whatever it keeps in
+            // registers comes on top of the full pass's state (the B fragments alone are KS*QG*4
+            // registers): ONE accumulator set, A fragments read just in time, and the tile's own
+            // scores filtered right behind its k-loop. ~1 us slower per workgroup than the
+            // software-pipelined form, and the launch stays at the full pass's register count -
+            // which is what lets the one-wave select kernel (ls_wsel.hip) run beside it.
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    const half8 a = a_frag(bufoff, rb, kk);
+#pragma unroll
+                    for (int g2 = 0; g2 < QG; ++g2) {
+                        f32x4v c;
+                        if (kk == 0) {
+                            c[0] = 0.0f; c[1] = 0.0f; c[2] = 0.0f; c[3] = 0.0f;
+                        } else {
+                            c = cur[rb][g2];
+                        }
+                        cur[rb][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[g2][kk], c, 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < NV; ++e) check(ph, cur, e, cur_row0);
+            return;
+        }
         if constexpr (SEQ_RB) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
                 const int pb = rb == 0 ? NRB - 1 : rb - 1;  // block whose scores are filtered now
                 const bool have = rb == 0 ? have_prev : true;
                 const int prow0 = (rb == 0 ? prev_row0 : cur_row0) + pb * 16;
-                constexpr int PF = SAMPLE ? 1 : LS_GEMM_PF, NA = PF + 1;  // A fragments are read PF k-steps ahead (the sample pass has 8 registers fewer)
+                constexpr int PF = SMP ? 1 : LS_GEMM_PF, NA = PF + 1;  // A fragments are read PF k-steps ahead (the sample pass has 8 registers fewer)
                 half8 a[NA];
 #pragma unroll
                 for (int p0 = 0; p0 < PF; ++p0) a[p0] = a_frag(bufoff, rb, p0);
@@ -421,7 +515,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
                     if (have) {
 #pragma unroll
                         for (int e = 0; e < QG * 4; ++e)
-                            if ((e * KS) / (QG * 4) == kk) check1(cur[pb][e / 4][e % 4], e / 4, prow0 + e % 4);
+                            if ((e * KS) / (QG * 4) == kk) check1(ph, cur[pb][e / 4][e % 4], e / 4, prow0 + e % 4);
                     }
                     constexpr int SD = 2 * LOADS <= KS ? 2 : 1;  // a piece every SD-th k-step
                     if (rb == 0 && kk % SD == SD - 1 && kk / SD < LOADS && stage_more)
@@ -432,7 +526,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
         }
         if (ONE_ACC && have_prev) {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) check(prev, e, prev_row0);
+            for (int e = 0; e < NV; ++e) check(ph, prev, e, prev_row0);
         }
         half8 a[2][NRB];  // A fragments are read one k-step ahead of their MFMAs
 #pragma unroll
@@ -460,7 +554,7 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             if (!ONE_ACC && have_prev) {
 #pragma unroll
                 for (int c2 = 0; c2 < CPK; ++c2)
-                    if (kk * CPK + c2 < NV) check(prev, kk * CPK + c2, prev_row0);
+                    if (kk * CPK + c2 < NV) check(ph, prev, kk * CPK + c2, prev_row0);
             }
             if (!SEQ_RB && kk < LOADS && stage_more)
                 stage_piece(stage_ti, stage_buf, kk);
@@ -468,26 +562,29 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     };
 
     f32x4v accA[NRB][QG], accB[NRB][QG];  // two sets alternate between tiles (ONE_ACC: accA only)
-#if LS_GEMM_STRAIGHT
     // The tile loop carries no "is there a previous tile" / "is there a next tile" branches (they
     // cut the loop body into basic blocks the scheduler cannot move MFMAs across): the
     // accumulators start at -inf, which passes no threshold (tau >= -FLT_MAX) and leaves a
     // top-4 list unchanged, so the first tile may filter them like a real previous tile; and
     // the full pass always requests the next tile, past the slice end too (the next slice's
     // rows or the zero pad rows, LS_CORPUS_PAD_ROWS >= 2 tiles: fetched, never read).
+    auto reset_acc = [&]() {
+#if LS_GEMM_STRAIGHT
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
+        for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-        for (int g2 = 0; g2 < QG; ++g2)
+            for (int g2 = 0; g2 < QG; ++g2)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) accA[rb][g2][e] = accB[rb][g2][e] = -INFINITY;
+                for (int e = 0; e < 4; ++e) accA[rb][g2][e] = accB[rb][g2][e] = -INFINITY;
 #endif
+    };
+    reset_acc();
     auto tile_row0 = [&](int i) { return (i * tile_stride) * TM + 4 * qd; };  // slice-relative
-    auto flush_last = [&](const f32x4v (&acc)[NRB][QG]) {  // the last tile still has to be filtered
+    auto flush_last = [&](auto ph, const f32x4v (&acc)[NRB][QG]) {  // the last tile still has to be filtered
         const int row0 = tile_row0(nt - 1);
 #pragma unroll
         for (int e = 0; e < NV; ++e)
-            if (!SEQ_RB || e / (QG * 4) == NRB - 1) check(acc, e, row0);  // SEQ_RB: last block only
+            if (!SEQ_RB || e / (QG * 4) == NRB - 1) check(ph, acc, e, row0);  // SEQ_RB: last block only
     };
     // The sample pass visits only a few tiles, so their DMA latencies would be paid one by one:
     // when all of them fit in LDS together they are fetched up front and consumed back to back.
@@ -497,13 +594,13 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             LS_SSTAMP_S(1);
             if constexpr (ONE_ACC) {
                 for (int i = 0; i < nt; ++i)
-                    run_tile(accA, accA, i > 0, tile_row0(i - 1), tile_row0(i), i * TILE_BYTES);
-                flush_last(accA);
+                    run_tile(phase_sample{}, accA, accA, i > 0, tile_row0(i - 1), tile_row0(i), i * TILE_BYTES);
+                flush_last(phase_sample{}, accA);
             } else {
-                run_tile(accA, accB, false, 0, 0, 0);
-                if (nt > 1) run_tile(accB, accA, true, tile_row0(0), 0, TILE_BYTES);
-                if (nt > 2) run_tile(accA, accB, true, tile_row0(1), 0, 2 * TILE_BYTES);
-                if ((nt - 1) & 1) flush_last(accB); else flush_last(accA);
+                run_tile(phase_sample{}, accA, accB, false, 0, 0, 0);
+                if (nt > 1) run_tile(phase_sample{}, accB, accA, true, tile_row0(0), 0, TILE_BYTES);
+                if (nt > 2) run_tile(phase_sample{}, accA, accB, true, tile_row0(1), 0, 2 * TILE_BYTES);
+                if ((nt - 1) & 1) flush_last(phase_sample{}, accB); else flush_last(phase_sample{}, accA);
             }
             LS_SSTAMP_S(2);
 #pragma unroll
@@ -514,52 +611,97 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
             return;
         }
     }
-    // ---- the tile loop. Ring of NBUF buffers; tile i sits in buffer i % NBUF. With three
-    // buffers tile i+2 is requested at the top of tile i (its buffer was last read during tile
-    // i-1, which every wave has left through the barrier); with two, tile i+1.
-    first_hand_over();
+    // ---- the tile loop of one phase. Ring of NBUF buffers; tile i sits in buffer i % NBUF. With
+    // three buffers tile i+2 is requested at the top of tile i (its buffer was last read during
+    // tile i-1, which every wave has left through the barrier); with two, tile i+1.
     constexpr int AHEAD = NBUF - 1;
-    int b_cur = 0, b_new = AHEAD * TILE_BYTES;  // LDS byte offsets of tile i and of tile i + AHEAD
-    auto advance = [&](int& b) { b = b + TILE_BYTES == NBUF * TILE_BYTES ? 0 : b + TILE_BYTES; };
-    auto one_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], int i) {
-        constexpr bool always = LS_GEMM_STRAIGHT && !SAMPLE && (AHEAD + 1) * TM <= LS_CORPUS_PAD_ROWS;
-        const bool more = always ? true : i + AHEAD < nt;
-        // the next tile's DMA pieces are issued between this tile's k-steps (run_tile), not in
-        // one burst behind the barrier
-        constexpr bool spread = (SEQ_RB || !SAMPLE) && LOADS <= KS;
-        if (more && !spread) stage((i + AHEAD) * tile_stride, b_new);
-        run_tile(cur, prev, LS_GEMM_STRAIGHT ? true : i > 0, tile_row0(i - 1), tile_row0(i), b_cur,
-                 more && spread, (i + AHEAD) * tile_stride, b_new);
-        // tile i+1 must be complete before anyone reads it. NBUF == 3: only when a younger tile
-        // was requested in this iteration may LOADS pieces stay in flight.
-        hand_over(NBUF == 3 && more);
-        advance(b_cur);
-        advance(b_new);
-    };
-    if constexpr (ONE_ACC) {
-        for (int i = 0; i < nt; ++i) one_tile(accA, accA, i);
-        if (nt > 0) flush_last(accA);
-    } else {
-        for (int i = 0; i < nt; i += 2) {
-            one_tile(accA, accB, i);
-            if (i + 1 < nt) one_tile(accB, accA, i + 1);
-        }
-        if (nt > 0) {
-            if ((nt - 1) & 1) flush_last(accB); else flush_last(accA);
-        }
-    }
-#pragma unroll
-    for (int g2 = 0; g2 < QG; ++g2) {
-        const long long qid = queue_id(qj[g2], split, qd, nsplits);
-        if (SAMPLE) {
-            reinterpret_cast<uint4*>(out.sample_top)[qid] = top4_keys(top[g2]);
+    auto run_phase = [&](auto ph) {
+        constexpr bool SMP = decltype(ph)::value;
+        first_hand_over();
+        if constexpr (SMP) LS_SSTAMP_F(1);
+        int b_cur = 0, b_new = AHEAD * TILE_BYTES;  // LDS byte offsets of tile i and of tile i + AHEAD
+        auto advance = [&](int& b) { b = b + TILE_BYTES == NBUF * TILE_BYTES ? 0 : b + TILE_BYTES; };
+        auto one_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], int i) {
+            constexpr bool always = LS_GEMM_STRAIGHT && !SMP && (AHEAD + 1) * TM <= LS_CORPUS_PAD_ROWS;
+            const bool more = always ? true : i + AHEAD < nt;
+            // the next tile's DMA pieces are issued between this tile's k-steps (run_tile), not in
+            // one burst behind the barrier
+            constexpr bool spread = (SEQ_RB || !SMP) && LOADS <= KS;
+            if (more && !spread) stage((i + AHEAD) * tile_stride, b_new);
+            run_tile(ph, cur, prev, LS_GEMM_STRAIGHT ? true : i > 0, tile_row0(i - 1), tile_row0(i), b_cur,
+                     more && spread, (i + AHEAD) * tile_stride, b_new);
+            // tile i+1 must be complete before anyone reads it. NBUF == 3: only when a younger tile
+            // was requested in this iteration may LOADS pieces stay in flight.
+            hand_over(NBUF == 3 && more);
+            advance(b_cur);
+            advance(b_new);
+        };
+        if constexpr (SMP && FUSED) {  // every tile filters itself (run_tile): nothing left to flush
+            for (int i = 0; i < nt; ++i) one_tile(accA, accA, i);
+        } else if constexpr (ONE_ACC) {
+            for (int i = 0; i < nt; ++i) one_tile(accA, accA, i);
+            if (nt > 0) flush_last(ph, accA);
         } else {
+            for (int i = 0; i < nt; i += 2) {
+                one_tile(accA, accB, i);
+                if (i + 1 < nt) one_tile(accB, accA, i + 1);
+            }
+            if (nt > 0) {
+                if ((nt - 1) & 1) flush_last(ph, accB); else flush_last(ph, accA);
+            }
+        }
+    };
+
+    if constexpr (FUSED) {
+        // ======== this batch's full pass, exactly as a LS_GEMM_PASS launch ============================
+        run_phase(phase_full{});
+#pragma unroll
+        for (int g2 = 0; g2 < QG; ++g2) {
+            const long long qid = queue_id(qj[g2], split, qd, nsplits);
+            out.counts[qid] = (u32)(cnt[g2] < cap ? cnt[g2] : cap);
+            if (cnt[g2] > cap) out.overflow[qj[g2]] = 1u;
+        }
+        LS_SSTAMP_F(2);
+        // ======== the NEXT batch's sample phase over this slice's sample tiles =====================
+        // Same geometry as this batch (the host fuses only then). Its prepared queries were written
+        // by a prep kernel that completed before this launch started (stream wait on its event).
+        tile_stride = out.sample_stride;
+        nt = (ntiles_all + tile_stride - 1) / tile_stride;
+        __builtin_amdgcn_s_barrier();  // every wave has left the tile ring
+        phase_prologue();
+        {
+            const u32x4* qn = out.qh_next;
+            asm volatile("" : "+s"(qn));  // a different buffer: nothing of the first load may be reused
+#pragma unroll
+            for (int g2 = 0; g2 < QG; ++g2)
+                qfrag[g2] = qn + ((((long long)(qt * LS_GEMM_WAVES + wave) * QG + g2) * KS) << 6) + lane;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int g2 = 0; g2 < QG; ++g2) bq[g2][kk] = __builtin_bit_cast(half8, qfrag[g2][kk << 6]);
+        }
+        nq = out.nq_next;
+        run_phase(phase_sample{});
+#pragma unroll
+        for (int g2 = 0; g2 < QG; ++g2)
+            reinterpret_cast<uint4*>(out.sample_top)[queue_id(qj[g2], split, qd, nsplits)] = top4_keys(top[g2]);
+    } else if constexpr (SAMPLE) {
+        run_phase(phase_sample{});
+#pragma unroll
+        for (int g2 = 0; g2 < QG; ++g2)
+            reinterpret_cast<uint4*>(out.sample_top)[queue_id(qj[g2], split, qd, nsplits)] = top4_keys(top[g2]);
+    } else {
+        run_phase(phase_full{});
+#pragma unroll
+        for (int g2 = 0; g2 < QG; ++g2) {
+            const long long qid = queue_id(qj[g2], split, qd, nsplits);
             out.counts[qid] = (u32)(cnt[g2] < cap ? cnt[g2] : cap);
             if (cnt[g2] > cap) out.overflow[qj[g2]] = 1u;
         }
     }
+    LS_SSTAMP_F(7);
 #ifdef LS_GEMM_TIMING
-    if (!SAMPLE && tid == 0) {  // the sample tops are dead once tau has been computed
+    if (!SAMPLE && !FUSED && tid == 0) {  // the sample tops are dead once tau has been computed
         unsigned long long* life = reinterpret_cast<unsigned long long*>(out.sample_top);
         life[2 * blockIdx.x] = t_start;
         life[2 * blockIdx.x + 1] = wall_clock64();
@@ -567,101 +709,130 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
 #endif
 }
 
+// The kernel proper: a thin entry point around the body (clang's amdgpu_num_vgpr attribute is not
+// enforced by this toolchain, so the 232-register budget of gemm_vgpr_budget is checked on the built
+// code object instead: tests/test_abi.py::test_register_budget_of_the_co_resident_kernels).
+template <int CHUNKS, int QG, int TOPN, bool NT, int MODE>
+__global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_gemm_filter_kernel(
+    const u32x4* __restrict__ corpus, long long n, const u32x4* __restrict__ qh, int nq, int nqt,
+    const float* __restrict__ tau, long long rows_per_split, int tile_stride, ls_gemm_out out) {
+    gemm_filter_body<CHUNKS, QG, TOPN, NT, MODE>(corpus, n, qh, nq, nqt, tau, rows_per_split, tile_stride, out);
+}
+
 int ls_gemm_qg(const ls_geom& g) { return gemm_qg(g.chunks); }
 int ls_gemm_tile_rows(const ls_geom& g) { return gemm_tm(g.chunks); }
 
+// One launcher for the three kinds of launch. `fz` non-null (with d_tau) = a fused launch (this
+// batch's full pass + the next batch's sample phase); else d_tau null = sample pass, non-null = full pass. ev_start /
+// ev_stop (either may be null) are attached to the dispatch itself (hipExtLaunchKernelGGL): they
+// cost no extra packet on the stream, and a pair of timing events brackets exactly the kernel.
 int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, const void* d_qh,
                           int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
                           int64_t rows_per_split, int tile_stride, const ls_gemm_bufs& b,
-                          bool sample_top2, hipStream_t s) {
+                          bool sample_top2, hipStream_t s, const ls_gemm_fuse* fz, hipEvent_t ev_start,
+                          hipEvent_t ev_stop) {
     const int QG = ls_gemm_qg(g);
     const int nqt = (int)(nq_pad / (LS_GEMM_WAVES * 16 * QG));
     const dim3 grid((unsigned)(nsplits * nqt));
-    ls_gemm_out o;
+    ls_gemm_out o{};
     o.queues = (uint2*)b.d_queues;
     o.counts = b.d_counts;
     o.overflow = b.d_overflow;
     o.sample_top = b.d_sample_top;
-    // full pass: the tile ring; sample pass: up to three tiles up front
+    if (fz) {
+        o.qh_next = (const u32x4*)fz->d_qh_next;
+        o.nq_next = (int)fz->nq_next;
+        o.sample_stride = fz->sample_stride;
+        o.sample_top = fz->d_sample_top_next;
+    }
+    // full pass / fused: the tile ring; sample pass: up to three tiles up front
     const size_t tile_bytes = (size_t)gemm_tile_bytes(g.chunks);
     const size_t smem = d_tau ? tile_bytes * gemm_nbuf(g.chunks)
                               : tile_bytes * (3 * tile_bytes <= LS_GEMM_LDS_BYTES ? 3 : 2);
-#define LS_GEMM_LAUNCH(C, SMP, TOPN, NT)                                                          \
+#define LS_GEMM_LAUNCH(C, MODE, TOPN, NT)                                                         \
     {                                                                                             \
-        auto kern = ls_gemm_filter_kernel<C, gemm_qg(C), TOPN, NT, SMP>;                          \
+        auto kern = ls_gemm_filter_kernel<C, gemm_qg(C), TOPN, NT, MODE>;                         \
         static ls_attr_once once;                                                                 \
         if (int rc = ls_set_max_dynamic_lds(once, (const void*)kern, LS_GEMM_LDS_BYTES)) return rc; \
-        hipLaunchKernelGGL(kern, grid, dim3(LS_GEMM_THREADS), smem, s, (const u32x4*)d_corpus,    \
-                           (long long)n, (const u32x4*)d_qh, (int)nq, nqt, d_tau,                 \
-                           (long long)rows_per_split, tile_stride, o);                            \
+        hipExtLaunchKernelGGL(kern, grid, dim3(LS_GEMM_THREADS), smem, s, ev_start, ev_stop, 0,   \
+                              (const u32x4*)d_corpus, (long long)n, (const u32x4*)d_qh, (int)nq,  \
+                              nqt, d_tau, (long long)rows_per_split, tile_stride, o);             \
         LS_HIP(hipGetLastError());                                                                \
         return LS_OK;                                                                             \
     }
-#define LS_GEMM_CASE(C)                                                      \
-    if (g.chunks == C) {                                                     \
-        if (d_tau && nqt == 1) LS_GEMM_LAUNCH(C, false, 4, true)             \
-        else if (d_tau) LS_GEMM_LAUNCH(C, false, 4, false)                   \
-        else if (C / 4 * gemm_qg(C) * 4 >= 128 && sample_top2) LS_GEMM_LAUNCH(C, true, 2, false) \
-        else LS_GEMM_LAUNCH(C, true, 4, false)                               \
+#define LS_GEMM_TOP2(C) (C / 4 * gemm_qg(C) * 4 >= 128 && sample_top2)
+#define LS_GEMM_CASE(C)                                                                  \
+    if (g.chunks == C) {                                                                 \
+        if (fz && nqt == 1 && LS_GEMM_TOP2(C)) LS_GEMM_LAUNCH(C, LS_GEMM_FUSED, 2, true)  \
+        else if (fz && nqt == 1) LS_GEMM_LAUNCH(C, LS_GEMM_FUSED, 4, true)                \
+        else if (fz && LS_GEMM_TOP2(C)) LS_GEMM_LAUNCH(C, LS_GEMM_FUSED, 2, false)        \
+        else if (fz) LS_GEMM_LAUNCH(C, LS_GEMM_FUSED, 4, false)                           \
+        else if (d_tau && nqt == 1) LS_GEMM_LAUNCH(C, LS_GEMM_PASS, 4, true)              \
+        else if (d_tau) LS_GEMM_LAUNCH(C, LS_GEMM_PASS, 4, false)                         \
+        else if (LS_GEMM_TOP2(C)) LS_GEMM_LAUNCH(C, LS_GEMM_SAMPLE, 2, false)             \
+        else LS_GEMM_LAUNCH(C, LS_GEMM_SAMPLE, 4, false)                                  \
     }
+#ifdef LS_GEMM_ONLY_CASE  // developer builds: one geometry (compile time of a register experiment)
+    LS_GEMM_CASE(LS_GEMM_ONLY_CASE)
+#else
     LS_GEMM_CASE(16) LS_GEMM_CASE(32) LS_GEMM_CASE(48) LS_GEMM_CASE(64)
     LS_GEMM_CASE(96) LS_GEMM_CASE(128)
+#endif
 #undef LS_GEMM_CASE
+#undef LS_GEMM_TOP2
 #undef LS_GEMM_LAUNCH
     ls_set_error("batched path: unsupported row geometry (%d chunks)", g.chunks);
     return LS_ERR_INVALID_ARG;
 }
 
 // ---- tau: j-th best sample score of each query --------------------------------------------------
-// The sample pass left, for every (workgroup, lane, query group), the 4 best sample scores that
-// lane saw (ord() of the score, 0 = none). A query owns 4 lanes in each of its nsplits
-// workgroups: 16*nsplits values, contiguous. One 256-thread workgroup per query (this kernel is
-// latency-bound and far from filling the chip: four waves sharing a query's values measured
-// 5.7 us against 9.3 us for one wave per query); 2 radix passes find the j-th largest.
-// Keeping only 4 per lane can only LOWER the result (if one lane held more than 4 of the best
-// j), i.e. let more rows through: tau is a speculative, verified threshold either way.
-template <int LS_TAU_PER_THREAD>  // values per thread: 16 * nsplits / 256, rounded up to 4, 8, 16, 32
-__global__ __launch_bounds__(256) void ls_tau_kernel(const u32* __restrict__ sample_top, int nsplits,
-                                                     int nq, int j_rank, float* __restrict__ tau) {
-    __shared__ u32 hist[2 * 256];
-    __shared__ u32 misc[2 * 8];
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+// The sample phase left, for every (workgroup, lane, query group), the 4 (or 2) best sample scores
+// that lane saw (ord() of the score, 0 = none). A query owns 4 lanes in each of its nsplits
+// workgroups: 16*nsplits values, contiguous. Keeping only a few per lane can only LOWER the result
+// (if one lane held more of the best j), i.e. let more rows through: tau is a speculative,
+// verified threshold either way.
+// Round 4: ONE WAVE per query, values in registers, no LDS and no barrier: the j-th largest by a
+// bit-wise search over the top 16 bits of the order key (sign, exponent, 7 mantissa bits) - 16 steps
+// of "how many values are >= candidate" (compares + one wave sum). The result is at most 0.8 % below
+// the exact j-th sample score, the same value the two 8-bit radix passes of the earlier 256-thread
+// kernel produced; it sits between two MFMA passes of a pipelined run, so its ~3 us are critical
+// path (the earlier kernel: 5.6 us).
+template <int P>  // uint4 loads per lane: 16 * nsplits / 256, rounded up to 4, 8, 16, 32
+__global__ __launch_bounds__(64) void ls_tau_kernel(const u32* __restrict__ sample_top, int nsplits,
+                                                    int nq, int j_rank, float* __restrict__ tau) {
+    const int q = blockIdx.x, lane = threadIdx.x;
     if (q >= nq) {
-        if (tid == 0) tau[q] = FLT_MAX;  // padded query: nothing passes
+        if (lane == 0) tau[q] = FLT_MAX;  // padded query: nothing passes
         return;
     }
-    const int total = nsplits * 16;  // values of this query: [slice][quarter][4]
-    u32 v[LS_TAU_PER_THREAD];
+    const int total4 = nsplits * 4;  // uint4s of this query: [slice][quarter]
+    const uint4* src = reinterpret_cast<const uint4*>(sample_top) + (long long)q * total4;
+    uint4 v[P];
 #pragma unroll
-    for (int j = 0; j < LS_TAU_PER_THREAD; ++j) {
-        const int idx = tid + j * 256;
-        v[j] = idx < total ? sample_top[(long long)q * total + idx] : 0u;
+    for (int j = 0; j < P; ++j) {
+        const int idx = lane + j * 64;
+        v[j] = idx < total4 ? src[idx] : make_uint4(0, 0, 0, 0);
     }
-    for (int i = tid; i < 2 * 256; i += 256) hist[i] = 0;
-    __syncthreads();
-    u32 pref = 0, pmask = 0, krem = (u32)j_rank;
-    // Only the top 16 bits of the order key are resolved (sign, exponent, 7 mantissa bits): the
-    // result is at most 0.8 % below the exact j-th sample score, i.e. still a valid (slightly
-    // more permissive) speculative threshold, for half the passes.
-    for (int pass = 0; pass < 2; ++pass) {
-        const int shift = 24 - 8 * pass;
+    auto count_ge = [&](u32 cand) -> u32 {
+        u32 c = 0;
 #pragma unroll
-        for (int j = 0; j < LS_TAU_PER_THREAD; ++j)
-            if (j * 256 < total)  // uniform: later slots hold no value
-                wave_hist_add(hist + pass * 256, (v[j] >> shift) & 255u,
-                              v[j] != 0u && (v[j] & pmask) == pref, lane);
-        __syncthreads();
-        find_bin(hist + pass * 256, krem, misc + pass * 8, tid);
-        __syncthreads();
-        if (pass == 0 && misc[3] < (u32)j_rank) {  // fewer than j sample scores: no bound
-            if (tid == 0) tau[q] = -FLT_MAX;
-            return;
+        for (int j = 0; j < P; ++j)
+            c += (u32)(v[j].x >= cand) + (u32)(v[j].y >= cand) + (u32)(v[j].z >= cand) + (u32)(v[j].w >= cand);
+        return wave_sum(c);
+    };
+    float out;
+    if (count_ge(1u) < (u32)j_rank) {
+        out = -FLT_MAX;  // fewer than j sample scores: no bound
+    } else {
+        u32 t = 0;
+#pragma unroll 1
+        for (int bit = 31; bit >= 16; --bit) {
+            const u32 cand = t | (1u << bit);
+            if (count_ge(cand) >= (u32)j_rank) t = cand;
         }
-        pref |= misc[pass * 8] << shift;
-        pmask |= 255u << shift;
-        krem = misc[pass * 8 + 1];
+        out = ls_unord(t);
     }
-    if (tid == 0) tau[q] = ls_unord(pref);
+    if (lane == 0) tau[q] = out;
 }
 
 int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_pad, int j_rank,
@@ -670,8 +841,8 @@ int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_p
         ls_set_error("batched path: too many slices for the tau kernel");
         return LS_ERR_INVALID_ARG;
     }
-#define LS_TAU_LAUNCH(P)                                                                       \
-    hipLaunchKernelGGL(ls_tau_kernel<P>, dim3((unsigned)nq_pad), dim3(256), 0, s, d_sample_top, \
+#define LS_TAU_LAUNCH(P)                                                                      \
+    hipLaunchKernelGGL(ls_tau_kernel<P>, dim3((unsigned)nq_pad), dim3(64), 0, s, d_sample_top, \
                        nsplits, (int)nq, j_rank, d_tau)
     if (nsplits <= 64) LS_TAU_LAUNCH(4);
     else if (nsplits <= 128) LS_TAU_LAUNCH(8);

@@ -20,6 +20,8 @@
 //     shared as they are (same queues, same [query][slice][quarter] layout).
 #include "ls_select_dev.h"
 
+#include <hip/hip_ext.h>
+
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define G32_TM 64       // corpus rows per tile (per slice half)
@@ -184,12 +186,12 @@ __global__ __launch_bounds__(G32_THREADS, 2) void ls_gemm32_filter_kernel(
 int ls_launch_gemm32_filter(const void* d_corpus, int64_t n, const ls_geom& g, const float* d_qp,
                             int64_t nq, int64_t nq_pad, const float* d_tau, int nsplits,
                             int64_t rows_per_split, int tile_stride, const ls_gemm_bufs& b,
-                            hipStream_t s) {
+                            hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int nqt = (int)(nq_pad / G32_BN);
     const dim3 grid((unsigned)(nsplits / 2 * nqt));
-    if (d_tau)
-        hipLaunchKernelGGL((ls_gemm32_filter_kernel<false>), grid, dim3(G32_THREADS), 0, s,
-                           (const float*)d_corpus, (long long)n, d_qp, (int)nq, nqt, g.d_pad, d_tau,
+    if (d_tau)  // (the events ride on the dispatch: no extra packet on the stream)
+        hipExtLaunchKernelGGL((ls_gemm32_filter_kernel<false>), grid, dim3(G32_THREADS), 0, s, ev_start,
+                           ev_stop, 0, (const float*)d_corpus, (long long)n, d_qp, (int)nq, nqt, g.d_pad, d_tau,
                            (long long)rows_per_split, tile_stride, (uint2*)b.d_queues, b.d_counts,
                            b.d_overflow, b.d_sample_top);
     else

@@ -15,7 +15,11 @@ struct ls_req;          // ls_api.hip: one queued synchronous host search
 #define LS_NSETS 2
 #define LS_BC_SLOTS 16
 #ifndef LS_BC_LANES
-#define LS_BC_LANES 2  // internal streams (with their own scratch) that LS_FLAG_PIPELINE batches rotate over
+// Scratch sets that consecutive LS_FLAG_PIPELINE batches rotate over. Four, so that nothing a batch
+// has to wait for is younger than two batches: prep(i+4) rewrites the prepared queries pass(i) read,
+// pass(i+4) the queues select(i) read. (With two, prep(i+2) had to wait for pass(i) itself, and the
+// ~20 us a cross-stream dependency takes to resolve landed between two passes.)
+#define LS_BC_LANES 4
 #endif
 #define LS_BC_SETS (1 + LS_BC_LANES)  // batched scratch sets: 0 = caller's stream, then the lanes
 #define LS_PROF_MAX 4096
@@ -63,10 +67,8 @@ struct ls_index {
     // first call on a second stream synchronises the previous one and switches the set to
     // multi-stream mode, where `done` is recorded behind the last kernel of every call and
     // waited for by the next call's stream (an event record costs a few us of GPU time per
-    // batch: a barrier packet with a release). Sets 1 .. LS_BC_LANES are the internal LANES of
-    // LS_FLAG_PIPELINE calls: consecutive batches rotate over them, each lane on its own
-    // stream, so that one batch's latency-bound small kernels (prep, tau, select) and kernel
-    // boundaries overlap the other batch's MFMA pass.
+    // batch: a barrier packet with a release). Sets 1 .. LS_BC_LANES serve LS_FLAG_PIPELINE calls:
+    // consecutive batches rotate over them (the three-stream chain, batched_search_on_stream).
     struct bc_set {
         void* d_qh = nullptr;      size_t qh_cap = 0;       // bytes: fp16 queries [nq_pad, d_pad]
         u64* d_queues = nullptr;   size_t queues_cap = 0;   // private candidate queues
@@ -74,14 +76,35 @@ struct ls_index {
         float* d_tau = nullptr;    size_t tau_cap = 0;
         u32* d_sample_top = nullptr; size_t sample_top_cap = 0;  // best sample scores per lane
         hipEvent_t done = nullptr;        // set 0, multi-stream mode
-        hipStream_t last_stream = nullptr;
+        hipStream_t last_stream = nullptr;  // where the set's results become final (the select's stream)
         bool used = false;
         bool multi_stream = false;
-        hipStream_t lane_stream = nullptr;  // sets 1 .. LS_BC_LANES
-        hipEvent_t lane_in = nullptr;       // recorded on the caller's stream, waited for by the lane
-        hipEvent_t lane_q = nullptr;        // the lane has consumed the caller's query buffer
-        hipEvent_t lane_out = nullptr;      // orders another stream behind the lane (ls_i_export_flags)
+        // sets 1 .. LS_BC_LANES (LS_FLAG_PIPELINE): the three-stream chain, see batched_search_on_stream
+        bool chain = false;
+        bool pass_recorded = false, sel_recorded = false;  // ev_pass / ev_sel carry a record
+        hipEvent_t ev_prep = nullptr;     // the set's prep kernel is done (recorded on the prep stream)
+        hipEvent_t ev_pass = nullptr;     // the set's filter stage is done (attached to the dispatch)
+        hipEvent_t ev_sel = nullptr;      // the set's select is done (recorded on the select stream)
     } bc_sets[LS_BC_SETS];
+    // one batch between "sample pass + tau queued" and "pass + select queued" (batched_search_on_stream)
+    struct bc_stage {
+        bool active = false;
+        int set_id = 0;
+        bool f32 = false, top2 = false;
+        int64_t nq = 0, nq_pad = 0, rps = 0;
+        int32_t k = 0;
+        int nsplits = 0, sample_stride = 0, jrank = 0, keys_need = 0;
+        u32* d_flags = nullptr;
+        float* d_out_s = nullptr;
+        int64_t* d_out_i = nullptr;
+    } defer;  // the pipelined batch whose pass is held back until the next call (or flush)
+    // LS_FLAG_PIPELINE batches: prep kernels, filter stages (MFMA passes, back to back) and selects each
+    // have their own stream; the scratch sets 1 .. LS_BC_LANES alternate between consecutive batches
+    hipStream_t chain_prep = nullptr, chain_main = nullptr, chain_sel = nullptr;
+    hipEvent_t chain_in = nullptr;        // recorded on the caller's stream, waited for by the prep stream
+    int32_t opt_fused = 1;                // pipelined fp16 batches: the next batch's sample phase rides on the pass launch: 0 never, 1 where it pays, 2 always
+    int32_t opt_chain_abl = 0;            // developer timing ablation of the chain's main-stream waits (debug option 15)
+    int32_t opt_wave_select = 1;          // one-wave select kernel (<= 48 VGPRs) where the shape allows
     uint64_t bc_lane_rr = 0;
     int32_t bc_last_set = 0;  // the set of the most recent batched call (ls_export_flags)
     u32* d_overflow = nullptr; size_t overflow_cap = 0;
@@ -118,7 +141,9 @@ struct ls_index {
     float* d_qpad = nullptr; size_t qpad_cap = 0;  // padded query group (ragged last group)
     long long s_stride = 0;            // floats between the score vectors of one generation
     int32_t opt_multi_query = 1;       // several queries per corpus pass (groups of 8 / 4)
-    int32_t opt_same_launch = 1;       // ordered calls: the selection rides on its own query's scan launch
+    int32_t opt_same_launch = 1;       // synchronous host calls: the selection rides on its own query's scan launch
+    std::vector<ls_fin_params> retry_jobs;  // the same-launch jobs of the host call in flight (LS_DONE_RETRY)
+    uint64_t n_same_launch_retries = 0;     // host calls that had to launch the stand-alone finalize
     u32* d_arrive = nullptr;           // arrival counter of the scan workgroups (same-launch selection)
     u32 arrive_count = 0;              // arrivals queued so far (host mirror; the kernels compare modulo 2^32)
     int32_t max_blocks = 0;
@@ -177,6 +202,7 @@ bool ls_i_batched_eligible(const ls_index* ix, int64_t nq, int32_t k);
 int ls_i_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
                           float* d_out_s, int64_t* d_out_i, hipStream_t s, bool host_api);
 int ls_i_flush_pending(ls_index* ix);
+int ls_i_flush_deferred(ls_index* ix);
 int ls_i_batched_repair(ls_index* ix);
 int ls_i_export_flags(ls_index* ix, void* d_dst, int64_t nq, hipStream_t s);
 

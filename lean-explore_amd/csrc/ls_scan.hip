@@ -227,19 +227,32 @@ __global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void l
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     if ((int)blockIdx.x < nfin) {
         const ls_fin_params& fp = fin.p[blockIdx.x];
+        bool arrived = true;
         if (fp.arrive) {
-            // this launch's own scan workgroups produce the job's input: wait until all of them
-            // have arrived (they never wait for anything, so they always get to run: the first
-            // nfin workgroups of the grid may spin here whatever the occupancy), then acquire
+            // this launch's own scan workgroups produce the job's input: ONE lane polls (relaxed,
+            // sc1) until all of them have arrived; finalize_body then reads their keys with sc1
+            // loads (no acquire fence). The scan workgroups never wait for anything;
+            // should they not get to run while this workgroup holds its slot (a CU-masked stream, a
+            // partitioned device) the wait gives up after 200 ms and asks the host for a retry.
+            u32* flag = reinterpret_cast<u32*>(smem_dyn);
             if (threadIdx.x == 0) {
+                const unsigned long long t0 = wall_clock64();
+                u32 ok = 1;
                 while ((int)(__hip_atomic_load(fp.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                             fp.arrive_target) < 0)
-                    __builtin_amdgcn_s_sleep(8);
+                             fp.arrive_target) < 0) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (wall_clock64() - t0 > LS_ARRIVE_TIMEOUT_TICKS) {
+                        ok = 0;
+                        break;
+                    }
+                }
+                *flag = ok;
             }
             __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            arrived = *flag != 0;
+            __syncthreads();  // smem_dyn is finalize_body's from here on
         }
-        finalize_body<LS_SCAN_THREADS>(fp, smem_dyn, threadIdx.x);
+        finalize_body<LS_SCAN_THREADS>(fp, smem_dyn, threadIdx.x, arrived);
         return;
     }
     const int bid = (int)blockIdx.x - nfin;
@@ -393,11 +406,7 @@ __global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void l
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
                 if (valid) {
-                    if (arrive)
-                        __hip_atomic_store(&S[qi * s_stride + row], sc[qi], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                    else
-                        S[qi * s_stride + row] = sc[qi];
+                    S[qi * s_stride + row] = sc[qi];
                     lst[qi] = ls_make_key(sc[qi], (u32)row);  // this lane's one key of the launch
                 }
             }
@@ -405,13 +414,7 @@ __global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void l
         }
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
-            if (valid) {  // TR contiguous floats
-                if (arrive)  // same-launch selection: write through, nothing left dirty for the release
-                    __hip_atomic_store(&S[qi * s_stride + row], sc[qi], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                else
-                    S[qi * s_stride + row] = sc[qi];
-            }
+            if (valid) S[qi * s_stride + row] = sc[qi];  // TR contiguous floats
             const u64 key = valid ? ls_make_key(sc[qi], (u32)row) : 0ull;
             u64 mask = __ballot(key > thr[qi]);
             while (mask) {  // rare once the threshold has warmed up
@@ -473,18 +476,27 @@ __global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void l
                 rank += (o > mine) || (o == mine && i < lane);
             }
         }
-        if (rank < kprime) cand[qi * c_stride + (long long)bid * kprime + rank] = mine;
-        if (rank == kprime) bound[qi * b_stride + bid] = mine;
+        if (arrive) {
+            // same-launch selection: the keys are the whole hand-off, written THROUGH (sc1) so that
+            // a workgroup behind another XCD's L2 reads them from memory; no release fence
+            if (rank < kprime)
+                __hip_atomic_store(&cand[qi * c_stride + (long long)bid * kprime + rank], mine,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rank == kprime)
+                __hip_atomic_store(&bound[qi * b_stride + bid], mine, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (rank < kprime) cand[qi * c_stride + (long long)bid * kprime + rank] = mine;
+            if (rank == kprime) bound[qi * b_stride + bid] = mine;
+        }
     }
     if (arrive) {
-        // publish: every wave drains its stores, the workgroup meets, ONE lane releases at agent
-        // scope (the selection workgroup may sit on another XCD, behind another L2) and arrives
+        // "drained sc1" hand-off (MI355X_MICROARCH.md, handoff-flag): every wave waits for its
+        // write-through stores, the workgroup meets, ONE lane adds 1 (relaxed, agent scope)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (threadIdx.x == 0)
             __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 #ifdef LS_SCAN_TIMING
     LS_SSTAMP(4);

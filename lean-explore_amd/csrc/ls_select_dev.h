@@ -215,6 +215,59 @@ __device__ __forceinline__ void wave_hist_add(u32* hist, u32 digit, bool active,
     }
 }
 
+// ---- single-wave helpers (ls_wsel.hip, the in-launch tau of ls_gemm.hip): no workgroup barrier ------
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+    for (int o = 32; o >= 1; o >>= 1) v += (u32)__shfl_xor((int)v, o, 64);
+    return v;
+}
+__device__ __forceinline__ u32 wave_max(u32 v) {
+    for (int o = 32; o >= 1; o >>= 1) {
+        const u32 t = (u32)__shfl_xor((int)v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ u32 wave_min(u32 v) {
+    for (int o = 32; o >= 1; o >>= 1) {
+        const u32 t = (u32)__shfl_xor((int)v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+// The wave's histogram (256 bins, lane t holds bins 4t..4t+3 in LDS) -> the bin that holds the
+// krem-th largest counted element; krem becomes the rank inside that bin, *nbin its population.
+__device__ __forceinline__ u32 wave_find_bin(const u32* hist, u32& krem, u32* nbin, int lane) {
+    const uint4 h = reinterpret_cast<const uint4*>(hist)[lane];
+    const u32 mine = h.x + h.y + h.z + h.w;
+    u32 suf = mine;  // inclusive suffix sum over lanes >= lane
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = (u32)__shfl_down((int)suf, o, 64);
+        if (lane + o < 64) suf += t;
+    }
+    const u32 above = suf - mine;
+    const bool here = krem > above && krem <= above + mine;  // exactly one lane (1 <= krem <= total)
+    u32 b = 0, kr = 0, hb = 0;
+    if (here) {
+        u32 cum = above;
+        if (cum + h.w >= krem) { b = 4 * lane + 3; hb = h.w; }
+        else {
+            cum += h.w;
+            if (cum + h.z >= krem) { b = 4 * lane + 2; hb = h.z; }
+            else {
+                cum += h.z;
+                if (cum + h.y >= krem) { b = 4 * lane + 1; hb = h.y; }
+                else { cum += h.y; b = 4 * lane; hb = h.x; }
+            }
+        }
+        kr = krem - cum;
+    }
+    const int src = __ffsll((long long)__ballot(here)) - 1;
+    krem = (u32)__builtin_amdgcn_readlane((int)kr, src);
+    *nbin = (u32)__builtin_amdgcn_readlane((int)hb, src);
+    return (u32)__builtin_amdgcn_readlane((int)b, src);
+}
+
 // Exact top-k of the non-zero keys in keys[0..cnt) (LDS, left untouched) -> res[0..kk) sorted
 // descending, kk = min(k, #non-zero). tmp: LDS scratch of >= 256 keys. k <= LS_RES_CAP.
 // hist: 8 * 256 counters (one histogram per radix pass), misc: 8 * 8 words.
@@ -503,8 +556,10 @@ __host__ __device__ __forceinline__ size_t ls_fin_lds_bytes(int keys_cap, int ke
 }
 
 // One workgroup of NT threads produces the final (scores, rows)[k] of one query.
+// `arrived` = false: a same-launch job whose wait for the scan workgroups timed out.
 template <int NT>
-static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem, int tid) {
+static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem, int tid,
+                                     bool arrived = true) {
     const int keff = (long long)p.k < p.n ? p.k : (int)p.n;
     u64* keys = reinterpret_cast<u64*>(smem);
     u64* res = keys + p.keys_cap;
@@ -519,13 +574,24 @@ static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem
     bool done = (p.n <= 0);
     u64 T = 0;  // k-th best emitted key: a lower bound of the true k-th best key
 
-    if (!done && !p.force_slow && mc >= keff && mc <= p.keys_cap) {
+    if (!done && arrived && !p.force_slow && mc >= keff && mc <= p.keys_cap) {
         u64 mb = 0;  // max over workgroups of the best key each one withheld
-        for (int i = tid; i < p.blocks; i += NT) {
-            const u64 b = p.bound[i];
-            mb = b > mb ? b : mb;
+        if (p.arrive) {
+            // same-launch job: the producers wrote these words through (sc1) and drained them before
+            // arriving; sc1 loads (L1 bypassed) stand in for the agent-scope acquire
+            for (int i = tid; i < p.blocks; i += NT) {
+                const u64 b = __hip_atomic_load(&p.bound[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mb = b > mb ? b : mb;
+            }
+            for (int i = tid; i < mc; i += NT)
+                keys[i] = __hip_atomic_load(&p.cand[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            for (int i = tid; i < p.blocks; i += NT) {
+                const u64 b = p.bound[i];
+                mb = b > mb ? b : mb;
+            }
+            for (int i = tid; i < mc; i += NT) keys[i] = p.cand[i];
         }
-        for (int i = tid; i < mc; i += NT) keys[i] = p.cand[i];
         for (int o = 32; o >= 1; o >>= 1) {
             const u64 other = __shfl_xor(mb, o, 64);
             mb = other > mb ? other : mb;
@@ -539,6 +605,16 @@ static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem
         T = (nvalid == keff && keff > 0) ? res[keff - 1] : 0ull;
         done = (mb == 0ull) || (T != 0ull && mb < T);
         __syncthreads();
+    }
+    if (!done && p.arrive) {
+        // same-launch job: S is not part of the hand-off (see ls_fin_params::arrive). Ask the host
+        // for the stand-alone finalize behind this launch instead of reading S here.
+        if (tid == 0) {  // (the stand-alone finalize counts the slow path in counters[0])
+            if (p.done)
+                __hip_atomic_store(p.done, p.done_val | LS_DONE_RETRY, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
     }
     if (!done) {
         if (tid == 0 && p.counters) atomicAdd(&p.counters[0], 1u);
@@ -568,21 +644,26 @@ static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem
         }
     }
     __syncthreads();
-    for (int i = tid; i < p.k; i += NT) {
-        const u64 key = (i < nvalid) ? res[i] : 0ull;
-        p.out_scores[i] = ls_key_score(key);
-        p.out_indices[i] = ls_key_index(key, p.base);
-    }
     if (p.done) {
-        // completion word for the host API: every wave drains its output stores, the workgroup
-        // meets, then ONE lane releases at system scope and publishes (cdna_hip_programming.md
-        // Guideline 16, with the host as the consumer)
+        // Host API: the outputs are pinned host rows and the host spins on a completion word. The
+        // rows are written THROUGH at system scope, every wave drains them, the workgroup meets and
+        // ONE lane publishes - the drained write-through hand-off with the host as the consumer. No
+        // system-scope release fence: it would write back this XCD's whole L2, which inside a scan
+        // launch holds ~100 KB of freshly written score vector nobody is waiting for.
+        for (int i = tid; i < p.k; i += NT) {
+            const u64 key = (i < nvalid) ? res[i] : 0ull;
+            __hip_atomic_store(&p.out_scores[i], ls_key_score(key), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&p.out_indices[i], (long long)ls_key_index(key, p.base), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(p.done, p.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) __hip_atomic_store(p.done, p.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+        for (int i = tid; i < p.k; i += NT) {
+            const u64 key = (i < nvalid) ? res[i] : 0ull;
+            p.out_scores[i] = ls_key_score(key);
+            p.out_indices[i] = ls_key_index(key, p.base);
         }
     }
     LS_STAMP(5);

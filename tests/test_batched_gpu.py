@@ -433,7 +433,7 @@ def test_launch_counter_counts_and_path_counter():
     if ix.debug_counter(8) == 0:             # (a repaired query would add scan launches)
         assert ix.debug_counter(11) - before == 5
     before = ix.debug_counter(11)
-    ix.debug_option(9, 2)
+    ix.debug_option(9, 1)
     ix.search(q[:1], 10)                     # per-query scan path: ONE launch (selection rides inside)
     assert ix.debug_counter(10) == 1 and ix.debug_counter(11) - before == 1
     ix.debug_option(9, 0)                    # selection as its own launch
@@ -444,12 +444,16 @@ def test_launch_counter_counts_and_path_counter():
     before = ix.debug_counter(11)
     ix.search(q, 10)
     assert ix.debug_counter(10) == 1 and ix.debug_counter(11) - before == 6
-    ix.debug_option(9, 2)                    # same-launch selection: 5 launches
+    # same-launch selection serves the synchronous calls that answer through completion words
+    # (nq <= 16): 12 queries = one group of 8 + one of 4 = 2 launches (3 with its own selection launch)
+    ix.debug_option(9, 1)
     before = ix.debug_counter(11)
-    D1, I1 = ix.search(q, 10)
-    assert ix.debug_counter(11) - before == 5
+    D1, I1 = ix.search(q[:12], 10)
+    assert ix.debug_counter(11) - before == 2 + ix.debug_counter(20)
     ix.debug_option(9, 0)
-    D0, I0 = ix.search(q, 10)
+    before = ix.debug_counter(11)
+    D0, I0 = ix.search(q[:12], 10)
+    assert ix.debug_counter(11) - before == 3
     assert np.array_equal(D0, D1) and np.array_equal(I0, I1)
     ix.close()
 

@@ -6,6 +6,11 @@
 //   E2  does a 64-thread, <= 48-VGPR kernel on a second stream run INSIDE a resident pass-shaped kernel
 //       (512 threads, 229 VGPRs -> 2 waves per SIMD use 464 of the 512 registers, 96 KB LDS)?
 //   E3  does hipExtAnyOrderLaunch lift the in-stream barrier on gfx950?
+//   E5  the chain's main-stream pattern: [waits on events of two other streams that completed long ago but
+//       that the HOST has never observed] big kernel (stop event, waited for by a third stream); small
+//       kernel - what do the wait packets cost when the runtime cannot elide them?
+//   E4  is a hipStreamWaitEvent on a dispatch-attached stop event a real dependency (the waiter must see
+//       what the kernel wrote at its very end)?
 // hipcc --offload-arch=gfx950 -O2 tools/coresidency_probe.hip -o /tmp/coresidency_probe && /tmp/coresidency_probe
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -42,6 +47,15 @@ __global__ __launch_bounds__(64) void small_kernel(unsigned long long ticks, uns
         stamps[2 * blockIdx.x] = t0;
         stamps[2 * blockIdx.x + 1] = wall_clock64();
     }
+}
+
+__global__ void late_writer(unsigned long long ticks, unsigned* flag, unsigned val) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+    if (threadIdx.x == 0 && blockIdx.x == 0) *flag = val;
+}
+__global__ void early_reader(const unsigned* flag, unsigned* seen) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *seen = *flag;
 }
 
 static double now_us() {
@@ -144,6 +158,73 @@ int main() {
         for (int i = 0; i < 1024; ++i) s0 = std::min(s0, hs[2 * i]);
         printf("E3 hipExtAnyOrderLaunch in the SAME stream (%s): small kernel's first wave starts %.1f us %s the big kernel's end\n",
                hipGetErrorString(e), s0 < b1 ? (b1 - s0) / 100.0 : (s0 - b1) / 100.0, s0 < b1 ? "BEFORE" : "after");
+    }
+    // ---- E5: barrier packets the runtime cannot elide ---------------------------------------------------
+    {
+        hipStream_t Pm, Mm, Sm;
+        int least = 0, greatest = 0;
+        CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        CK(hipStreamCreateWithPriority(&Mm, hipStreamNonBlocking, greatest));
+        CK(hipStreamCreateWithPriority(&Pm, hipStreamNonBlocking, (least + greatest) / 2));
+        CK(hipStreamCreateWithPriority(&Sm, hipStreamNonBlocking, least));
+        const int NE = 64;
+        std::vector<hipEvent_t> ep(NE), es(NE), ek(NE);
+        for (int i = 0; i < NE; ++i) {
+            CK(hipEventCreateWithFlags(&ep[i], hipEventDisableTiming));
+            CK(hipEventCreateWithFlags(&es[i], hipEventDisableTiming));
+            CK(hipEventCreateWithFlags(&ek[i], hipEventDisableTiming));
+        }
+        const char* vn[] = {"no waits on the main stream", "waits on 2 old events (unobserved by the host) before each big kernel",
+                            "same, plus the select-like kernel on a third stream behind the big kernel's stop event"};
+        for (int variant = 0; variant < 3; ++variant) {
+            for (int round = 0; round < 2; ++round) {
+                // "old" events: tiny kernels on P and S, recorded, never synchronised by the host
+                for (int i = 0; i < NE; ++i) {
+                    hipLaunchKernelGGL(late_writer, dim3(1), dim3(64), 0, Pm, 1ull, (unsigned*)d_small, 0u);
+                    CK(hipEventRecord(ep[i], Pm));
+                    hipLaunchKernelGGL(late_writer, dim3(1), dim3(64), 0, Sm, 1ull, (unsigned*)d_small + 8, 0u);
+                    CK(hipEventRecord(es[i], Sm));
+                }
+                hipLaunchKernelGGL(big_kernel, dim3(NB), dim3(512), 96 * 1024, Mm, 30000ull, (unsigned long long*)nullptr);  // lets P / S finish first
+                CK(hipEventRecord(t0, Mm));
+                for (int i = 0; i < NE; ++i) {
+                    if (variant >= 1) {
+                        CK(hipStreamWaitEvent(Mm, ep[i], 0));
+                        CK(hipStreamWaitEvent(Mm, es[i], 0));
+                    }
+                    hipExtLaunchKernelGGL(big_kernel, dim3(NB), dim3(512), 96 * 1024, Mm, nullptr, ek[i], 0, T, (unsigned long long*)nullptr);
+                    hipLaunchKernelGGL(small_kernel<40>, dim3(1024), dim3(64), 0, Mm, 300ull, d_small + 64);
+                    if (variant == 2) {
+                        CK(hipStreamWaitEvent(Sm, ek[i], 0));
+                        hipLaunchKernelGGL(small_kernel<40>, dim3(1024), dim3(64), 8 * 1024, Sm, 1500ull, d_small + 4096 - 2048);
+                    }
+                }
+                CK(hipEventRecord(t1, Mm));
+                CK(hipDeviceSynchronize());
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, t0, t1));
+                if (round == 1)
+                    printf("E5 %-100s %.2f us per (100 us kernel + 3 us kernel)\n", vn[variant], ms * 1e3 / NE);
+            }
+        }
+    }
+    // ---- E4: the stop event as a dependency ------------------------------------------------------------
+    {
+        unsigned *d_flag, *d_seen;
+        CK(hipMalloc(&d_flag, 8));
+        CK(hipMalloc(&d_seen, 4 * 64));
+        CK(hipMemset(d_flag, 0, 8));
+        int bad = 0;
+        for (int i = 1; i <= 64; ++i) {
+            hipExtLaunchKernelGGL(late_writer, dim3(256), dim3(64), 0, M, nullptr, ev[i % REP], 0, 3000ull, d_flag, (unsigned)i);
+            CK(hipStreamWaitEvent(S, ev[i % REP], 0));
+            hipLaunchKernelGGL(early_reader, dim3(1), dim3(64), 0, S, (const unsigned*)d_flag, d_seen + (i - 1));
+        }
+        CK(hipDeviceSynchronize());
+        unsigned seen[64];
+        CK(hipMemcpy(seen, d_seen, sizeof(seen), hipMemcpyDeviceToHost));
+        for (int i = 1; i <= 64; ++i) bad += seen[i - 1] != (unsigned)i;
+        printf("E4 reader on stream S behind hipStreamWaitEvent(stopEvent of the 30 us writer on M): %d of 64 readers saw a stale flag\n", bad);
     }
     return 0;
 }

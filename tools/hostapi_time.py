@@ -17,11 +17,11 @@ for (n, d, dt, nq, k) in [(200000, 384, 'f32', 1, 50), (200000, 1024, 'f32', 1, 
                           (200000, 384, 'f32', 8, 50), (200000, 384, 'f16', 1, 50)]:
     c = H.gauss(1234, n, d); q = H.gauss(5678, nq, d)
     ix = FlatIPIndex.from_array(c, dtype=dt)
-    res = {0: [], 2: []}
+    res = {0: [], 1: []}
     for rep in range(3):
-        for mode in (2, 0):
+        for mode in (1, 0):
             ix.debug_option(9, mode)
             res[mode].append(lat(ix, q, k, 300))
     f = lambda v: "/".join(f"{a:.1f}" for a, _ in v)
-    print(f"N={n} d={d} {dt} nq={nq} k={k}: same-launch selection p50 {f(res[2])} us | separate launch p50 {f(res[0])} us", flush=True)
+    print(f"N={n} d={d} {dt} nq={nq} k={k}: same-launch selection p50 {f(res[1])} us | separate launch p50 {f(res[0])} us", flush=True)
     ix.close()

@@ -346,7 +346,7 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
     # the timed region.
     pipelined = world == 1 and nq <= 16 and not inlib
     out_ring = [(torch.empty((nq, k), dtype=torch.float32, device=dev),
-                 torch.empty((nq, k), dtype=torch.int64, device=dev)) for _ in range(16)]
+                 torch.empty((nq, k), dtype=torch.int64, device=dev)) for _ in range(64)]
     step_i = [0]
 
     # N > 1, small batches: the sharded pipeline (local search of step i carries the finalize of
@@ -363,8 +363,8 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
     # region, instead of one host round trip per batch
     batched_async = world == 1 and not pipelined and not env.rehearse and not inlib
 
-    def step():
-        o = out_ring[step_i[0] & 15]
+    def step(profile=False):
+        o = out_ring[step_i[0] & 63]
         step_i[0] += 1
         if inlib:
             # one process, every GPU: the sharded handle queues the local searches on its per-device
@@ -373,7 +373,10 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         if pipelined:
             return local.search_device(tq, k, o[0], o[1], pipeline=True)
         if batched_async:
-            return local.search_device(tq, k, o[0], o[1], pipeline=True)
+            # the profiling pass queues the same batches on ONE stream (LS_FLAG_ASYNC): under
+            # LS_FLAG_PIPELINE the pass launches of the two lanes overlap on purpose, so a pair of
+            # events around one of them also measures its wait for CUs, not the kernel
+            return local.search_device(tq, k, o[0], o[1], pipeline=not profile, asynchronous=profile)
         if sharded_pipe:
             return index.search_device_pipelined(tq, k, exchange_every=EXCHANGE_EVERY)
         return index.search_device(tq, k)
@@ -469,7 +472,7 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
     local.set_profiling(True)
     n_prof = min(steps, 4096 // max(1, min(nq, 16)))
     for _ in range(n_prof):
-        step()
+        step(profile=True)
     drain()
     env.barrier()
     scan_ms_avg, _total = local.last_kernel_ms()
@@ -485,6 +488,10 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         env.exchange_info = local.exchange_info()
     ev_ms = scan_ms_avg
     roof_src = "mean of hipEvent pairs bracketing each launch (second pass of the same steps)"
+    if batched_async:
+        roof_src = ("mean of hipEvent pairs attached to each MFMA-pass dispatch, second pass of the same "
+                    "batches queued on ONE stream (LS_FLAG_ASYNC): in the timed, pipelined run the two "
+                    "lanes' pass launches overlap and a launch's duration includes its wait for CUs")
     if pipelined and nq == 1:
         # one launch per step, back to back on one stream: the timed region's own hipEvents give
         # the average launch duration (kernel boundary included) without per-launch event overhead
@@ -559,7 +566,10 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
                                          + (2 if world > 1 else 0)),
                    "note": "each launch = scan(step i) + one workgroup finalising step i-1"
                    if (pipelined or sharded_pipe) else
-                   ("batched MFMA path: sample pass (+ query prep), tau, MFMA pass, select"
+                   ("batched MFMA path, pipelined: query prep, MFMA pass (+ the sample phase of the "
+                    "batch two calls ahead), tau, select - on two lanes + a select stream"
+                    if (mfma_path and batched_async) else
+                    "batched MFMA path: query prep, sample pass, tau, MFMA pass, select"
                     if mfma_path else "scan + select launches per query")},
         "effective_gbs": round(algorithmic_bytes(n_local, d, elem, nq, k) * steps / dt / 1e9, 1),
         "recall_at_k": recall,

@@ -60,13 +60,15 @@ extern "C" {
                              /* faiss.normalize_L2, search/engine.py:242, into the search)     */
 #define LS_FLAG_ASYNC 2u     /* ls_search_device only: queue and return; results are ordered  */
                              /* on `stream` like any other work queued there                  */
-#define LS_FLAG_PIPELINE 4u  /* ls_search_device only: queue on the index's internal lanes so */
-                             /* that consecutive calls overlap (scan path: the selection step */
-                             /* of one query runs under the scan of the next; batched MFMA    */
-                             /* path: consecutive batches alternate between two internal      */
-                             /* streams with their own scratch, behind whatever `stream` has  */
-                             /* queued so far); results are NOT ordered on `stream` - they    */
-                             /* are valid after ls_check()                                    */
+#define LS_FLAG_PIPELINE 4u  /* ls_search_device only: queue on the index's internal streams  */
+                             /* so that consecutive calls overlap (scan path: the selection   */
+                             /* step of one query runs under the scan of the next; batched    */
+                             /* MFMA path: consecutive batches alternate between two internal */
+                             /* lanes with four scratch sets, behind whatever `stream` has    */
+                             /* queued so far; the MFMA pass of a batch may be queued only    */
+                             /* when the call after next arrives, because it also computes    */
+                             /* that call's sample scores, or at ls_check()); results are NOT */
+                             /* ordered on `stream` - they are valid after ls_check()         */
 
 #define LS_MAX_K 2048 /* same ceiling as FAISS's GPU k-selection; reference uses k = 1000     */
 
@@ -165,8 +167,8 @@ int ls_search_device(ls_index* index, const void* d_q, int64_t nq, int32_t k, ui
  * pipelined search queued since the last ls_check final: queries of batched calls whose
  * speculative threshold let fewer than k rows through, or whose candidate queues overflowed, are
  * re-run here by the exact per-query scan path (from the library's own copy of the queries) and
- * their output rows re-written. Returns LS_OK once everything is exact. Up to 16 batched calls
- * may be outstanding; the 17th triggers the same repair step on its own. */
+ * their output rows re-written. Returns LS_OK once everything is exact. Up to 64 batched calls
+ * may be outstanding; the 65th triggers the same repair step on its own. */
 int ls_check(ls_index* index, void* stream);
 
 /* Copy the per-query verification flags of the most recent search queued on this handle into
@@ -213,11 +215,16 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * option 5: speculative, verified sample threshold on the batched path (default on; off = the
  * certified k-th sample score); option 6: several queries per corpus pass on the scan path
  * (default on); option 7: force the number of scan workgroups per launch (0 = automatic);
- * option 9: ordered (non-pipelined) scan-path calls run the selection step inside the scan launch of
- * its own query, behind an arrival counter of the scan workgroups: 0 never, 1 (default) for launches
- * of at most 200 scan workgroups (small shards), 2 always;
+ * option 9: synchronous host searches (ls_search, nq <= 16) run the selection step inside the scan
+ * launch of its own query, behind an arrival counter of the scan workgroups (fence-free hand-off of the
+ * emitted keys; a query whose keys cannot be proven complete answers "retry" in its completion word
+ * and the host launches the stand-alone selection): 0 off, 1 on (default);
  * option 10: synchronous host searches (ls_search) that arrive while another one is running are
  * served together, up to 16 queries of equal k and flags per corpus pass (default on);
+ * option 13: pipelined fp16 batches let the sample phase of the batch two calls ahead ride on the MFMA
+ * pass launch: 0 never, 1 for stored rows of up to 768 bytes (default), 2 always; option 14: select
+ * step of the batched path as one wave per query in <= 48 registers where the shape allows (k <= 128,
+ * <= 128 corpus slices; runs inside a resident MFMA pass): default on;
  * option 8 (sharded handles): exchange step 0 = RCCL all-gather between distinct devices (default),
  * 1 = peer copies into the primary device's gather buffer; option 11 (sharded handles): one host
  * thread per shard queues that shard's work: -1 automatic (on when the device ids are distinct,
@@ -230,6 +237,7 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * sharded handles: counter 13 exchange steps run, 14 re-exchanges after a shard repaired a
  * query, 15 exchange transport (0 copies, 1 RCCL selected, 2 RCCL communicators initialised, 3 RCCL failed
  * on this node: fell back to peer copies), 19 calls whose shards were queued by the enqueue workers;
+ * counter 20: synchronous host calls that had to launch the stand-alone selection (option 9's retry);
  * counters 0, 1, 8, 11, 12 are summed over the shards, 9 and 10 are the primary shard's;
  * counter 16: combined batches ls_search served, 17: the requests they carried; counter 18 (sharded
  * handles): mean host nanoseconds spent queueing one search (every device's work + exchange + merge).

@@ -217,7 +217,7 @@ void ls_destroy(ls_index* ix) {
     (void)hipFree(ix->d_counters);
     (void)hipFree(ix->d_arrive);
     (void)hipFree(ix->d_qpad);
-    for (hipStream_t cs : {ix->chain_prep, ix->chain_main, ix->chain_sel})
+    for (hipStream_t cs : {ix->chain_main[0], ix->chain_main[1], ix->chain_sel})
         if (cs) (void)hipStreamSynchronize(cs);
     for (auto& st : ix->bc_sets) {
         if (st.ev_prep) (void)hipEventDestroy(st.ev_prep);
@@ -238,7 +238,7 @@ void ls_destroy(ls_index* ix) {
     if (ix->h_out_s) (void)hipHostFree(ix->h_out_s);
     if (ix->h_out_i) (void)hipHostFree(ix->h_out_i);
     for (hipEvent_t e : ix->prof_ev) (void)hipEventDestroy(e);
-    for (hipStream_t cs : {ix->chain_prep, ix->chain_main, ix->chain_sel})
+    for (hipStream_t cs : {ix->chain_main[0], ix->chain_main[1], ix->chain_sel})
         if (cs) (void)hipStreamDestroy(cs);
     if (ix->chain_in) (void)hipEventDestroy(ix->chain_in);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
@@ -643,28 +643,31 @@ static int64_t bc_chunk(const ls_index* ix, int64_t nq, int32_t k) {
 // Kernels of a batch: query prep -> sample pass -> tau -> MFMA pass -> select. Plain calls queue all
 // of it on the caller's stream.
 //
-// LS_FLAG_PIPELINE calls go through the handle's three-stream CHAIN (round 4):
-//   prep stream   : prep(i)            behind the caller's stream (chain_in) and behind the previous
-//                                      readers of the scratch set's prepared queries; a one-wave,
-//                                      37-register kernel that runs INSIDE whatever pass is resident
-//   main stream   : ... pass(i-1)+sample(i) -> tau(i) -> pass(i)+sample(i+1) -> tau(i+1) ...
-//                                      The sample phase of batch i rides at the end of pass i-1's
-//                                      launch (LS_GEMM_FUSED): between two passes remain the tau kernel
-//                                      and two kernel boundaries. For that, batch i's pass is queued
-//                                      when call i+1 arrives (or at the next flush: ls_check, a call
-//                                      of another shape, ls_export_flags, ls_add ...): results of
-//                                      pipelined calls are defined to be valid after ls_check anyway.
-//                                      The main stream waits for prep(i+1) and select(i-2): events that
-//                                      completed long before (a wait on such an event costs nothing)
-//   select stream : select(i)          behind pass(i): the one-wave select kernel (<= 48 VGPRs,
-//                                      ls_wsel.hip) runs INSIDE pass(i+1), in the registers and LDS
-//                                      the pass leaves free, instead of between two passes
-// An event that the critical stream's successor waits for is attached to the dispatch itself
-// (hipExtLaunchKernelGGL): no extra packet between two passes (tools/coresidency_probe.hip: 101.2
-// us per 100 us kernel with or without, 104.3 with hipEventRecord). Cross-stream dependencies take
-// ~15 us to resolve on this runtime (tools/c3_timeline.sh), which is why none of them sits between
-// two passes. Four scratch sets rotate (LS_BC_LANES). Round 3 rotated whole batches over two "lanes": every
-// batch's sample pass, tau kernel and select then sat between two MFMA passes (~25 us).
+// LS_FLAG_PIPELINE calls go through the handle's CHAIN (round 4): four streams, four scratch sets.
+//   prep stream   : prep(i)        behind the caller's stream (chain_in) and behind the previous readers
+//                                  of the scratch set's prepared queries; a one-wave, 37-register
+//                                  kernel that runs INSIDE whatever pass is resident
+//   two main lanes: lane i % 2 runs  ... L(i-2) -> tau(i) -> L(i) -> tau(i+2) -> L(i+2) ...
+//                                  where L(i) = ONE launch: the MFMA pass of batch i, then the sample
+//                                  phase of batch i+2 (LS_GEMM_FUSED). Nothing orders the two lanes:
+//                                  the workgroups of L(i+1) move onto the CUs as those of L(i) retire,
+//                                  so the kernel boundaries around a pass (5 us behind it, 7 us in
+//                                  front), the tau kernel and the lane's event waits all hide under
+//                                  the OTHER lane's pass. For that, batch i's pass is queued when call
+//                                  i+2 arrives (or at the next flush: ls_check, a call of another shape,
+//                                  ls_export_flags, ls_add ...): results of pipelined calls are
+//                                  defined to be valid after ls_check anyway.
+//   select stream : select(i)      behind L(i): the one-wave select kernel (<= 48 VGPRs, ls_wsel.hip)
+//                                  runs INSIDE the passes that follow, in the registers and LDS a
+//                                  pass leaves free, instead of between two passes
+// The event the select stream waits for is attached to the pass's dispatch (hipExtLaunchKernelGGL):
+// no extra packet behind a pass. Measured on the way here (tools/c3_timeline.sh, tools/
+// coresidency_probe.hip, profiles/ab/r04_c3_chain.txt): a cross-stream dependency takes ~15-20 us to
+// resolve on this runtime, a wait packet in front of a pass ~8 us, the boundaries around a pass 5 + 7
+// us - with ONE main stream those sat between two passes (36 us per batch), hence two lanes. Round
+// 3 rotated whole batches over two "lanes" as well, but each lane then ran its own sample pass - the
+// same 8-wave, 96 KB kernel, which could only start on CUs the other lane's pass had left (~25 us
+// per batch).
 static int bc_launch_select(ls_index* ix, const ls_index::bc_stage& b, hipStream_t ss) {
     ls_index::bc_set& st = ix->bc_sets[b.set_id];
     ls_gemm_bufs bufs;
@@ -682,7 +685,7 @@ static int bc_launch_select(ls_index* ix, const ls_index::bc_stage& b, hipStream
 // Queue the MFMA pass and the select of batch `b` (its sample pass and tau are already queued on
 // `sm`). `next` non-null: the pass launch also runs the sample phase of that batch (same plan).
 static int bc_launch_pass_select(ls_index* ix, const ls_index::bc_stage& b, const ls_index::bc_stage* next,
-                                 hipStream_t sm, hipStream_t ss, bool chain) {
+                                 hipStream_t sm, hipStream_t ss, bool tau_next = false) {
     ls_index::bc_set& st = ix->bc_sets[b.set_id];
     const ls_geom& g = ix->g;
     int rc;
@@ -701,12 +704,14 @@ static int bc_launch_pass_select(ls_index* ix, const ls_index::bc_stage& b, cons
         }
         pe = &ix->prof_ev[2 * ix->prof_n];
     }
-    // the pass's events ride on its dispatch: completion for the select stream, and - while
-    // profiling - a timing pair that brackets exactly the kernel
+    // The select of a chain batch runs on the chain's select stream, behind an event attached to the
+    // pass's dispatch (no extra packet in the lane). While profiling, a timing pair rides there
+    // instead and brackets exactly the kernel.
+    const bool xsel = ss != sm;
     hipEvent_t const ev_start = prof ? pe[0] : nullptr;
-    hipEvent_t const ev_stop = prof ? pe[1] : (chain ? st.ev_pass : nullptr);
-    // the set's previous select has read the queues this pass refills
-    if (chain && st.sel_recorded && !(ix->opt_chain_abl & 1)) LS_HIP(hipStreamWaitEvent(sm, st.ev_sel, 0));
+    hipEvent_t const ev_stop = prof ? pe[1] : (xsel ? st.ev_pass : nullptr);
+    // the set's previous select (four batches ago) has read the queues this pass refills
+    if (xsel && st.sel_recorded) LS_HIP(hipStreamWaitEvent(sm, st.ev_sel, 0));
     if (b.f32) {
         rc = ls_launch_gemm32_filter(ix->d_corpus, ix->n, g, (const float*)st.d_qh, b.nq, b.nq_pad,
                                      st.d_tau, b.nsplits, b.rps, 1, bufs, sm, ev_start, ev_stop);
@@ -726,16 +731,20 @@ static int bc_launch_pass_select(ls_index* ix, const ls_index::bc_stage& b, cons
     if (rc != LS_OK) return rc;
     ix->n_launches_total++;
     if (prof) {
-        if (chain) LS_HIP(hipEventRecord(st.ev_pass, sm));  // (profiling pass only: its own packet)
+        if (xsel) LS_HIP(hipEventRecord(st.ev_pass, sm));  // (profiling pass only: its own packet)
         ix->prof_n++;
     }
-    if (chain) {
-        st.pass_recorded = true;
-        LS_HIP(hipStreamWaitEvent(ss, st.ev_pass, 0));
+    if (tau_next) {  // the rider's tau goes in front of this batch's select: it is the lane's critical kernel
+        ls_index::bc_set& sn = ix->bc_sets[next->set_id];
+        if ((rc = ls_launch_tau(sn.d_sample_top, next->nsplits, next->nq, next->nq_pad, next->jrank,
+                                sn.d_tau, sm)) != LS_OK)
+            return rc;
+        ix->n_launches_total++;
     }
+    if (xsel) LS_HIP(hipStreamWaitEvent(ss, st.ev_pass, 0));
     if ((rc = bc_launch_select(ix, b, ss)) != LS_OK) return rc;
     ix->n_launches_total++;
-    if (chain) {
+    if (xsel) {
         LS_HIP(hipEventRecord(st.ev_sel, ss));
         st.sel_recorded = true;
     }
@@ -743,11 +752,14 @@ static int bc_launch_pass_select(ls_index* ix, const ls_index::bc_stage& b, cons
     return LS_OK;
 }
 
-// The pipelined batch whose pass is still held back (see above): queue its pass and select now.
+// The pipelined batches whose passes are still held back (see above): queue their passes and selects now.
 int ls_i_flush_deferred(ls_index* ix) {
-    if (!ix->defer.active) return LS_OK;
-    ix->defer.active = false;
-    return bc_launch_pass_select(ix, ix->defer, nullptr, ix->chain_main, ix->chain_sel, true);
+    while (!ix->held.empty()) {
+        const ls_index::bc_stage h = ix->held.front();
+        ix->held.pop_front();
+        if (int rc = bc_launch_pass_select(ix, h, nullptr, ix->chain_main[h.lane], ix->chain_sel)) return rc;
+    }
+    return LS_OK;
 }
 
 static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k,
@@ -769,24 +781,23 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     }
     const bool chain = (flags & LS_FLAG_PIPELINE) != 0;
     if (!chain && (rc = ls_i_flush_deferred(ix)) != LS_OK) return rc;
-    const int set_id = chain ? 1 + (int)(ix->bc_lane_rr++ % LS_BC_LANES) : 0;
+    const uint64_t seq = chain ? ix->bc_lane_rr++ : 0;
+    const int lane = (int)(seq & 1);  // LS_BC_LANES is even: a scratch set always belongs to one lane
+    const int set_id = chain ? 1 + (int)(seq % LS_BC_LANES) : 0;
     ls_index::bc_set& st = ix->bc_sets[set_id];
     hipStream_t const caller = s;
     hipStream_t sp = s, sm = s, ss = s;  // prep / sample, tau, pass / select
     if (chain) {
-        if (!ix->chain_prep) {
-            // Three streams that must NOT share a hardware queue: the runtime multiplexes a process's
-            // streams over four queues per priority class in creation order, and two of the chain's
-            // streams on one queue run in submission order - select(i), which waits for pass(i), then
-            // holds back tau(i+1) and pass(i+1) behind it (seen in a kernel trace: main and select
-            // stream both on queue 4, 76 us between two passes). One stream per priority class gets
-            // each its own queue, and the order is the useful one: passes first, selects last.
+        if (!ix->chain_main[0]) {
+            // (two streams of one priority class are given two hardware queues, in creation order;
+            // kernel traces show them as queues 3 and 4)
             int least = 0, greatest = 0;
             LS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            LS_HIP(hipStreamCreateWithPriority(&ix->chain_main, hipStreamNonBlocking, greatest));
-            LS_HIP(hipStreamCreateWithPriority(&ix->chain_prep, hipStreamNonBlocking,
-                                               (least + greatest) / 2));
-            LS_HIP(hipStreamCreateWithPriority(&ix->chain_sel, hipStreamNonBlocking, least));
+            LS_HIP(hipStreamCreateWithPriority(&ix->chain_main[0], hipStreamNonBlocking, greatest));
+            LS_HIP(hipStreamCreateWithPriority(&ix->chain_main[1], hipStreamNonBlocking, greatest));
+            // the selects' own stream, in the same class: a lower class is starved for as long as
+            // workgroups of a pass are waiting for CUs, which with two lanes is always
+            LS_HIP(hipStreamCreateWithPriority(&ix->chain_sel, hipStreamNonBlocking, greatest));
             LS_HIP(hipEventCreateWithFlags(&ix->chain_in, hipEventDisableTiming));
         }
         if (!st.ev_prep) {
@@ -794,8 +805,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
             LS_HIP(hipEventCreateWithFlags(&st.ev_pass, hipEventDisableTiming));
             LS_HIP(hipEventCreateWithFlags(&st.ev_sel, hipEventDisableTiming));
         }
-        sp = ix->chain_prep;
-        sm = ix->chain_main;
+        sp = sm = ix->chain_main[lane];
         ss = ix->chain_sel;
     } else if (st.used && st.last_stream != s) {
         // set 0 is shared by plain calls: a call on another stream waits for the previous one
@@ -840,6 +850,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
 
     ls_index::bc_stage b;
     b.active = true;
+    b.lane = lane;
     b.set_id = set_id;
     b.f32 = f32;
     b.nq = nq;
@@ -867,10 +878,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         // behind everything the caller has queued so far (its queries) ...
         LS_HIP(hipEventRecord(ix->chain_in, caller));
         LS_HIP(hipStreamWaitEvent(sp, ix->chain_in, 0));
-        // ... and behind the passes that read the set's prepared queries: the set's own previous
-        // pass (four batches ago), and - its fused sample phase - the pass queued just before that
-        // one on the same stream. The held-back batch's pass is not queued yet; it reads another set.
-        if (st.pass_recorded) LS_HIP(hipStreamWaitEvent(sp, st.ev_pass, 0));
+        // (everything else that touches the set is earlier work of this very lane: stream order)
     }
     rc = f32 ? ls_launch_prep_f32(d_q, (float*)st.d_qh, d_qkeep, nq, nq_pad, g,
                                   (flags & LS_FLAG_NORMALIZE) != 0, d_flags, sp)
@@ -883,39 +891,47 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         // repair copy): work the caller queues on its stream from here on may overwrite it
         LS_HIP(hipEventRecord(st.ev_prep, sp));
         LS_HIP(hipStreamWaitEvent(caller, st.ev_prep, 0));
-        if (!(ix->opt_chain_abl & 2)) LS_HIP(hipStreamWaitEvent(sm, st.ev_prep, 0));
     }
     // ---- sample pass: a few tiles of every slice, spread over the slice ------------------------------
-    // Pipelined fp16 batches of one plan: the sample phase rides on the held-back batch's pass launch
-    // (the register-starved geometries - config 4's 1.5 KiB rows - spend ~1 % of a multi-millisecond
-    // batch between passes and keep their own sample launch)
+    // Pipelined fp16 batches of one plan: the sample phase rides on the pass launch of the batch TWO
+    // calls back, which is held until now for that (the register-starved geometries - config 4's
+    // 1.5 KiB rows - spend ~1 % of a multi-millisecond batch between passes and keep their own
+    // sample launch)
     const bool fuse_ok = chain && !f32 && (ix->opt_fused == 2 || (ix->opt_fused == 1 && g.chunks <= 48));
-    const ls_index::bc_stage& d = ix->defer;
-    const bool ride = fuse_ok && d.active && !d.f32 && d.nq_pad == nq_pad && d.k == k &&
-                      d.nsplits == nsplits && d.rps == b.rps && d.sample_stride == b.sample_stride &&
-                      d.jrank == b.jrank && d.top2 == b.top2 && d.set_id != set_id;
+    bool ride = false;
+    if (fuse_ok && ix->held.size() == 2) {
+        const ls_index::bc_stage& d = ix->held.front();
+        ride = d.lane == lane && d.nq_pad == nq_pad && d.k == k && d.nsplits == nsplits && d.rps == b.rps &&
+               d.sample_stride == b.sample_stride && d.jrank == b.jrank && d.top2 == b.top2 &&
+               d.set_id != set_id;
+    }
     if (ride) {
-        ix->defer.active = false;
-        if ((rc = bc_launch_pass_select(ix, d, &b, sm, ss, true)) != LS_OK) return rc;
+        const ls_index::bc_stage d = ix->held.front();
+        ix->held.pop_front();
+        if ((rc = bc_launch_pass_select(ix, d, &b, sm, ss, true)) != LS_OK) return rc;  // + tau(this batch)
     } else {
-        if ((rc = ls_i_flush_deferred(ix)) != LS_OK) return rc;
+        // nothing to ride on (the first two batches of a run, another shape, a geometry that does not
+        // fuse): a full pipeline is flushed, and the sample pass gets its own launch
+        if (!fuse_ok || ix->held.size() == 2) {
+            if ((rc = ls_i_flush_deferred(ix)) != LS_OK) return rc;
+        }
         rc = f32 ? ls_launch_gemm32_filter(ix->d_corpus, ix->n, g, (const float*)st.d_qh, nq, nq_pad,
                                            nullptr, nsplits, b.rps, b.sample_stride, bufs, sm)
                  : ls_launch_gemm_filter(ix->d_corpus, ix->n, g, st.d_qh, nq, nq_pad, nullptr, nsplits,
                                          b.rps, b.sample_stride, bufs, b.top2, sm);
         if (rc != LS_OK) return rc;
         ++launches;
+        if ((rc = ls_launch_tau(st.d_sample_top, nsplits, nq, nq_pad, b.jrank, st.d_tau, sm)) != LS_OK)
+            return rc;
+        ++launches;
     }
-    if ((rc = ls_launch_tau(st.d_sample_top, nsplits, nq, nq_pad, b.jrank, st.d_tau, sm)) != LS_OK)
-        return rc;
-    ++launches;
-    // ---- pass + select: now, or (pipelined fp16 batches) with the next call / the next flush ---------
+    // ---- pass + select: now, or (pipelined fp16 batches) two calls from now / at the next flush -----
     const bool hold = fuse_ok;
     if (hold) {
-        ix->defer = b;
+        ix->held.push_back(b);
     } else {
         const uint64_t before = ix->n_launches_total;
-        if ((rc = bc_launch_pass_select(ix, b, nullptr, sm, ss, chain)) != LS_OK) return rc;
+        if ((rc = bc_launch_pass_select(ix, b, nullptr, sm, ss)) != LS_OK) return rc;
         launches += (int)(ix->n_launches_total - before);
         ix->n_launches_total = before;
     }
@@ -923,7 +939,9 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     st.chain = chain;
     st.last_stream = ss;
     ix->bc_last_set = set_id;
-    ix->n_batched_launches = launches + (hold ? 2 : 0);  // (a held-back batch: its pass and select follow)
+    // kernels of THIS batch (a held-back batch: its pass and select follow; a rider's tau was queued
+    // with the carrying pass)
+    ix->n_batched_launches = launches + (hold ? 2 : 0) + (ride ? 1 : 0);
     ix->n_launches_total += (uint64_t)launches;
     ix->last_path = f32 ? 3 : 2;
     ix->d_last_flags = d_flags;
@@ -1500,10 +1518,6 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
     }
     if (which == 13) {  // fused filter launch (sample phase + tau + MFMA pass): 0 off, 1 where it pays (default), 2 always
         ix->opt_fused = value < 0 ? 0 : (value > 2 ? 2 : value);
-        return LS_OK;
-    }
-    if (which == 15) {  // timing ablation (results may be wrong): bit 0 / 1 drop the main stream's waits for select / prep
-        ix->opt_chain_abl = value;
         return LS_OK;
     }
     if (which == 14) {  // one-wave select kernel (co-resident with a running pass): default on

@@ -13,7 +13,7 @@ struct ls_shard_group;  // ls_shard.hip
 struct ls_req;          // ls_api.hip: one queued synchronous host search
 
 #define LS_NSETS 2
-#define LS_BC_SLOTS 16
+#define LS_BC_SLOTS 64  // unchecked batched calls a handle carries before it checks them itself (a check drains the pipeline)
 #ifndef LS_BC_LANES
 // Scratch sets that consecutive LS_FLAG_PIPELINE batches rotate over. Four, so that nothing a batch
 // has to wait for is younger than two batches: prep(i+4) rewrites the prepared queries pass(i) read,
@@ -81,15 +81,15 @@ struct ls_index {
         bool multi_stream = false;
         // sets 1 .. LS_BC_LANES (LS_FLAG_PIPELINE): the three-stream chain, see batched_search_on_stream
         bool chain = false;
-        bool pass_recorded = false, sel_recorded = false;  // ev_pass / ev_sel carry a record
-        hipEvent_t ev_prep = nullptr;     // the set's prep kernel is done (recorded on the prep stream)
-        hipEvent_t ev_pass = nullptr;     // the set's filter stage is done (attached to the dispatch)
+        bool sel_recorded = false;        // ev_sel carries a record
+        hipEvent_t ev_prep = nullptr;     // the set's prep kernel is done: the caller may reuse its query buffer
+        hipEvent_t ev_pass = nullptr;     // the set's pass is done (attached to its dispatch): the select may start
         hipEvent_t ev_sel = nullptr;      // the set's select is done (recorded on the select stream)
     } bc_sets[LS_BC_SETS];
     // one batch between "sample pass + tau queued" and "pass + select queued" (batched_search_on_stream)
     struct bc_stage {
         bool active = false;
-        int set_id = 0;
+        int set_id = 0, lane = 0;
         bool f32 = false, top2 = false;
         int64_t nq = 0, nq_pad = 0, rps = 0;
         int32_t k = 0;
@@ -97,13 +97,14 @@ struct ls_index {
         u32* d_flags = nullptr;
         float* d_out_s = nullptr;
         int64_t* d_out_i = nullptr;
-    } defer;  // the pipelined batch whose pass is held back until the next call (or flush)
+    };
+    std::deque<bc_stage> held;  // pipelined batches whose pass is held back (at most two: see batched_search_on_stream)
     // LS_FLAG_PIPELINE batches: prep kernels, filter stages (MFMA passes, back to back) and selects each
     // have their own stream; the scratch sets 1 .. LS_BC_LANES alternate between consecutive batches
-    hipStream_t chain_prep = nullptr, chain_main = nullptr, chain_sel = nullptr;
+    hipStream_t chain_main[2] = {nullptr, nullptr};  // the chain's two lanes
+    hipStream_t chain_sel = nullptr;                 // ... and its select stream
     hipEvent_t chain_in = nullptr;        // recorded on the caller's stream, waited for by the prep stream
     int32_t opt_fused = 1;                // pipelined fp16 batches: the next batch's sample phase rides on the pass launch: 0 never, 1 where it pays, 2 always
-    int32_t opt_chain_abl = 0;            // developer timing ablation of the chain's main-stream waits (debug option 15)
     int32_t opt_wave_select = 1;          // one-wave select kernel (<= 48 VGPRs) where the shape allows
     uint64_t bc_lane_rr = 0;
     int32_t bc_last_set = 0;  // the set of the most recent batched call (ls_export_flags)

@@ -12,7 +12,8 @@
 //
 // One wave per query, no workgroup barrier anywhere; LDS (wave-private): keys[1024] | surv[128] |
 // hist[256]. Shapes it serves: k <= 128, at most 1024 candidate keys (the plan's +5 sigma
-// estimate) and at most 1024 queues per query; everything else keeps ls_batch_select_kernel.
+// estimate) and at most 128 corpus slices (512 queues per query); everything else keeps
+// ls_batch_select_kernel.
 #include "ls_select_dev.h"
 
 #include <hip/hip_ext.h>
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(48))) void ls_wa
 }
 
 bool ls_wave_select_ok(int nsplits, int k, int keys_need) {
-    return k <= LS_WSEL_MAXK && keys_need <= LS_WSEL_KEYS && nsplits * 4 <= 1024;
+    // (up to 8 queues per lane: the 16-per-lane instantiation needs 58 registers and would not fit beside a pass)
+    return k <= LS_WSEL_MAXK && keys_need <= LS_WSEL_KEYS && nsplits <= 128;
 }
 
 int ls_launch_wave_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k, int64_t base, int64_t n,
@@ -196,8 +198,7 @@ int ls_launch_wave_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k,
                           (long long)base, (long long)n, (long long)rows_per_split, b.d_overflow,      \
                           d_out_scores, (long long*)d_out_indices)
     if (nsplits <= 64) LS_WSEL_LAUNCH(4);
-    else if (nsplits <= 128) LS_WSEL_LAUNCH(8);
-    else LS_WSEL_LAUNCH(16);
+    else LS_WSEL_LAUNCH(8);
 #undef LS_WSEL_LAUNCH
     LS_HIP(hipGetLastError());
     return LS_OK;

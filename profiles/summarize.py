@@ -9,8 +9,10 @@ read side is doubled. WRITE_SIZE is taken as reported (uncalibrated on this part
 the traffic here).
 
 The counters are those of the DOMINANT kernel only, matched by its full template instantiation:
-the batched path launches ls_gemm_filter_kernel twice per batch (sample pass `<.., true>`, full
-pass `<.., false>`); only the full pass is the roofline kernel."""
+the batched path's ls_gemm_filter_kernel has three instantiations per geometry, told apart by the last
+template argument: `, 0>` the MFMA pass alone (bench.py's profiling pass, one stream: the roofline
+kernel), `, 1>` the stand-alone sample pass, `, 2>` the pipelined run's pass + next batch's sample
+phase (two lanes overlap: its begin-to-end time includes waiting for CUs)."""
 
 import csv
 import glob
@@ -26,7 +28,7 @@ dst = ROOT / "gpurun_out" / "profiles"  # copied back by gpurun; then moved into
 dst.mkdir(parents=True, exist_ok=True)
 
 DOMINANT = {  # substring(s) that must ALL appear in the kernel name
-    "c3": ("ls_gemm_filter_kernel", ", false>"), "c4": ("ls_gemm_filter_kernel", ", false>"),
+    "c3": ("ls_gemm_filter_kernel", ", 0>"), "c4": ("ls_gemm_filter_kernel", ", 0>"),
     "bm25": ("bm25_score_kernel",),
 }
 need = DOMINANT.get(wl, ("ls_scan_kernel",))

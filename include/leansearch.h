@@ -167,8 +167,8 @@ int ls_search_device(ls_index* index, const void* d_q, int64_t nq, int32_t k, ui
  * pipelined search queued since the last ls_check final: queries of batched calls whose
  * speculative threshold let fewer than k rows through, or whose candidate queues overflowed, are
  * re-run here by the exact per-query scan path (from the library's own copy of the queries) and
- * their output rows re-written. Returns LS_OK once everything is exact. Up to 64 batched calls
- * may be outstanding; the 65th triggers the same repair step on its own. */
+ * their output rows re-written. Returns LS_OK once everything is exact. Up to 128 batched calls
+ * may be outstanding; the 129th triggers the same repair step on its own. */
 int ls_check(ls_index* index, void* stream);
 
 /* Copy the per-query verification flags of the most recent search queued on this handle into

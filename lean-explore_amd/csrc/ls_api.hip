@@ -403,7 +403,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         const int own_keys_cap = std::max(256, blocks * kprime);
         const bool same_launch =
             !pipeline && ix->n > 0 && ix->opt_same_launch != 0 && ix->done_base != nullptr &&
-            s == ix->own_stream &&
+            s == ix->own_stream && keff <= 256 &&  // (k > 256 orders its result on 1024 threads: own launch)
             ls_fin_lds_bytes_host(own_keys_cap, (int)std::max<int64_t>(keff, 1)) <= LS_PIGGY_LDS_MAX;
         if (ix->n_pending && same_launch) {  // left by an earlier pipelined call: its own launch
             rc = ls_i_flush_pending(ix);

@@ -13,7 +13,7 @@ struct ls_shard_group;  // ls_shard.hip
 struct ls_req;          // ls_api.hip: one queued synchronous host search
 
 #define LS_NSETS 2
-#define LS_BC_SLOTS 64  // unchecked batched calls a handle carries before it checks them itself (a check drains the pipeline)
+#define LS_BC_SLOTS 128  // unchecked batched calls a handle carries before it checks them itself (a check drains the pipeline)
 #ifndef LS_BC_LANES
 // Scratch sets that consecutive LS_FLAG_PIPELINE batches rotate over. Four, so that nothing a batch
 // has to wait for is younger than two batches: prep(i+4) rewrites the prepared queries pass(i) read,

@@ -285,10 +285,33 @@ __device__ unsigned long long g_fin_stamp[8];
 #else
 #define LS_STAMP(i) do {} while (0)
 #endif
-static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* tmp, u32* hist, u32* misc,
+static __device__ __forceinline__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* tmp, u32* hist, u32* misc,
                         int tid, int nt) {
     if (k > cnt) k = cnt;
     if (k <= 0) return 0;
+    if (cnt <= 256 && cnt <= nt) {
+        // A handful of keys (the pre-filtered candidates of a small k, a merge of short lists): rank
+        // every key by counting and keep the ranks below k - one barrier instead of the ~15 of the
+        // radix passes. Keys of value 0 ("no result") rank behind every real key.
+        const int G = (cnt * 4 <= nt) ? 4 : 1;
+        const int me = tid / G, part = tid % G;
+        u64 mine = 0;
+        int rank = 0;
+        if (me < cnt) {
+            mine = keys[me];
+#pragma unroll 8
+            for (int j = part; j < cnt; j += G) rank += keys[j] > mine;
+        }
+        if (G >= 2) rank += __shfl_xor(rank, 1, 64);
+        if (G == 4) rank += __shfl_xor(rank, 2, 64);
+        const int nnz = __syncthreads_count(me < cnt && part == 0 && mine != 0ull);
+        if (me < cnt && part == 0 && mine != 0ull && rank < k) res[rank] = mine;
+        __syncthreads();
+        LS_STAMP(3);
+        LS_STAMP(4);
+        LS_STAMP(5);
+        return k < nnz ? k : nnz;
+    }
     const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
     const int cnt_pad = (cnt + 63) & ~63;  // whole waves take part in the ballots
     // ---- range of the score halves + number of non-zero keys (one pass, no atomics) ---------
@@ -356,7 +379,7 @@ static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* t
         // threshold that admits exactly kk keys, so the remaining passes are skipped
         if (neq == krem) break;
     }
-    LS_STAMP(2);
+    LS_STAMP(3);
     const u32 T_hi = pref;
     u32 T_lo = 0;
     if (neq > krem) {  // several candidates share the k-th score: split them on the row half
@@ -419,10 +442,63 @@ static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* t
         T_lo = lpref;
     }
     const u64 T = ((u64)T_hi << 32) | (u64)T_lo;  // exactly kk non-zero keys are >= T
+    // ---- kk > 256: bucket the survivors by the FIRST radix digit, rank inside the buckets ----------
+    // The first pass's histogram already says how many survivors each of its 256 bins holds (every
+    // key of a bin above the selected one; the selected bin's share is that pass's remaining rank),
+    // so a suffix sum gives every bucket its slot range, one LDS atomic per survivor scatters it
+    // there, and a survivor's final rank is its bucket's first slot + the number of LARGER keys in
+    // its own bucket - tens of LDS reads instead of the 55 stages of a 1024-key bitonic network
+    // (10 us of the 24.8 us stand-alone selection at k = 1000). Buckets that would be walked for
+    // too long (a few distinct scores: BM25, all-equal corpora) fall back to the sorting network.
+    bool bucketed = false;
+    u32* const bstart = hist + 1 * 256;  // the later passes' histograms are dead once T is known
+    u32* const bcur = hist + 2 * 256;
+    const int shift0 = hb >= 7 ? hb - 7 : 0;
+    const u32 dmask0 = hb >= 7 ? 255u : (hb >= 0 ? ((2u << hb) - 1u) : 0u);
+    if (kk > 256 && npass > 0) {
+        if (tid < 64) {
+            const u32 bin0 = misc[0], need0 = misc[1];  // pass 0: selected bin, survivors it contributes
+            u32 sz[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const u32 b = 4u * tid + e;
+                sz[e] = b > bin0 ? hist[b] : (b == bin0 ? need0 : 0u);
+            }
+            const u32 mine = sz[0] + sz[1] + sz[2] + sz[3];
+            u32 suf = mine;  // inclusive suffix sum over lanes >= tid
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 t = (u32)__shfl_down((int)suf, o, 64);
+                if (tid + o < 64) suf += t;
+            }
+            u32 at = suf - mine;  // survivors in higher bins
+            u32 big = 0;
+#pragma unroll
+            for (int e = 3; e >= 0; --e) {
+                bstart[4 * tid + e] = at;
+                bcur[4 * tid + e] = 0u;
+                at += sz[e];
+                big = sz[e] > big ? sz[e] : big;
+            }
+            for (int o = 32; o >= 1; o >>= 1) {
+                const u32 t = (u32)__shfl_xor((int)big, o, 64);
+                big = t > big ? t : big;
+            }
+            if (tid == 0) misc[7 * 8 + 6] = big;
+        }
+        __syncthreads();
+        bucketed = misc[7 * 8 + 6] <= 192u;
+    }
     u64* dst = (kk <= 256) ? tmp : res;
     for (int i = tid; i < cnt_pad; i += nt) {  // one LDS atomic per wave and step
         const u64 key = i < cnt ? keys[i] : 0ull;
         const bool keep = key != 0ull && key >= T;
+        if (bucketed) {
+            if (keep) {
+                const u32 b = ((u32)(key >> 32) >> shift0) & dmask0;
+                res[bstart[b] + atomicAdd(&bcur[b], 1u)] = key;
+            }
+            continue;
+        }
         const u64 bal = __ballot(keep);
         if (bal) {
             u32 base = 0;
@@ -432,7 +508,7 @@ static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* t
         }
     }
     __syncthreads();
-    LS_STAMP(3);
+    LS_STAMP(4);
     if (kk <= 256) {  // order by counting: rank = number of larger survivors
         // with threads to spare, 4 of them share one survivor (each counts a slice of the others;
         // the slices are summed by lane shuffles): the serial LDS walk is kk / 4 long
@@ -442,11 +518,37 @@ static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* t
         int rank = 0;
         if (me < kk) {
             mine = tmp[me];
+#pragma unroll 8
             for (int j = part; j < kk; j += G) rank += tmp[j] > mine;
         }
         if (G >= 2) rank += __shfl_xor(rank, 1, 64);
         if (G == 4) rank += __shfl_xor(rank, 2, 64);
         if (me < kk && part == 0) res[rank] = mine;
+        __syncthreads();
+    } else if (bucketed) {
+        constexpr int E = LS_RES_CAP / 256;  // survivors per thread at most (256 threads, k = 2048)
+        u64 mine[E];
+        int rank[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = tid + e * nt;
+            mine[e] = 0ull;
+            rank[e] = 0;
+            if (i < kk) {
+                const u64 key = res[i];
+                const u32 b = ((u32)(key >> 32) >> shift0) & dmask0;
+                const int lo = (int)bstart[b], n = (int)bcur[b];
+                int r = lo;
+#pragma unroll 8
+                for (int j = lo; j < lo + n; ++j) r += res[j] > key;  // (independent LDS reads: keep 8 in flight)
+                mine[e] = key;
+                rank[e] = r;
+            }
+        }
+        __syncthreads();  // every bucket has been read: the ordered keys go back in place
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (tid + e * nt < kk) res[rank[e]] = mine[e];
         __syncthreads();
     } else {
         const int m = next_pow2(kk);
@@ -456,7 +558,7 @@ static __device__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* t
         else if (nt == 256) lds_sort_desc<256>(res, m, tid);
         else block_bitonic_desc(res, m, tid, nt);
     }
-    LS_STAMP(4);
+    LS_STAMP(5);
     return kk;
 }
 
@@ -575,33 +677,126 @@ static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem
     u64 T = 0;  // k-th best emitted key: a lower bound of the true k-th best key
 
     if (!done && arrived && !p.force_slow && mc >= keff && mc <= p.keys_cap) {
-        u64 mb = 0;  // max over workgroups of the best key each one withheld
-        if (p.arrive) {
-            // same-launch job: the producers wrote these words through (sc1) and drained them before
-            // arriving; sc1 loads (L1 bypassed) stand in for the agent-scope acquire
-            for (int i = tid; i < p.blocks; i += NT) {
-                const u64 b = __hip_atomic_load(&p.bound[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mb = b > mb ? b : mb;
-            }
-            for (int i = tid; i < mc; i += NT)
-                keys[i] = __hip_atomic_load(&p.cand[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            for (int i = tid; i < p.blocks; i += NT) {
-                const u64 b = p.bound[i];
-                mb = b > mb ? b : mb;
-            }
-            for (int i = tid; i < mc; i += NT) keys[i] = p.cand[i];
+        // Same-launch jobs: the producers wrote these words through (sc1) and drained them before
+        // arriving; sc1 loads (L1 bypassed) stand in for the agent-scope acquire.
+        auto ld = [&](const u64* a) -> u64 {
+            return p.arrive ? __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *a;
+        };
+        // ---- pivot: a lower bound of the k-th best key from ONE entry per workgroup ---------------------
+        // Every scan workgroup emitted its keys best first. Take the m-th key of each (m = keys a
+        // workgroup must contribute on average, ceil(k / blocks): 1 for k = 50 over 448 workgroups) and
+        // let P be the r-th largest of these pivots, r = ceil(k / m): at least r workgroups then hold m
+        // keys >= P, i.e. >= k keys >= P, so the k-th best key is >= P and everything below P can be
+        // dropped before any selection work: ~60 of the 2240 candidates survive for config 2, a third
+        // for k = 1000. One wave finds P in registers (bit-wise search on the score half, counting by
+        // ballots); the other waves' candidate loads are in flight meanwhile.
+        const int m_need = (keff + p.blocks - 1) / p.blocks;
+        const bool prefilter = p.blocks >= 64 && p.blocks <= 1024 && m_need <= p.kprime;
+        // (loads return in order: the pivots go out first, so the wave that needs them does not wait
+        // for its share of the candidates as well)
+        u32 pv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int b = tid + 64 * j;
+            pv[j] = (prefilter && tid < 64 && b < p.blocks)
+                        ? (u32)(ld(&p.cand[(long long)b * p.kprime + (m_need - 1)]) >> 32) : 0u;
         }
+        u64 mb = 0;  // max over workgroups of the best key each one withheld
+        for (int i = tid; i < p.blocks; i += NT) {
+            const u64 b = ld(&p.bound[i]);
+            mb = b > mb ? b : mb;
+        }
+        // candidate keys: CH per thread and round in registers (config 2: one round of 9 on 256
+        // threads), the first round's loads in flight while the pivot is being found
+        constexpr int CH = LS_FINAL_CAP / NT < 16 ? LS_FINAL_CAP / NT : 16;
+        u64 mine[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int i = tid + j * NT;
+            mine[j] = i < mc ? ld(&p.cand[i]) : 0ull;
+        }
+        if (tid < 64) {
+            u32 t0 = 0;
+            if (prefilter) {
+                const u32 r = (u32)((keff + m_need - 1) / m_need);
+                u32 vmax = 0, vmin = 0xffffffffu, nnz = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    vmax = pv[j] > vmax ? pv[j] : vmax;
+                    if (pv[j]) {
+                        vmin = pv[j] < vmin ? pv[j] : vmin;
+                        ++nnz;
+                    }
+                }
+                vmax = wave_max(vmax);
+                vmin = wave_min(vmin);
+                nnz = wave_sum(nnz);
+                if (nnz >= r) {
+                    const u32 diff = vmax ^ vmin;
+                    t0 = vmax;
+                    if (diff) {
+                        // ANY value with >= r pivots at or above it will do: the 8 bits below the highest
+                        // differing one are resolved (a slightly lower pivot lets a few more keys through)
+                        const int hb = 31 - __clz((int)diff);
+                        const int lowest = hb >= 7 ? hb - 7 : 0;
+                        const int npl = (p.blocks + 63) >> 6;
+                        t0 = hb == 31 ? 0u : (vmax >> (hb + 1) << (hb + 1));  // the bits all pivots share
+#pragma unroll 1
+                        for (int bit = hb; bit >= lowest; --bit) {
+                            const u32 cand = t0 | (1u << bit);
+                            u32 c = 0;
+#pragma unroll
+                            for (int j = 0; j < 16; ++j)
+                                if (j < npl) c += (u32)__popcll(__ballot(pv[j] >= cand));
+                            if (c >= r) t0 = cand;
+                        }
+                    }
+                }
+            }
+            if (tid == 0) misc[7 * 8 + 5] = t0;
+        }
+        LS_STAMP(1);
         for (int o = 32; o >= 1; o >>= 1) {
             const u64 other = __shfl_xor(mb, o, 64);
             mb = other > mb ? other : mb;
         }
         if ((tid & 63) == 0) red[tid >> 6] = mb;
+        if (tid == 0) misc[7 * 8 + 4] = 0u;  // survivor count
         __syncthreads();
         mb = 0;
         for (int w = 0; w < NT / 64; ++w) mb = red[w] > mb ? red[w] : mb;
-        LS_STAMP(1);
-        nvalid = lds_topk(keys, mc, keff, res, tmp, hist, misc, tid, NT);
+        const u32 T0 = misc[7 * 8 + 5];
+        for (int c0 = 0;; c0 += CH * NT) {  // survivors -> LDS: ONE atomic per wave and round of CH keys
+            u32 nkeep = 0;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) nkeep += mine[j] != 0ull && (u32)(mine[j] >> 32) >= T0;
+            u32 inc = nkeep;  // inclusive prefix over the wave's lanes
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 t = (u32)__shfl_up((int)inc, o, 64);
+                if ((tid & 63) >= o) inc += t;
+            }
+            const u32 wave_total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+            u32 base = 0;
+            if (wave_total) {
+                if ((tid & 63) == 0) base = atomicAdd(&misc[7 * 8 + 4], wave_total);
+                base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+            }
+            u32 at = base + inc - nkeep;
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (mine[j] != 0ull && (u32)(mine[j] >> 32) >= T0) keys[at++] = mine[j];
+            if (c0 + CH * NT >= mc) break;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int i = c0 + CH * NT + tid + j * NT;
+                mine[j] = i < mc ? ld(&p.cand[i]) : 0ull;
+            }
+        }
+        __syncthreads();
+        const int nsurv = (int)misc[7 * 8 + 4];
+        __syncthreads();  // (lds_topk reuses misc)
+        LS_STAMP(2);
+        nvalid = lds_topk(keys, nsurv, keff, res, tmp, hist, misc, tid, NT);
         T = (nvalid == keff && keff > 0) ? res[keff - 1] : 0ull;
         done = (mb == 0ull) || (T != 0ull && mb < T);
         __syncthreads();
@@ -666,9 +861,9 @@ static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem
             p.out_indices[i] = ls_key_index(key, p.base);
         }
     }
-    LS_STAMP(5);
+    LS_STAMP(6);
 #ifdef LS_FIN_TIMING
     if (tid == 0 && p.counters)
-        for (int i = 0; i < 5; ++i) p.counters[2 + i] = (u32)(g_fin_stamp[i + 1] - g_fin_stamp[i]);
+        for (int i = 0; i < 6; ++i) p.counters[2 + i] = (u32)(g_fin_stamp[i + 1] - g_fin_stamp[i]);
 #endif
 }

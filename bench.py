@@ -622,6 +622,63 @@ def run_host_api(env: Env, workload: str, calls: int = 300) -> dict:
                     "and stream sync inside the timed call"}
 
 
+def run_bm25(n_docs: int = 200_000, k: int = 1000, calls: int = 300) -> dict:
+    """BM25+ name retrieval (reference search/engine.py:192-223; bm25s's eager-sparse
+    scoring) on the HIP kernels: one 3-token query over `n_docs` synthetic declaration names, synchronous
+    host call, checked bit for bit against the numpy oracle outside the timed loop."""
+    from lean_explore_amd.bm25 import BM25Index
+    from lean_explore_amd.search.tokenization import tokenize_spaced
+
+    words = ("add comm assoc zero one mul le lt succ pred map filter append length nil cons sum prod "
+             "continuous measurable integral deriv norm inner dist open closed compact").split()
+    rng = np.random.default_rng(3)
+    names = []
+    for i in range(n_docs):
+        parts = [words[j] for j in rng.integers(0, len(words), size=rng.integers(1, 5))]
+        ns = ["Nat", "List", "Real", "MeasureTheory", "Mathlib"][rng.integers(0, 5)]
+        names.append(f"{ns}.{'_'.join(parts)}{i % 97 if i % 3 == 0 else ''}")
+    corpus = [list(dict.fromkeys(tokenize_spaced(nm))) for nm in names]
+    ix = BM25Index().index(corpus)
+    q = ["nat", "add", "comm"]
+    ids = ix.token_ids(q)
+    postings = int(sum(int(ix.indptr[t + 1] - ix.indptr[t]) for t in ids))
+    nnz = int(ix.indptr[-1])
+    for _ in range(20):
+        ix.retrieve(q, k)
+    lat = np.empty(calls)
+    for i in range(calls):
+        t0 = time.perf_counter()
+        ix.retrieve(q, k)
+        lat[i] = time.perf_counter() - t0
+    out = {"workload": f"bm25: {n_docs} names, 3-token query, k={k}", "calls": calls,
+           "us_per_query_p50": round(float(np.median(lat)) * 1e6, 2),
+           "us_per_query_mean": round(float(lat.mean()) * 1e6, 2),
+           "queries_per_s": round(1.0 / float(lat.mean()), 1),
+           "launches_per_query": 2,
+           # what the doc-major score kernel reads per query (document pointers + every (token, value)
+           # entry + the score vector it writes) against the three posting lists a CSC walk would touch
+           "algorithmic_bytes_doc_major": 4 * (n_docs + 1) + 8 * nnz + 4 * n_docs,
+           "posting_list_bytes_csc": 8 * postings,
+           "selection_left_fast_path": int(ix.debug_counter(0)),
+           "what": "BM25Index.retrieve (ls_bm25_search, synchronous host call): score kernel + selection"}
+    pmc = ROOT / "profiles" / "pmc_bm25.json"
+    if pmc.exists():
+        try:
+            out["hbm_bytes_per_launch_pmc"] = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            out["kernel_avg_us_rocprof"] = json.loads(pmc.read_text()).get("kernel_avg_us_rocprof")
+        except Exception:
+            pass
+    try:
+        from oracle import bm25_ref
+
+        docs, sc = ix.retrieve(q, k)
+        dref, sref = bm25_ref.retrieve(bm25_ref.build(corpus), q, k)
+        out["bit_exact_vs_oracle"] = bool(np.array_equal(docs, dref) and np.array_equal(sc, sref))
+    except Exception as e:  # the oracle is the checker: report, never lose the line
+        out["bit_exact_vs_oracle"] = repr(e)
+    return out
+
+
 def self_spawn(args) -> int:
     """`python bench.py --gpus N` with no launcher: run N ranks under torch.distributed.run."""
     with socket.socket() as s:
@@ -668,7 +725,8 @@ def main():
         sec = []
         if args.workload == "c2":  # the default, driver-timed run carries both halves of the metric,
             # the reference's real call shape and the per-GPU shard of config 4
-            sec = ["c3", "c2p", "c4"] if env.n_gpus == 1 else ["c3", "c4"]
+            # ... and (1 GPU) config 2's shape at N = 1 M rows: 1.5 GB, six times the Infinity Cache
+            sec = ["c3", "c2p", "c2m", "c4"] if env.n_gpus == 1 else ["c3", "c4"]
     elif args.secondary in ("none", ""):
         sec = []
     else:
@@ -677,7 +735,7 @@ def main():
     for w in sec:
         nq = WORKLOADS[w][3]
         st, wu = (1000, 50) if nq <= 16 else ((300, 20) if w == "c3" else (30, 3))
-        secondary[w] = run_dense(env, w, st, wu, want_cpu=not args.no_cpu_baseline,
+        secondary[w] = run_dense(env, w, st, wu, want_cpu=not args.no_cpu_baseline and w != "c2m",
                                  verify=not args.no_verify, c4_rows=args.c4_rows, cpu_budget_s=9.0)
     if (args.secondary == "auto" and args.workload == "c2" and env.n_gpus == 1) or \
             "c5" in args.secondary.split(","):
@@ -690,6 +748,11 @@ def main():
             secondary["c5"] = hybrid_bench.run(queries=12)
         except Exception as e:  # the model stack is plumbing around the path: never lose the line to it
             secondary["c5"] = {"error": repr(e)}
+    if args.secondary == "auto" and args.workload == "c2" and env.n_gpus == 1 and env.rank == 0:
+        try:
+            secondary["bm25"] = run_bm25()
+        except Exception as e:
+            secondary["bm25"] = {"error": repr(e)}
     host_api = None
     if not args.no_host_api and env.n_gpus == 1 and args.workload == "c2" and env.rank == 0:
         host_api = {w: run_host_api(env, w) for w in ("c2", "c2p")}

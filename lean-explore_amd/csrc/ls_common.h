@@ -78,7 +78,7 @@ typedef unsigned int u32;
 #define LS_ABL_NOBARRIER 0
 #endif
 #ifndef LS_ABL_NODMA
-#define LS_ABL_NODMA 0
+#define LS_ABL_NODMA 0     // no tile DMA after the first tile: the MFMA stream alone
 #endif
 #ifndef LS_GEMM_LEAN
 #define LS_GEMM_LEAN 0               // 1: every geometry recomputes DMA offsets / queue bases (fewer registers)

@@ -28,7 +28,7 @@ dst = ROOT / "gpurun_out" / "profiles"  # copied back by gpurun; then moved into
 dst.mkdir(parents=True, exist_ok=True)
 
 DOMINANT = {  # substring(s) that must ALL appear in the kernel name
-    "c3": ("ls_gemm_filter_kernel", ", 0>"), "c4": ("ls_gemm_filter_kernel", ", 0>"),
+    "c3": ("ls_gemm_filter_kernel", ", 0>("), "c4": ("ls_gemm_filter_kernel", ", 0>("),
     "bm25": ("bm25_score_kernel",),
 }
 need = DOMINANT.get(wl, ("ls_scan_kernel",))
@@ -62,6 +62,28 @@ if stats:
     dom = [r for r in keep if is_dominant(r["Name"])]
     if dom:
         kernel_avg_ns = sum(float(r["TotalDurationNs"]) for r in dom) / sum(int(r["Calls"]) for r in dom)
+# The pipelined batched path runs its MFMA passes on two lanes that overlap on purpose: a launch's
+# begin-to-end time then includes its wait for CUs. From the kernel trace, keep the dominant kernel's
+# launches that had the chip's pass slots to themselves (no other ls_gemm_filter_kernel dispatch
+# overlaps them): bench.py's profiling pass queues exactly such launches (one stream).
+isolated_avg_ns = None
+if wl in ("c3", "c4"):
+    ev = []
+    for f in glob.glob(str(src / "trace" / "**" / "*kernel_trace.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if "ls_gemm_filter_kernel" in r["Kernel_Name"]:
+                    ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), is_dominant(r["Kernel_Name"])))
+    ev.sort()
+    iso = []
+    for i, (s0, e0, d) in enumerate(ev):
+        if not d:
+            continue
+        clash = (i > 0 and max(e for _, e, _ in ev[max(0, i - 4):i]) > s0) or (i + 1 < len(ev) and ev[i + 1][0] < e0)
+        if not clash:
+            iso.append(e0 - s0)
+    if iso:
+        isolated_avg_ns = sum(iso) / len(iso)
 bench_line = ""
 log = src / "bench_trace.log"
 if log.exists():
@@ -77,6 +99,11 @@ if log.exists():
 out = {"workload": wl, "tag": tag, "kernel_match": list(need)}
 if kernel_avg_ns is not None:
     out["kernel_avg_us_rocprof"] = round(kernel_avg_ns / 1e3, 3)
+if isolated_avg_ns is not None:
+    out["kernel_avg_us_rocprof_all_launches"] = out.get("kernel_avg_us_rocprof")
+    out["kernel_avg_us_rocprof"] = round(isolated_avg_ns / 1e3, 3)
+    out["kernel_avg_note"] = ("mean over the launches no other ls_gemm_filter_kernel dispatch overlaps (kernel trace); "
+                              "the pipelined run's two lanes overlap their passes on purpose")
 fetch = counter_per_launch("pmc_fetch", "FETCH_SIZE")
 write = counter_per_launch("pmc_write", "WRITE_SIZE")
 out["launches_sampled"] = len(fetch)

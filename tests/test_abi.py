@@ -74,3 +74,46 @@ def test_compute_fails_loudly_without_device(gpu_available):
     assert "no CPU path" in str(e.value)
     with pytest.raises(native.LeanSearchError):
         normalize_L2(np.ones((1, 8), np.float32))
+
+
+def test_register_budget_of_the_co_resident_kernels(tmp_path):
+    """The pipelined batched path relies on a build-time fact (csrc/ls_gemm.hip, ls_wsel.hip): the MFMA
+    pass (with or without the next batch's sample phase) of the two-accumulator geometries needs <= 232
+    VGPRs - two waves per SIMD then leave 48 of its 512 registers - and the one-wave select and query
+    prep kernels need <= 48, so they run INSIDE a resident pass (tools/coresidency_probe.hip). clang's
+    amdgpu_num_vgpr attribute is not enforced by this toolchain, so the numbers are read back from the
+    compiler's resource-usage remarks (config 3's geometry only: seconds, no GPU needed)."""
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = ROOT / "lean-explore_amd" / "csrc"
+    usage = {}
+    for src, extra in (("ls_gemm.hip", ["-DLS_GEMM_ONLY_CASE=48"]), ("ls_wsel.hip", [])):
+        p = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast",
+                            "-Rpass-analysis=kernel-resource-usage", *extra, "-c", str(csrc / src), "-o",
+                            str(tmp_path / (src + ".o"))], capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        name = None
+        for line in p.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                usage[name] = {}
+            m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill): (\d+)", line)
+            if m and name:
+                usage[name][m.group(1)] = int(m.group(2))
+
+    def pick(*parts):
+        hits = {n: u for n, u in usage.items() if all(s in n for s in parts)}
+        assert hits, (parts, sorted(usage))
+        return hits
+
+    # ls_gemm_filter_kernel<48, 2, TOPN, NT, MODE>: MODE 0 = pass, 2 = pass + next batch's sample phase
+    for mode in ("Li0EEv", "Li2EEv"):
+        for n, u in pick("ls_gemm_filter_kernelILi48ELi2E", mode).items():
+            assert u["VGPRs"] <= 232 and u["VGPRs Spill"] == 0 and u["ScratchSize [bytes/lane]"] == 0, (n, u)
+    for n, u in {**pick("ls_wave_select_kernelILi4E"), **pick("ls_wave_select_kernelILi8E"),
+                 **pick("ls_prep_f16_kernel")}.items():
+        assert u["VGPRs"] <= 48 and u["ScratchSize [bytes/lane]"] == 0, (n, u)

@@ -13,7 +13,7 @@ rows.sort()
 def short(n):
     for k in ("prep_f16", "tau", "select"):
         if k in n: return k
-    if "gemm_filter" in n: return "sample" if ", 1>" in n[-12:] else "pass"
+    if "gemm_filter" in n: return "sample" if ", 1>(" in n else "pass"
     return n[:20]
 sl = rows[-22:-2]
 prev = None

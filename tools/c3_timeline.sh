@@ -14,7 +14,7 @@ rows.sort()
 def short(n):
     for k in ("prep_f16", "tau", "select"):
         if k in n: return k
-    if "gemm_filter" in n: return "sample" if n.rstrip().endswith(", 1>") else "pass"  # ", 0>" pass, ", 2>" fused
+    if "gemm_filter" in n: return "sample" if ", 1>(" in n else "pass"  # ", 0>" pass, ", 2>" pass + a later batch's sample phase
     return None
 ev = [(s, e, short(n), q) for s, e, n, q in rows if short(n)]
 passes = [x for x in ev if x[2] == "pass"][-150:]
@@ -42,7 +42,7 @@ rows.sort()
 def short(n):
     for k in ("prep_f16", "tau", "select"):
         if k in n: return k
-    if "gemm_filter" in n: return "sample" if n.rstrip().endswith(", 1>") else ("pass+sample" if n.rstrip().endswith(", 2>") else "pass")
+    if "gemm_filter" in n: return "sample" if ", 1>(" in n else ("pass+sample" if ", 2>(" in n else "pass")
     return n[:24]
 sl = rows[-60:-30]
 t0 = sl[0][0]

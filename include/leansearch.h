@@ -221,8 +221,8 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * and the host launches the stand-alone selection): 0 off, 1 on (default);
  * option 10: synchronous host searches (ls_search) that arrive while another one is running are
  * served together, up to 16 queries of equal k and flags per corpus pass (default on);
- * option 13: pipelined fp16 batches let the sample phase of the batch two calls ahead ride on the MFMA
- * pass launch: 0 never, 1 for stored rows of up to 768 bytes (default), 2 always; option 14: select
+ * option 13: pipelined fp16 batches of stored rows of up to 768 bytes let the sample phase of the batch
+ * two calls ahead ride on the MFMA pass launch: 0 off, 1 on (default); option 14: select
  * step of the batched path as one wave per query in <= 48 registers where the shape allows (k <= 128,
  * <= 128 corpus slices; runs inside a resident MFMA pass): default on;
  * option 8 (sharded handles): exchange step 0 = RCCL all-gather between distinct devices (default),

@@ -897,7 +897,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     // calls back, which is held until now for that (the register-starved geometries - config 4's
     // 1.5 KiB rows - spend ~1 % of a multi-millisecond batch between passes and keep their own
     // sample launch)
-    const bool fuse_ok = chain && !f32 && (ix->opt_fused == 2 || (ix->opt_fused == 1 && g.chunks <= 48));
+    const bool fuse_ok = chain && !f32 && ix->opt_fused != 0 && g.chunks <= 48;
     bool ride = false;
     if (fuse_ok && ix->held.size() == 2) {
         const ls_index::bc_stage& d = ix->held.front();
@@ -1516,8 +1516,8 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->opt_kprime = value;
         return LS_OK;
     }
-    if (which == 13) {  // fused filter launch (sample phase + tau + MFMA pass): 0 off, 1 where it pays (default), 2 always
-        ix->opt_fused = value < 0 ? 0 : (value > 2 ? 2 : value);
+    if (which == 13) {  // pipelined fp16 batches (rows <= 768 bytes): a later batch's sample phase rides on the pass launch (default on)
+        ix->opt_fused = value != 0;
         return LS_OK;
     }
     if (which == 14) {  // one-wave select kernel (co-resident with a running pass): default on

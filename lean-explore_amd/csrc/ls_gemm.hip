@@ -463,15 +463,20 @@ __device__ __forceinline__ void gemm_filter_body(
         if constexpr (SMP && FUSED) {
             // The sample phase of a fused launch is a handful of tiles, and whatever it keeps in
             // registers comes on top of the full pass's state (the B fragments alone are KS*QG*4
-            // registers): ONE accumulator set, A fragments read just in time, and the tile's own
-            // scores filtered right behind its k-loop. ~1 us slower per workgroup than the
-            // software-pipelined form, and the launch stays at the full pass's register count -
-            // which is what lets the one-wave select kernel (ls_wsel.hip) run beside it.
+            // registers): ONE accumulator set, and the tile's own scores filtered right behind its
+            // k-loop instead of inside the next tile's. The launch stays at the full pass's register
+            // count - which is what lets the one-wave select kernel (ls_wsel.hip) run beside it.
+            half8 a[2][NRB];  // A fragments one k-step ahead (the second accumulator set's registers are free here)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) a[0][rb] = a_frag(bufoff, rb, 0);
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
+                if (kk + 1 < KS) {
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) a[(kk + 1) & 1][rb] = a_frag(bufoff, rb, kk + 1);
+                }
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
-                    const half8 a = a_frag(bufoff, rb, kk);
 #pragma unroll
                     for (int g2 = 0; g2 < QG; ++g2) {
                         f32x4v c;
@@ -480,7 +485,7 @@ __device__ __forceinline__ void gemm_filter_body(
                         } else {
                             c = cur[rb][g2];
                         }
-                        cur[rb][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bq[g2][kk], c, 0, 0, 0);
+                        cur[rb][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk & 1][rb], bq[g2][kk], c, 0, 0, 0);
                     }
                 }
             }
@@ -615,11 +620,18 @@ __device__ __forceinline__ void gemm_filter_body(
     // three buffers tile i+2 is requested at the top of tile i (its buffer was last read during
     // tile i-1, which every wave has left through the barrier); with two, tile i+1.
     constexpr int AHEAD = NBUF - 1;
-    auto run_phase = [&](auto ph) {
+    int b_cur = 0, b_new = AHEAD * TILE_BYTES;  // LDS byte offsets of tile i and of tile i + AHEAD
+    // `fresh`: the phase's first tile(s) were requested by phase_prologue (ring restarts at buffer 0).
+    // Not fresh (a fused launch's sample phase, two buffers): the full pass's last iteration already
+    // requested sample tile 0 as its "next tile" and handed it over - the ring just goes on.
+    auto run_phase = [&](auto ph, bool fresh = true) {
         constexpr bool SMP = decltype(ph)::value;
-        first_hand_over();
+        if (fresh) {
+            first_hand_over();
+            b_cur = 0;
+            b_new = AHEAD * TILE_BYTES;
+        }
         if constexpr (SMP) LS_SSTAMP_F(1);
-        int b_cur = 0, b_new = AHEAD * TILE_BYTES;  // LDS byte offsets of tile i and of tile i + AHEAD
         auto advance = [&](int& b) { b = b + TILE_BYTES == NBUF * TILE_BYTES ? 0 : b + TILE_BYTES; };
         auto one_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], int i) {
             constexpr bool always = LS_GEMM_STRAIGHT && !SMP && (AHEAD + 1) * TM <= LS_CORPUS_PAD_ROWS;
@@ -627,9 +639,12 @@ __device__ __forceinline__ void gemm_filter_body(
             // the next tile's DMA pieces are issued between this tile's k-steps (run_tile), not in
             // one burst behind the barrier
             constexpr bool spread = (SEQ_RB || !SMP) && LOADS <= KS;
-            if (more && !spread) stage((i + AHEAD) * tile_stride, b_new);
+            // (a fused launch's full pass: the request past the slice's last tile fetches the sample
+            // phase's first tile - tile 0 of the slice - instead of rows nobody reads)
+            const int ti_next = (FUSED && !SMP && NBUF == 2 && i + AHEAD >= nt) ? 0 : (i + AHEAD) * tile_stride;
+            if (more && !spread) stage(ti_next, b_new);
             run_tile(ph, cur, prev, LS_GEMM_STRAIGHT ? true : i > 0, tile_row0(i - 1), tile_row0(i), b_cur,
-                     more && spread, (i + AHEAD) * tile_stride, b_new);
+                     more && spread, ti_next, b_new);
             // tile i+1 must be complete before anyone reads it. NBUF == 3: only when a younger tile
             // was requested in this iteration may LOADS pieces stay in flight.
             hand_over(NBUF == 3 && more);
@@ -667,8 +682,12 @@ __device__ __forceinline__ void gemm_filter_body(
         // by a prep kernel that completed before this launch started (stream wait on its event).
         tile_stride = out.sample_stride;
         nt = (ntiles_all + tile_stride - 1) / tile_stride;
-        __builtin_amdgcn_s_barrier();  // every wave has left the tile ring
-        phase_prologue();
+        // the straight-line full pass (two buffers) has already fetched and handed over sample tile 0
+        constexpr bool PREFETCHED = LS_GEMM_STRAIGHT && NBUF == 2 && 2 * TM <= LS_CORPUS_PAD_ROWS;
+        if constexpr (!PREFETCHED) {
+            __builtin_amdgcn_s_barrier();  // every wave has left the tile ring
+            phase_prologue();
+        }
         {
             const u32x4* qn = out.qh_next;
             asm volatile("" : "+s"(qn));  // a different buffer: nothing of the first load may be reused
@@ -681,7 +700,7 @@ __device__ __forceinline__ void gemm_filter_body(
                 for (int g2 = 0; g2 < QG; ++g2) bq[g2][kk] = __builtin_bit_cast(half8, qfrag[g2][kk << 6]);
         }
         nq = out.nq_next;
-        run_phase(phase_sample{});
+        run_phase(phase_sample{}, !PREFETCHED);
 #pragma unroll
         for (int g2 = 0; g2 < QG; ++g2)
             reinterpret_cast<uint4*>(out.sample_top)[queue_id(qj[g2], split, qd, nsplits)] = top4_keys(top[g2]);
@@ -761,16 +780,24 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
         return LS_OK;                                                                             \
     }
 #define LS_GEMM_TOP2(C) (C / 4 * gemm_qg(C) * 4 >= 128 && sample_top2)
+// (the fused launch exists for the two-accumulator geometries only: rows of up to 768 bytes. The
+// register-starved ones spend ~1 % of a multi-millisecond batch outside the pass; a forced fused run of
+// config 4's geometry also mis-thresholded every query - exact after repairs, 40x slower - and was
+// not pursued)
 #define LS_GEMM_CASE(C)                                                                  \
     if (g.chunks == C) {                                                                 \
-        if (fz && nqt == 1 && LS_GEMM_TOP2(C)) LS_GEMM_LAUNCH(C, LS_GEMM_FUSED, 2, true)  \
-        else if (fz && nqt == 1) LS_GEMM_LAUNCH(C, LS_GEMM_FUSED, 4, true)                \
-        else if (fz && LS_GEMM_TOP2(C)) LS_GEMM_LAUNCH(C, LS_GEMM_FUSED, 2, false)        \
-        else if (fz) LS_GEMM_LAUNCH(C, LS_GEMM_FUSED, 4, false)                           \
-        else if (d_tau && nqt == 1) LS_GEMM_LAUNCH(C, LS_GEMM_PASS, 4, true)              \
-        else if (d_tau) LS_GEMM_LAUNCH(C, LS_GEMM_PASS, 4, false)                         \
-        else if (LS_GEMM_TOP2(C)) LS_GEMM_LAUNCH(C, LS_GEMM_SAMPLE, 2, false)             \
-        else LS_GEMM_LAUNCH(C, LS_GEMM_SAMPLE, 4, false)                                  \
+        if constexpr (C <= 48) {                                                         \
+            if (fz && nqt == 1) LS_GEMM_LAUNCH(C, LS_GEMM_FUSED, 4, true)                \
+            else if (fz) LS_GEMM_LAUNCH(C, LS_GEMM_FUSED, 4, false)                      \
+        }                                                                                \
+        if (fz) {                                                                        \
+            ls_set_error("batched path: no fused launch for %d-chunk rows", g.chunks);   \
+            return LS_ERR_INVALID_ARG;                                                   \
+        }                                                                                \
+        if (d_tau && nqt == 1) LS_GEMM_LAUNCH(C, LS_GEMM_PASS, 4, true)                  \
+        else if (d_tau) LS_GEMM_LAUNCH(C, LS_GEMM_PASS, 4, false)                        \
+        else if (LS_GEMM_TOP2(C)) LS_GEMM_LAUNCH(C, LS_GEMM_SAMPLE, 2, false)            \
+        else LS_GEMM_LAUNCH(C, LS_GEMM_SAMPLE, 4, false)                                 \
     }
 #ifdef LS_GEMM_ONLY_CASE  // developer builds: one geometry (compile time of a register experiment)
     LS_GEMM_CASE(LS_GEMM_ONLY_CASE)

@@ -104,7 +104,7 @@ struct ls_index {
     hipStream_t chain_main[2] = {nullptr, nullptr};  // the chain's two lanes
     hipStream_t chain_sel = nullptr;                 // ... and its select stream
     hipEvent_t chain_in = nullptr;        // recorded on the caller's stream, waited for by the prep stream
-    int32_t opt_fused = 1;                // pipelined fp16 batches: the next batch's sample phase rides on the pass launch: 0 never, 1 where it pays, 2 always
+    int32_t opt_fused = 1;                // pipelined fp16 batches of rows <= 768 bytes: a later batch's sample phase rides on the pass launch
     int32_t opt_wave_select = 1;          // one-wave select kernel (<= 48 VGPRs) where the shape allows
     uint64_t bc_lane_rr = 0;
     int32_t bc_last_set = 0;  // the set of the most recent batched call (ls_export_flags)

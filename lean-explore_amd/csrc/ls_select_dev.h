@@ -731,6 +731,7 @@ static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem
                 vmax = wave_max(vmax);
                 vmin = wave_min(vmin);
                 nnz = wave_sum(nnz);
+                LS_STAMP(7);  // (developer stamp: the pivot loads have landed)
                 if (nnz >= r) {
                     const u32 diff = vmax ^ vmin;
                     t0 = vmax;
@@ -865,5 +866,6 @@ static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem
 #ifdef LS_FIN_TIMING
     if (tid == 0 && p.counters)
         for (int i = 0; i < 6; ++i) p.counters[2 + i] = (u32)(g_fin_stamp[i + 1] - g_fin_stamp[i]);
+    if (tid == 0 && p.counters) p.counters[1] = (u32)(g_fin_stamp[7] - g_fin_stamp[0]);  // (timing builds only)
 #endif
 }

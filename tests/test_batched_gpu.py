@@ -324,6 +324,31 @@ def test_pipelined_lanes_large_and_ragged_batches():
     ix.close()
 
 
+@pytest.mark.parametrize("d", [100, 250, 384, 768])
+def test_pipelined_run_needs_no_repairs(d):
+    """A steady pipelined run (every pass launch carries the sample phase of the batch two calls ahead where
+    the geometry fuses: rows of up to 768 bytes; d = 768 keeps its own sample launch): the thresholds the
+    riding sample phase produces must be as good as the stand-alone sample pass's - a mis-thresholded
+    batch would still be exact (every query repaired by the scan path) but 40x slower, so the repair
+    counter is the assertion, next to the results themselves."""
+    import torch
+
+    c = H.gauss(96, 150_000, d)
+    ix = FlatIPIndex.from_array(c, dtype="f16")
+    dev = torch.device("cuda:0")
+    nq, k, calls = 512, 100, 10
+    qs = [H.gauss(500 + i, nq, d) for i in range(calls)]
+    outs = [ix.search_device(torch.from_numpy(q).to(dev), k, pipeline=True) for q in qs]
+    ix.check()
+    assert ix.debug_counter(8) <= nq * calls // 200, f"{ix.debug_counter(8)} of {nq * calls} queries were repaired"
+    for q, (s_, i_) in list(zip(qs, outs))[::3]:
+        Dr, Ir = oracle.c_search(c, q[:64], k, f16=True)
+        _, _, S = oracle.np_search(c, q[:64], k, f16=True)
+        rep = oracle.compare_topk(s_[:64].cpu().numpy(), i_[:64].cpu().numpy(), Dr, Ir, S)
+        assert rep["recall"] == 1.0, rep
+    ix.close()
+
+
 # ---------------------------------------------------------------- fp32 index: exact f32 MFMA path
 def check_batched_f32(c, q, k, normalize=False, base=0):
     ix = FlatIPIndex.from_array(c, dtype="f32", base=base)

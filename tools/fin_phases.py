@@ -22,9 +22,9 @@ for (n, d, k) in [(200_000, 384, 50), (200_000, 1024, 1000)]:
         lat = []
         for _ in range(50):
             t0 = time.perf_counter(); ix.search(q, k, normalize=True); lat.append(time.perf_counter() - t0)
-            ph.append([ix.debug_counter(2 + i) for i in range(6)])
+            ph.append([ix.debug_counter(2 + i) for i in range(6)] + [ix.debug_counter(1)])
         ph = np.median(np.array(ph), axis=0) / 100.0
         print(f"N={n} d={d} k={k} selection {'inside the scan launch' if mode else 'as its own launch'}: call p50 {np.median(lat)*1e6:.1f} us | "
-              f"loads issued + pivot {ph[0]:.1f} | survivors to LDS {ph[1]:.1f} | k-th key {ph[2]:.1f} | compact {ph[3]:.1f} | "
+              f"loads issued + pivot {ph[0]:.1f} (pivot loads landed after {ph[6]:.1f}) | survivors to LDS {ph[1]:.1f} | k-th key {ph[2]:.1f} | compact {ph[3]:.1f} | "
               f"order {ph[4]:.1f} | output+done {ph[5]:.1f} us", flush=True)
     ix.close()

@@ -27,17 +27,12 @@ for mode in ("asynchronous", "pipeline"):
         if i % 16 == 15:
             ix.check()
     print(f"{mode}: host time to queue one call: p50 {np.median(t)*1e6:.1f} us, p90 {np.quantile(t, .9)*1e6:.1f} us", flush=True)
-names = ["start->first tile", "sample tiles", "publish+arrive", "wait 1", "tau+publish+arrive", "wait 2", "full pass"]
 for rep in range(3):
-    ix.search_device(q, 100, *outs[0], asynchronous=True); ix.check()
+    for _ in range(4):
+        ix.search_device(q, 100, *outs[0], pipeline=True)
+    ix.check()
     v = np.array([ix.debug_counter(3000 + j) for j in range(8 * 256)], dtype=np.int64).reshape(-1, 8)
     t0 = v[:, 0].min()
     f = lambda a: "/".join(f"{x:.1f}" for x in np.percentile(a / 100.0, [0, 50, 100]))
-    print("fused launch, 256 workgroups (us; min/p50/max): start " + f(v[:, 0] - t0) + " | " +
-          " | ".join(f"{names[i]} {f(v[:, i + 1] - v[:, i])}" for i in range(7)) +
-          f" | last end {(v[:, 7].max() - t0) / 100.0:.1f}", flush=True)
-    w = np.array([ix.debug_counter(3000 + 2048 + j) for j in range(8 * 256)], dtype=np.int64).reshape(-1, 8)
-    w = w[::4]  # wave 0 computes a tau only in the workgroups of slices 0..63 of each tile: all of them here
-    sub = ["wait over -> tau start", "loads + staging", "pass 0 counting", "find bin", "pass 1 counting", "find bin", "store", "drain + barrier"]
-    ref = np.concatenate([v[::4, 4:5], w], axis=1)
-    print("   tau step of wave 0 (us; min/p50/max): " + " | ".join(f"{sub[i]} {f(ref[:, i + 1] - ref[:, i])}" for i in range(8)), flush=True)
+    print("pass + riding sample phase, 256 workgroups of the last fused launch (us; min/p50/max): start " + f(v[:, 0] - t0) +
+          f" | full pass {f(v[:, 2] - v[:, 0])} | sample phase {f(v[:, 7] - v[:, 2])} | last end {(v[:, 7].max() - t0) / 100.0:.1f}", flush=True)

@@ -99,6 +99,18 @@ int ls_create(ls_index** out, const float* corpus, int64_t n, int32_t d, int32_t
 int ls_create_sharded(ls_index** out, const float* corpus, int64_t n, int32_t d, int32_t dtype,
                       const int32_t* device_ids, int32_t n_devices);
 
+/* REPLICAS instead of row shards: every device of device_ids holds the whole corpus, and the synchronous
+ * host calls (ls_search - the reference's call, search/engine.py:250) are dealt round-robin to the
+ * replicas, each with its own queue of concurrent callers: G callers run on G devices at once. For a
+ * corpus that fits one GPU (the reference's ~200 k x 1024 fp32 = 0.8 GB) this is the shape that
+ * scales queries/s with the device count; row shards only pay for corpora that do not fit (each query
+ * touches every shard, plus the exchange). The handle is an ordinary ls_index*: ls_add appends to every
+ * replica, ls_reconstruct reads replica 0, ls_search_device (queries resident on device_ids[0]) is
+ * served by the replica there, ls_shard_count / ls_shard_info list the replicas (each covering all
+ * rows). Results are those of a single-device index. debug counter 21: host calls dispatched. */
+int ls_create_replicated(ls_index** out, const float* corpus, int64_t n, int32_t d, int32_t dtype,
+                         const int32_t* device_ids, int32_t n_devices);
+
 /* As ls_create_sharded with the row blocks already in HBM: d_blocks[g] is device memory on
  * device_ids[g], row-major float32 [rows[g], d]; global rows are numbered block after block. */
 int ls_create_sharded_from_device(ls_index** out, const void* const* d_blocks, const int64_t* rows,

@@ -1202,6 +1202,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
     if (rc != LS_OK) return rc;
     if (nq == 0) return LS_OK;
     flags &= LS_FLAG_NORMALIZE;
+    if (ls_group_is_replicated(ix)) return ls_replica_search(ix, q, nq, k, flags, out_scores, out_indices);
     if (!ix->opt_combine || nq > LS_QUERIES_PER_LAUNCH_MAX)  // big batches gain nothing from company
         return host_search_locked(ix, q, nq, k, flags, out_scores, out_indices);
     ls_req me{q, nq, k, flags, out_scores, out_indices};
@@ -1600,7 +1601,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 20) return -1;
+    if (!ix || which < 0 || which > 21) return -1;
     if (which == 16 || which == 17) {
         std::lock_guard<std::mutex> ql(ix->q_mu);
         return (int64_t)(which == 16 ? ix->n_combined_batches : ix->n_combined_requests);
@@ -1613,7 +1614,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
     if (which == 11) return (int64_t)ix->n_launches_total;
     if (which == 12) return (int64_t)ix->n_chunked_calls;
     if (which == 20) return (int64_t)ix->n_same_launch_retries;
-    if (which > 9) return 0;  // 13..15, 18 and 19 are group counters
+    if (which > 9) return 0;  // 13..15, 18, 19 and 21 are group counters
     if (hipSetDevice(ix->device) != hipSuccess) return -1;
     u32 v = 0;
     if (hipMemcpy(&v, ix->d_counters + which, sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess)

@@ -210,6 +210,9 @@ int ls_i_export_flags(ls_index* ix, void* d_dst, int64_t nq, hipStream_t s);
 // ---- the group handle (ls_shard.hip); every function takes the GROUP's ls_index -----------------
 int ls_group_search(ls_index* ix, const float* q, bool q_on_host, int64_t nq, int32_t k,
                     uint32_t flags, float* out_s, int64_t* out_i, hipStream_t s);
+int ls_replica_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flags, float* out_s,
+                      int64_t* out_i);  // replicated handles: synchronous host calls, round-robin
+bool ls_group_is_replicated(const ls_index* ix);
 int ls_group_check(ls_index* ix, hipStream_t s);
 void ls_group_destroy(ls_index* ix);
 int ls_group_add(ls_index* ix, const float* rows, int64_t n_add);

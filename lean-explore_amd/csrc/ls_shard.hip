@@ -193,6 +193,8 @@ struct ls_shard_group {
     std::vector<ls_index*> sub;  // one single-device handle per shard
     std::vector<int> dev;        // device ordinal of shard g
     std::vector<int64_t> lo;     // first global row of shard g (relative to the group's base)
+    bool replicated = false;     // every sub-handle holds the WHOLE corpus (ls_create_replicated)
+    std::atomic<uint32_t> rr{0}; // replicated: the next synchronous host call goes to replica rr % G
     bool distinct = false;       // all device ids differ (an RCCL communicator can be formed)
     int exchange_mode = 0;       // 0: RCCL all-gather when `distinct`; 1: peer copies to the primary
     std::vector<ncclComm_t> comms;
@@ -445,6 +447,7 @@ static int group_check_locked(ls_index* ix) {
 
 int ls_group_check(ls_index* ix, hipStream_t s) {
     ls_device_guard guard;
+    if (ix->group->replicated) return ls_check(ix->group->sub[0], s);
     int rc = group_check_locked(ix);
     if (rc != LS_OK) return rc;
     LS_HIP(hipStreamSynchronize(s));
@@ -455,6 +458,13 @@ int ls_group_search(ls_index* ix, const float* q, bool q_on_host, int64_t nq, in
                     uint32_t flags, float* out_s, int64_t* out_i, hipStream_t s) {
     ls_device_guard guard;  // every exit (errors included) leaves the caller's device current
     ls_shard_group* G = ix->group;
+    if (G->replicated) {
+        // device-resident queries live on device_ids[0]: the replica there serves them (the other
+        // replicas take synchronous host calls, ls_replica_search)
+        ls_index* sub = G->sub[0];
+        if (q_on_host) return ls_search(sub, q, nq, k, flags, out_s, out_i);
+        return ls_search_device(sub, q, nq, k, flags, out_s, out_i, s);
+    }
     const int P = G->dev[0];
     const int32_t d = ix->g.d;
     const size_t qn = (size_t)nq * d, on = (size_t)nq * k;
@@ -644,6 +654,12 @@ int ls_group_add(ls_index* ix, const float* rows, int64_t n_add) {
                      (long long)(ix->n + n_add));
         return LS_ERR_INVALID_ARG;
     }
+    if (G->replicated) {  // every replica appends the same rows
+        for (ls_index* sub : G->sub)
+            if (int rc = ls_add(sub, rows, n_add)) return rc;
+        ix->n += n_add;
+        return LS_OK;
+    }
     int rc = group_check_locked(ix);
     if (rc != LS_OK) return rc;
     rc = ls_add(G->sub[G->G - 1], rows, n_add);
@@ -654,6 +670,7 @@ int ls_group_add(ls_index* ix, const float* rows, int64_t n_add) {
 int ls_group_reconstruct(ls_index* ix, int64_t row0, int64_t count, float* out) {
     ls_device_guard guard;
     ls_shard_group* G = ix->group;
+    if (G->replicated) return ls_reconstruct(G->sub[0], row0, count, out);
     for (int g = 0; g < G->G && count > 0; ++g) {
         const int64_t lo = G->lo[g], hi = lo + G->sub[g]->n;
         if (row0 >= hi || row0 + count <= lo) continue;
@@ -667,6 +684,10 @@ int ls_group_reconstruct(ls_index* ix, int64_t row0, int64_t count, float* out) 
 int ls_group_debug_option(ls_index* ix, int32_t which, int32_t value) {
     ls_device_guard guard;
     ls_shard_group* G = ix->group;
+    if (G->replicated && (which == 8 || which == 11 || which == 12)) {
+        ls_set_error("ls_debug_option(%d): a replicated handle has no exchange step", which);
+        return LS_ERR_INVALID_ARG;
+    }
     if (which == 8) {  // 0: RCCL all-gather between distinct devices (default); 1: peer copies
         if (value != 0 && value != 1) {
             ls_set_error("ls_debug_option(8): exchange mode must be 0 (RCCL) or 1 (peer copies)");
@@ -695,6 +716,7 @@ int ls_group_debug_option(ls_index* ix, int32_t which, int32_t value) {
 int64_t ls_group_debug_counter(ls_index* ix, int32_t which) {
     ls_device_guard guard;
     ls_shard_group* G = ix->group;
+    if (which == 21) return (int64_t)G->rr.load();  // replicated: host calls dispatched so far
     if (which == 18) return G->enqueue_calls ? (int64_t)(G->enqueue_ns / G->enqueue_calls) : 0;
     if (which == 13) return (int64_t)G->n_exchanges;
     if (which == 14) return (int64_t)G->n_reexchanges;
@@ -721,6 +743,17 @@ int ls_group_last_kernel_ms(ls_index* ix, float* scan_ms, float* total_ms) {
     ls_device_guard guard;
     return ls_last_kernel_ms(ix->group->sub[0], scan_ms, total_ms);
 }
+
+// One synchronous host call on a replicated handle: the next replica in turn takes it (its own
+// combining queue serves callers that arrive together on that replica). No group lock is taken.
+int ls_replica_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flags,
+                      float* out_s, int64_t* out_i) {
+    ls_device_guard guard;
+    ls_shard_group* G = ix->group;
+    const uint32_t r = G->rr.fetch_add(1, std::memory_order_relaxed) % (uint32_t)G->G;
+    return ls_search(G->sub[r], q, nq, k, flags, out_s, out_i);
+}
+bool ls_group_is_replicated(const ls_index* ix) { return ix->group && ix->group->replicated; }
 
 // ---- construction ----------------------------------------------------------------------------------
 static int group_begin(ls_index** out, int64_t n, int32_t d, int32_t dtype, const int32_t* device_ids,
@@ -838,6 +871,42 @@ int ls_create_sharded(ls_index** out, const float* corpus, int64_t n, int32_t d,
     return LS_OK;
 }
 
+// A corpus that fits one GPU (the reference's real case: ~200 k x 1024 fp32 = 0.8 GB) gains nothing
+// from row shards - every query would still touch every device, plus an exchange. REPLICAS scale
+// the reference's workload instead: one full copy per device, and the synchronous host calls
+// (ls_search: what the reference issues, search/engine.py:250) are dealt round-robin to the
+// replicas, each with its own queue of concurrent callers, stream and pinned buffers, so G callers
+// run on G devices at once. Everything else behaves like one index: ls_add appends to every replica,
+// ls_reconstruct reads replica 0, device-resident queries (ls_search_device: they live on
+// device_ids[0]) are served by the replica there. Results are those of a single-device index.
+int ls_create_replicated(ls_index** out, const float* corpus, int64_t n, int32_t d, int32_t dtype,
+                         const int32_t* device_ids, int32_t n_devices) {
+    if (n > 0 && !corpus) {
+        ls_set_error("ls_create_replicated: corpus is null");
+        return LS_ERR_INVALID_ARG;
+    }
+    ls_device_guard guard;
+    ls_index* ix = nullptr;
+    int rc = group_begin(out, n, d, dtype, device_ids, n_devices, "ls_create_replicated", &ix);
+    if (rc != LS_OK) return rc;
+    ls_shard_group* G = ix->group;
+    G->replicated = true;
+    for (int g = 0; g < n_devices && rc == LS_OK; ++g) {
+        ls_index* sub = nullptr;
+        rc = ls_create(&sub, corpus, n, d, dtype, device_ids[g]);
+        if (rc != LS_OK) break;
+        G->sub.push_back(sub);
+        G->lo.push_back(0);
+    }
+    if (rc == LS_OK) rc = group_finish(ix);
+    if (rc != LS_OK) {
+        ls_destroy(ix);
+        return rc;
+    }
+    *out = ix;
+    return LS_OK;
+}
+
 int ls_create_sharded_from_device(ls_index** out, const void* const* d_blocks, const int64_t* rows,
                                   int32_t d, int32_t dtype, const int32_t* device_ids,
                                   int32_t n_devices) {
@@ -888,7 +957,8 @@ int32_t ls_shard_exchange_info(ls_index* ix, char* buf, int32_t cap) {
     std::lock_guard<std::mutex> lk(ix->mu);
     const ls_shard_group* G = ix->group;
     std::string o = "{\"exchange\": \"";
-    o += G->rccl_failed ? "peer-copy (RCCL failed)"
+    o += G->replicated ? "none (replicas: every device holds the whole corpus)"
+         : G->rccl_failed ? "peer-copy (RCCL failed)"
          : group_uses_rccl(G) ? (G->comms_ready ? "rccl all-gather" : "rccl all-gather (not used yet)")
          : (G->distinct ? "peer-copy (selected)" : "device-to-device copies (shards share a device)");
     o += "\", \"rccl_version\": " + std::to_string(G->rccl_version);

@@ -110,7 +110,8 @@ def write_index(index: FlatIPIndex, path: str | Path, *, allow_lossy: bool = Fal
         f.write(corpus.tobytes())
 
 
-def read_index(path: str | Path, dtype="f32", device: int = 0, devices=None) -> FlatIPIndex:
+def read_index(path: str | Path, dtype="f32", device: int = 0, devices=None,
+               replicate: bool = False) -> FlatIPIndex:
     """faiss.read_index (reference search/engine.py:159) -> exact HIP index (``devices``: row-sharded
     over several GPUs inside this process)."""
     path = Path(path)
@@ -124,7 +125,7 @@ def read_index(path: str | Path, dtype="f32", device: int = 0, devices=None) -> 
             tag = struct.pack("<I", cc).decode("ascii", "replace")
             raise ValueError(f"{path}: unsupported index container {tag!r} "
                              "(expected IxFI flat-IP or IwFl IVF-flat)")
-    index = FlatIPIndex(d, dtype=dtype, device=device, devices=devices)
+    index = FlatIPIndex(d, dtype=dtype, device=device, devices=devices, replicate=replicate)
     if corpus.shape[0]:
         index.add(corpus)
     return index

@@ -67,12 +67,17 @@ class FlatIPIndex:
     supports_fused_normalize = True  # search(..., normalize=True) fuses faiss.normalize_L2
 
     def __init__(self, d: int, dtype: Any = "f32", device: int = 0, base: int = 0,
-                 devices: Any = None):
+                 devices: Any = None, replicate: bool = False):
         if d <= 0:
             raise ValueError("d must be positive")
         self.d = int(d)
         self._dtype = _dtype_code(dtype)
         self.devices = _device_list(devices)
+        # replicate=True: every device of `devices` holds the WHOLE corpus and synchronous searches
+        # are dealt round-robin to the replicas (ls_create_replicated) instead of row shards
+        self.replicate = bool(replicate)
+        if self.replicate and not self.devices:
+            raise ValueError("replicate=True needs devices=[...]")
         self.device = int(self.devices[0]) if self.devices else int(device)
         self._base = int(base)
         self._handle: ctypes.c_void_p | None = None
@@ -87,11 +92,12 @@ class FlatIPIndex:
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_array(cls, corpus: np.ndarray, dtype: Any = "f32", device: int = 0,
-                   base: int = 0, devices: Any = None) -> "FlatIPIndex":
+                   base: int = 0, devices: Any = None, replicate: bool = False) -> "FlatIPIndex":
         corpus = np.asarray(corpus)
         if corpus.ndim != 2:
             raise ValueError("corpus must be [n, d]")
-        ix = cls(corpus.shape[1], dtype=dtype, device=device, base=base, devices=devices)
+        ix = cls(corpus.shape[1], dtype=dtype, device=device, base=base, devices=devices,
+                 replicate=replicate)
         ix.add(corpus)
         ix._ensure_built()
         return ix
@@ -206,7 +212,8 @@ class FlatIPIndex:
         h = ctypes.c_void_p()
         if self.devices is not None:
             ids = (ctypes.c_int32 * len(self.devices))(*self.devices)
-            native.check(lib.ls_create_sharded(
+            create = lib.ls_create_replicated if self.replicate else lib.ls_create_sharded
+            native.check(create(
                 ctypes.byref(h), corpus.ctypes.data if corpus.size else None, corpus.shape[0],
                 self.d, self._dtype, ids, len(self.devices)))
         else:

@@ -41,6 +41,7 @@ SYMBOLS: dict[str, tuple] = {
     "ls_create": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _i64, _i32, _i32, _i32]),
     "ls_create_from_device": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _i64, _i32, _i32, _i32]),
     "ls_create_sharded": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _i64, _i32, _i32, _vp, _i32]),
+    "ls_create_replicated": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _i64, _i32, _i32, _vp, _i32]),
     "ls_create_sharded_from_device": (ctypes.c_int, [ctypes.POINTER(_vp), _vp, _vp, _i32, _i32, _vp,
                                                      _i32]),
     "ls_shard_count": (_i32, [_vp]),

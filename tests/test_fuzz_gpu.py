@@ -62,12 +62,13 @@ def test_random_parity_sweep(default_seed):
                 continue
             if cases % 3 == 2:
                 # every third case goes through the device API instead: the same batch queued
-                # three times with LS_FLAG_PIPELINE (scan path: finalize rides on the next launch;
-                # batched paths: the two internal lanes), one ls_check, all three compared
+                # five times with LS_FLAG_PIPELINE (scan path: finalize rides on the next launch;
+                # batched paths: the chain - from the third call on a pass launch carries the sample phase of the
+                # batch two calls ahead), one ls_check, all five compared
                 import torch
 
                 tq = torch.from_numpy(q).cuda()
-                outs = [ix.search_device(tq, k, normalize=normalize, pipeline=True) for _ in range(3)]
+                outs = [ix.search_device(tq, k, normalize=normalize, pipeline=True) for _ in range(5)]
                 ix.check()
                 D, I = outs[0][0].cpu().numpy(), outs[0][1].cpu().numpy()
                 for s_, i_ in outs[1:]:

@@ -277,6 +277,52 @@ def test_enqueue_workers_give_the_same_answer(nq, k, dtype):
         ix.close()
 
 
+def test_replicated_handle_round_robin_and_concurrent_callers():
+    """ls_create_replicated: every device holds the whole corpus, synchronous searches are dealt
+    round-robin to the replicas (three replicas rehearsed on this GPU); results are those of a plain
+    index, add() reaches every replica, threads calling concurrently are served in parallel."""
+    import threading
+
+    n, d, k = 30_000, 96, 40
+    corpus, q = H.int_corpus(81, n, d), H.int_corpus(82, 12, d)
+    ix = FlatIPIndex.from_array(corpus, devices=[0, 0, 0], replicate=True)
+    try:
+        assert [s_[1:] for s_ in ix.shards()] == [(0, n)] * 3      # every replica covers all rows
+        assert ix.exchange_info()["exchange"].startswith("none (replicas")
+        for i in range(7):
+            D, I = ix.search(q[i:i + 1], k)
+            _check(D, I, corpus, q[i:i + 1], k, False, True)
+        assert ix.debug_counter(21) == 7                          # dealt in turn: 3 + 2 + 2
+        more = H.int_corpus(83, 500, d)
+        ix.add(more)
+        both = np.concatenate([corpus, more])
+        assert ix.ntotal == n + 500
+        for i in range(3):                                        # one call per replica: all of them grew
+            D, I = ix.search(q, k)
+            _check(D, I, both, q, k, False, True)
+        errs = []
+
+        def worker(j):
+            try:
+                for _ in range(20):
+                    D, I = ix.search(q[j:j + 1], k)
+                    _check(D, I, both, q[j:j + 1], k, False, True)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        ts = [threading.Thread(target=worker, args=(j,)) for j in range(6)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs[:1]
+        assert np.array_equal(ix.host_corpus(), both)
+        import torch
+
+        s_, i_ = ix.search_device(torch.from_numpy(q).cuda(0), k)   # device queries: the replica on device_ids[0]
+        _check(s_.cpu().numpy(), i_.cpu().numpy(), both, q, k, False, True)
+    finally:
+        ix.close()
+
+
 def test_group_calls_leave_the_callers_device_current():
     """The group entry points hop over the shards' devices; the calling thread's current device
     (shared with PyTorch) must be what it was, on success and on error."""

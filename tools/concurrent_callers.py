@@ -33,3 +33,17 @@ for n in (200_000, 25_000):
         print(f"N={n} d=384 f32 k=50, {T:2d} callers: " + " | ".join(row), flush=True)
     print("   combined batches", ix.debug_counter(16), "requests in them", ix.debug_counter(17), flush=True)
     ix.close()
+
+# Replicas (ls_create_replicated): every visible GPU holds the whole corpus, synchronous calls are dealt
+# round-robin. On a one-GPU box the replicas share the device (a rehearsal of the mechanism: the scans then
+# share one HBM, so there is nothing to gain); on a multi-GPU node this is the number that scales.
+import torch
+ndev = max(1, torch.cuda.device_count())
+devs = list(range(ndev)) if ndev > 1 else [0, 0]
+c = H.gauss(1234, 200_000, 384); q = H.gauss(5678, 16, 384)
+ix = FlatIPIndex.from_array(c, devices=devs, replicate=True)
+for _ in range(50): ix.search(q[:1], 50, normalize=True)
+for T in (1, 2, 4, 8, 16):
+    qps, p50 = run(ix, q, 50, T)
+    print(f"N=200000 d=384 f32 k=50, {len(devs)} replicas on devices {devs}, {T:2d} callers: {qps:8.0f} q/s p50 {p50:6.1f} us", flush=True)
+ix.close()

@@ -179,8 +179,8 @@ int ls_search_device(ls_index* index, const void* d_q, int64_t nq, int32_t k, ui
  * pipelined search queued since the last ls_check final: queries of batched calls whose
  * speculative threshold let fewer than k rows through, or whose candidate queues overflowed, are
  * re-run here by the exact per-query scan path (from the library's own copy of the queries) and
- * their output rows re-written. Returns LS_OK once everything is exact. Up to 128 batched calls
- * may be outstanding; the 129th triggers the same repair step on its own. */
+ * their output rows re-written. Returns LS_OK once everything is exact. Up to 1024 batched calls
+ * (fewer for batches of more than 4096 queries) may be outstanding; one more triggers the same repair step on its own. */
 int ls_check(ls_index* index, void* stream);
 
 /* Copy the per-query verification flags of the most recent search queued on this handle into
@@ -250,6 +250,7 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * query, 15 exchange transport (0 copies, 1 RCCL selected, 2 RCCL communicators initialised, 3 RCCL failed
  * on this node: fell back to peer copies), 19 calls whose shards were queued by the enqueue workers;
  * counter 20: synchronous host calls that had to launch the stand-alone selection (option 9's retry);
+ * counter 22: checks of pending batched calls the library ran on its own (slots exhausted or re-sliced; summed);
  * counters 0, 1, 8, 11, 12 are summed over the shards, 9 and 10 are the primary shard's;
  * counter 16: combined batches ls_search served, 17: the requests they carried; counter 18 (sharded
  * handles): mean host nanoseconds spent queueing one search (every device's work + exchange + merge).

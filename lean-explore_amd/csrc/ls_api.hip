@@ -230,7 +230,7 @@ void ls_destroy(ls_index* ix) {
         (void)hipFree(st.d_tau);
         (void)hipFree(st.d_sample_top);
     }
-    (void)hipFree(ix->d_qkeep);
+    for (float* b : ix->d_qkeep_blk) (void)hipFree(b);
     (void)hipFree(ix->d_overflow);
     if (ix->h_overflow) (void)hipHostFree(ix->h_overflow);
     if (ix->h_q) (void)hipHostFree(ix->h_q);
@@ -516,14 +516,14 @@ int ls_i_batched_repair(ls_index* ix) {
     hipStream_t s = pend.back().stream;
     for (const auto& bc : pend)  // all slots are read after the youngest call has drained
         if (bc.stream != s) LS_HIP(hipStreamSynchronize(bc.stream));
-    LS_HIP(hipMemcpyAsync(ix->h_overflow, ix->d_overflow,
-                          sizeof(u32) * (size_t)(ix->bc_slot_stride * LS_BC_SLOTS),
-                          hipMemcpyDeviceToHost, s));
+    LS_HIP(hipMemcpyAsync(ix->h_overflow, ix->d_overflow,  // (slots are handed out in order: the used prefix)
+                          sizeof(u32) * (size_t)ix->bc_slot_stride * pend.size(), hipMemcpyDeviceToHost, s));
     LS_HIP(hipStreamSynchronize(s));
     bool any = false;
     for (const auto& bc : pend) {
         const u32* fl = ix->h_overflow + (size_t)bc.slot * ix->bc_slot_stride;
-        const float* qk = ix->d_qkeep + (size_t)bc.slot * ix->bc_qkeep_stride;
+        const float* qk = ix->d_qkeep_blk[bc.slot / LS_BC_QKEEP_BLOCK] +
+                          (size_t)(bc.slot % LS_BC_QKEEP_BLOCK) * ix->bc_qkeep_stride;
         for (int64_t q = 0; q < bc.nq;) {
             if (!fl[q] || LS_ABL_NOREPAIR) {
                 ++q;
@@ -773,11 +773,12 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     const int QT = f32 ? 64 : LS_GEMM_WAVES * 16 * QG;  // queries per workgroup
     const int64_t nq_pad = (nq + QT - 1) / QT * QT;
     const int64_t qkeep_need = nq * g.d;
-    if ((int)ix->bc_pending.size() >= LS_BC_SLOTS ||
+    if ((int)ix->bc_pending.size() >= ix->bc_slots() ||
         (!ix->bc_pending.empty() &&
          (nq_pad > ix->bc_slot_stride || qkeep_need > ix->bc_qkeep_stride))) {
         rc = ls_i_batched_repair(ix);  // slots exhausted (or too small): check what is pending
         if (rc != LS_OK) return rc;
+        ix->n_forced_checks++;
     }
     const bool chain = (flags & LS_FLAG_PIPELINE) != 0;
     if (!chain && (rc = ls_i_flush_deferred(ix)) != LS_OK) return rc;
@@ -832,20 +833,26 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     if ((rc = ls_grow(&st.d_tau, &st.tau_cap, (size_t)nq_pad)) != LS_OK) return rc;
     if (ix->bc_pending.empty()) {
         if (nq_pad > ix->bc_slot_stride) ix->bc_slot_stride = nq_pad;
-        if (qkeep_need > ix->bc_qkeep_stride) ix->bc_qkeep_stride = qkeep_need;
+        if (qkeep_need > ix->bc_qkeep_stride) {  // the query copies are re-sliced: drop the old blocks
+            ix->bc_qkeep_stride = qkeep_need;
+            for (float*& blk : ix->d_qkeep_blk) {
+                if (blk) LS_HIP(hipFree(blk));
+                blk = nullptr;
+            }
+        }
     }
     if ((rc = ls_grow(&ix->d_overflow, &ix->overflow_cap,
-                   (size_t)ix->bc_slot_stride * LS_BC_SLOTS)) != LS_OK)
-        return rc;
-    if ((rc = ls_grow(&ix->d_qkeep, &ix->qkeep_cap,
-                   (size_t)ix->bc_qkeep_stride * LS_BC_SLOTS)) != LS_OK)
+                   (size_t)ix->bc_slot_stride * ix->bc_slots())) != LS_OK)
         return rc;
     const int slot = (int)ix->bc_pending.size();
+    float*& qblk = ix->d_qkeep_blk[slot / LS_BC_QKEEP_BLOCK];
+    if (!qblk)
+        LS_HIP(hipMalloc((void**)&qblk, sizeof(float) * (size_t)ix->bc_qkeep_stride * LS_BC_QKEEP_BLOCK));
     u32* d_flags = ix->d_overflow + (size_t)slot * ix->bc_slot_stride;
-    float* d_qkeep = ix->d_qkeep + (size_t)slot * ix->bc_qkeep_stride;
+    float* d_qkeep = qblk + (size_t)(slot % LS_BC_QKEEP_BLOCK) * ix->bc_qkeep_stride;
     if ((rc = ls_grow(&st.d_sample_top, &st.sample_top_cap, nrec * 16)) != LS_OK) return rc;
     if ((rc = ls_grow_pinned(&ix->h_overflow, &ix->h_overflow_cap,
-                          (size_t)ix->bc_slot_stride * LS_BC_SLOTS)) != LS_OK)
+                          (size_t)ix->bc_slot_stride * ix->bc_slots())) != LS_OK)
         return rc;
 
     ls_index::bc_stage b;
@@ -1601,7 +1608,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 21) return -1;
+    if (!ix || which < 0 || which > 22) return -1;
     if (which == 16 || which == 17) {
         std::lock_guard<std::mutex> ql(ix->q_mu);
         return (int64_t)(which == 16 ? ix->n_combined_batches : ix->n_combined_requests);
@@ -1614,6 +1621,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
     if (which == 11) return (int64_t)ix->n_launches_total;
     if (which == 12) return (int64_t)ix->n_chunked_calls;
     if (which == 20) return (int64_t)ix->n_same_launch_retries;
+    if (which == 22) return (int64_t)ix->n_forced_checks;
     if (which > 9) return 0;  // 13..15, 18, 19 and 21 are group counters
     if (hipSetDevice(ix->device) != hipSuccess) return -1;
     u32 v = 0;

@@ -13,7 +13,12 @@ struct ls_shard_group;  // ls_shard.hip
 struct ls_req;          // ls_api.hip: one queued synchronous host search
 
 #define LS_NSETS 2
-#define LS_BC_SLOTS 128  // unchecked batched calls a handle carries before it checks them itself (a check drains the pipeline)
+// Unchecked batched calls a handle carries before it checks them itself (a check drains the pipeline:
+// ~2 batch times). Every slot owns a flag slice (capped at 16 MB in total: fewer slots for huge
+// batches) and a copy of the raw queries; the copies are allocated in blocks of LS_BC_QKEEP_BLOCK slots
+// as the backlog actually grows, so a caller that checks regularly never pays for the rest.
+#define LS_BC_SLOTS 1024
+#define LS_BC_QKEEP_BLOCK 64
 #ifndef LS_BC_LANES
 // Scratch sets that consecutive LS_FLAG_PIPELINE batches rotate over. Four, so that nothing a batch
 // has to wait for is younger than two batches: prep(i+4) rewrites the prepared queries pass(i) read,
@@ -124,8 +129,12 @@ struct ls_index {
     };
     std::vector<batched_call> bc_pending;
     int64_t bc_slot_stride = 0;  // u32 per flag slot
-    float* d_qkeep = nullptr;  size_t qkeep_cap = 0;  // LS_BC_SLOTS x bc_qkeep_stride floats
+    float* d_qkeep_blk[LS_BC_SLOTS / LS_BC_QKEEP_BLOCK] = {};  // each LS_BC_QKEEP_BLOCK x bc_qkeep_stride floats
     int64_t bc_qkeep_stride = 0;
+    int bc_slots() const {  // slots in use for the current slot stride
+        const int64_t by_mem = (4ll << 20) / (bc_slot_stride > 0 ? bc_slot_stride : 1);
+        return (int)(by_mem < 16 ? 16 : (by_mem > LS_BC_SLOTS ? LS_BC_SLOTS : by_mem));
+    }
     u32* d_last_flags = nullptr;  // flag slice of the most recent batched call (ls_export_flags)
     int64_t last_flags_n = 0;
     uint64_t n_batched_fallback = 0;  // queries repaired by the scan path (host counter)
@@ -144,6 +153,7 @@ struct ls_index {
     int32_t opt_multi_query = 1;       // several queries per corpus pass (groups of 8 / 4)
     int32_t opt_same_launch = 1;       // synchronous host calls: the selection rides on its own query's scan launch
     std::vector<ls_fin_params> retry_jobs;  // the same-launch jobs of the host call in flight (LS_DONE_RETRY)
+    uint64_t n_forced_checks = 0;           // checks of pending batched calls the library ran on its own
     uint64_t n_same_launch_retries = 0;     // host calls that had to launch the stand-alone finalize
     u32* d_arrive = nullptr;           // arrival counter of the scan workgroups (same-launch selection)
     u32 arrive_count = 0;              // arrivals queued so far (host mirror; the kernels compare modulo 2^32)

@@ -324,6 +324,60 @@ def test_pipelined_lanes_large_and_ragged_batches():
     ix.close()
 
 
+@pytest.mark.parametrize("nq,k,calls_until_forced", [(24, 100, 1024), (8192, 10, 512)])
+def test_backlog_of_unchecked_calls_is_checked_by_the_library(nq, k, calls_until_forced):
+    """The handle carries up to 1024 unchecked pipelined calls (their flag slices and query copies; fewer
+    when one call's flag slice is large: 16 MB of flags in total); the call after that makes the library
+    run the check itself. A planted cluster in call 2 needs a repair: it must have happened by then -
+    before the caller's own ls_check - and calls queued after the forced check are still covered by the
+    caller's ls_check (second cluster)."""
+    import torch
+
+    d = 384
+    c = H.gauss(97, 200_000, d)
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda:0")
+    total = calls_until_forced + 6
+    planted = {2: 3125 * 7 + 40 * 32, calls_until_forced + 3: 3125 * 20 + 40 * 32}
+    qsmall = {i: H.gauss(700 + i, 24, d) for i in planted}
+    for i, lo in planted.items():
+        for r in range(lo, lo + 300):
+            v = qsmall[i][0] + 0.05 * rng.standard_normal(d).astype(np.float32)
+            c[r] = v / np.linalg.norm(v)
+    ix = FlatIPIndex.from_array(c, dtype="f16")
+    base = torch.from_numpy(H.gauss(698, nq, d)).to(dev)
+    keep = {}
+    for i in range(total):
+        tq = base.clone() if i in planted or i % 97 == 0 else base
+        if i in planted:
+            tq[:24] = torch.from_numpy(qsmall[i]).to(dev)
+        s = ii = None
+        if nq > 1000 and i not in planted and i % 97:  # (big batches: one shared output for the unverified calls)
+            s, ii = keep.setdefault("shared", (torch.empty((nq, k), device=dev),
+                                               torch.empty((nq, k), dtype=torch.int64, device=dev)))
+        out = ix.search_device(tq, k, s, ii, pipeline=True)
+        if i in planted or i % 97 == 0:
+            keep[i] = (tq[:24].cpu().numpy(), out)
+        if i == calls_until_forced - 1:
+            assert ix.debug_counter(22) == 0, "no check may have run yet"
+        if i == calls_until_forced:
+            assert ix.debug_counter(22) == 1, "the library must have checked the backlog itself"
+            assert ix.debug_counter(8) >= 1, "... and repaired call 2"
+    assert ix.debug_counter(12) == 0, "the batches must not have been cut into checked sub-batches"
+    forced = ix.debug_counter(8)
+    ix.check()
+    assert ix.debug_counter(8) > forced, "the second cluster is repaired by the caller's check"
+    for i, val in keep.items():
+        if i == "shared":
+            continue
+        q, (s_, i_) = val
+        Dr, Ir = oracle.c_search(c, q, k, f16=True)
+        _, _, S = oracle.np_search(c, q, k, f16=True)
+        rep = oracle.compare_topk(s_[:24].cpu().numpy(), i_[:24].cpu().numpy(), Dr, Ir, S)
+        assert rep["recall"] == 1.0, (i, rep)
+    ix.close()
+
+
 @pytest.mark.parametrize("d", [100, 250, 384, 768])
 def test_pipelined_run_needs_no_repairs(d):
     """A steady pipelined run (every pass launch carries the sample phase of the batch two calls ahead where

@@ -27,6 +27,9 @@ typedef unsigned int u32;
 #define LS_KP_MAX 16                 // per-workgroup emitted candidates (k') + 1 bound
 #define LS_FINAL_THREADS 1024
 #define LS_FINAL_CAP 8192            // keys the finalize workgroup sorts in LDS (64 KiB)
+#ifndef LS_SS_MAX_KEYS
+#define LS_SS_MAX_KEYS 4096           // lists up to this long are ordered by splitter buckets (64 buckets of <= 256)
+#endif
 #define LS_SCAN_PATH_MAX_NQ 16            // nq <= this: per-query HBM-bound scan path
 #ifndef LS_SCAN_MQ_SCATTER
 #define LS_SCAN_MQ_SCATTER 1          // multi-query scan launches: reduce-scatter of the partial sums (0: one butterfly per pair)

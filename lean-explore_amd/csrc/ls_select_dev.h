@@ -285,6 +285,17 @@ __device__ unsigned long long g_fin_stamp[8];
 #else
 #define LS_STAMP(i) do {} while (0)
 #endif
+// splitter buckets (lds_topk): the sorted sample's every (LS_SS_SAMPLE/64)-th key is a splitter; bucket of a
+// key = number of splitters (j = 0..62, descending) above it
+#define LS_SS_SAMPLE 128
+__device__ __forceinline__ int ss_bucket(const u64* ssort, u64 key) {
+    constexpr int S = LS_SS_SAMPLE / 64;
+    int lo = 0;
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1)
+        if (ssort[S * (lo + step - 1) + (S - 1)] > key) lo += step;
+    return lo;
+}
 static __device__ __forceinline__ int lds_topk(const u64* keys, int cnt, int k, u64* res, u64* tmp, u32* hist, u32* misc,
                         int tid, int nt) {
     if (k > cnt) k = cnt;
@@ -311,6 +322,139 @@ static __device__ __forceinline__ int lds_topk(const u64* keys, int cnt, int k, 
         LS_STAMP(4);
         LS_STAMP(5);
         return k < nnz ? k : nnz;
+    }
+    if (cnt <= LS_SS_MAX_KEYS && nt >= 256 && nt % 256 == 0) {  // (nt / LS_SS_SAMPLE: a power of two <= 64)
+        // ---- splitter buckets (round 4): one bucketing by DATA QUANTILES instead of radix digits ----------
+        // 128 of the keys (an even stride through the list) are ranked by counting; every 2nd of them is
+        // a splitter, which cuts the key space into 64 buckets of ~cnt/64 keys WHATEVER the values look
+        // like - real keys are distinct (distinct rows), so BM25's thousands of equal scores spread over
+        // the buckets like anything else, where the radix digits of the score half put them all in one
+        // bin (k-th key 8.4 + row passes and compaction 5.0 + sorting network 9.2 us at k = 1000). A key's
+        // bucket is a 6-step binary search; a count per bucket and one prefix scan say which bucket holds
+        // the k-th key; the buckets above it are scattered to their final slot ranges in res[], the
+        // straddling one to tmp[]; a key's rank is its bucket's first slot + the larger keys of its own
+        // bucket. 7 barriers, no radix pass, no sorting network; falls through to the radix code below if a
+        // bucket turns out long (> 256: a stride that resonates with the list's structure).
+        constexpr int NS = LS_SS_SAMPLE;
+        const int G = nt / NS;  // threads per sample key
+        u64* const ssort = reinterpret_cast<u64*>(hist);  // NS u64 <= hist[0..512)
+        u32* const bcnt = hist + 512;
+        u32* const bstart = hist + 576;
+        u32* const bcur = hist + 640;
+        unsigned char* const bid = reinterpret_cast<unsigned char*>(hist + 704);  // bucket of keys[i], <= 4096 B
+        unsigned char* const posb = reinterpret_cast<unsigned char*>(hist);       // bucket of res[i] (ssort is dead by then)
+        if (tid < NS) {
+            // (a "no result" key in the sample becomes a distinct value below every real key - real keys carry
+            // a non-zero score half - so that plain > ranks the sample as a permutation)
+            const u64 sk = keys[(int)(((long long)tid * cnt) / NS)];
+            tmp[tid] = sk != 0ull ? sk : (u64)(tid + 1);
+        }
+        if (tid < 64) bcnt[tid] = 0u;
+        __syncthreads();
+        {
+            const int me = tid / G, part = tid % G;
+            const u64 mine = tmp[me];
+            int rank = 0;
+#pragma unroll 8
+            for (int j = part; j < NS; j += G) rank += tmp[j] > mine;
+            for (int o = 1; o < G; o <<= 1) rank += __shfl_xor(rank, o, 64);
+            if (part == 0) ssort[rank] = mine;
+        }
+        __syncthreads();
+        for (int i = tid; i < cnt; i += nt) {
+            const u64 key = keys[i];
+            if (key != 0ull) {
+                const int b = ss_bucket(ssort, key);
+                bid[i] = (unsigned char)b;
+                atomicAdd(&bcnt[b], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const u32 c = bcnt[tid];
+            u32 inc = c;
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 t = (u32)__shfl_up((int)inc, o, 64);
+                if (tid >= o) inc += t;
+            }
+            const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+            const u32 kq = (u32)k < total ? (u32)k : total;  // min(k, #non-zero keys)
+            const u32 start = inc - c;
+            bstart[tid] = start;
+            bcur[tid] = 0u;
+            u32 big = start < kq ? c : 0u;  // only the buckets that reach into the top kq are walked
+            for (int o = 32; o >= 1; o >>= 1) {
+                const u32 t = (u32)__shfl_xor((int)big, o, 64);
+                big = t > big ? t : big;
+            }
+            if (kq > 0 && start < kq && kq <= inc) {  // exactly one lane: the bucket that holds the kq-th key
+                misc[0] = (u32)tid;
+                misc[1] = start;
+                misc[2] = c;
+            }
+            if (tid == 0) {
+                misc[3] = kq;
+                misc[4] = big;
+            }
+        }
+        __syncthreads();
+        const int kk = (int)misc[3];
+        if (kk == 0) return 0;
+        if (misc[4] <= 256u) {
+            const int bk = (int)misc[0], nres = (int)misc[1], cbk = (int)misc[2];
+            LS_STAMP(3);
+            for (int i = tid; i < cnt; i += nt) {
+                const u64 key = keys[i];
+                if (key == 0ull) continue;
+                const int b = (int)bid[i];
+                if (b < bk) {
+                    const u32 at = bstart[b] + atomicAdd(&bcur[b], 1u);
+                    res[at] = key;
+                    posb[at] = (unsigned char)b;
+                } else if (b == bk) {
+                    tmp[atomicAdd(&bcur[b], 1u)] = key;
+                }
+            }
+            __syncthreads();
+            LS_STAMP(4);
+            constexpr int E = LS_RES_CAP / 256;  // keys of res[] per thread at most (256 threads, k = 2048)
+            u64 mine[E];
+            int rank[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = tid + e * nt;
+                mine[e] = 0ull;
+                rank[e] = 0;
+                if (i < nres) {
+                    const u64 key = res[i];
+                    const int b = (int)posb[i];
+                    const int lo = (int)bstart[b], n = (int)bcnt[b];
+                    int r = lo;
+#pragma unroll 8
+                    for (int j = lo; j < lo + n; ++j) r += res[j] > key;
+                    mine[e] = key;
+                    rank[e] = r;
+                }
+            }
+            u64 tk = 0ull;  // the straddling bucket: only its ranks below kk are results
+            int tr = kk;
+            if (tid < cbk) {
+                tk = tmp[tid];
+                int r = nres;
+#pragma unroll 8
+                for (int j = 0; j < cbk; ++j) r += tmp[j] > tk;
+                tr = r;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (tid + e * nt < nres) res[rank[e]] = mine[e];
+            if (tr < kk) res[tr] = tk;
+            __syncthreads();
+            LS_STAMP(5);
+            return kk;
+        }
+        __syncthreads();  // a long bucket: the radix code below starts over (it re-initialises hist and misc)
     }
     const int lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
     const int cnt_pad = (cnt + 63) & ~63;  // whole waves take part in the ballots
@@ -659,8 +803,10 @@ __host__ __device__ __forceinline__ size_t ls_fin_lds_bytes(int keys_cap, int ke
 
 // One workgroup of NT threads produces the final (scores, rows)[k] of one query.
 // `arrived` = false: a same-launch job whose wait for the scan workgroups timed out.
+// (forced inline: as a call, `p` - an element of the kernel's by-value job array - would be copied to
+// scratch memory to have an address: 984 bytes per lane)
 template <int NT>
-static __device__ void finalize_body(const ls_fin_params& p, unsigned char* smem, int tid,
+static __device__ __forceinline__ void finalize_body(const ls_fin_params& p, unsigned char* smem, int tid,
                                      bool arrived = true) {
     const int keff = (long long)p.k < p.n ? p.k : (int)p.n;
     u64* keys = reinterpret_cast<u64*>(smem);

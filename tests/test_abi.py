@@ -90,7 +90,7 @@ def test_register_budget_of_the_co_resident_kernels(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     csrc = ROOT / "lean-explore_amd" / "csrc"
     usage = {}
-    for src, extra in (("ls_gemm.hip", ["-DLS_GEMM_ONLY_CASE=48"]), ("ls_wsel.hip", [])):
+    for src, extra in (("ls_gemm.hip", ["-DLS_GEMM_ONLY_CASE=48"]), ("ls_wsel.hip", []), ("ls_select.hip", [])):
         p = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast",
                             "-Rpass-analysis=kernel-resource-usage", *extra, "-c", str(csrc / src), "-o",
                             str(tmp_path / (src + ".o"))], capture_output=True, text=True, timeout=900)
@@ -117,3 +117,7 @@ def test_register_budget_of_the_co_resident_kernels(tmp_path):
     for n, u in {**pick("ls_wave_select_kernelILi4E"), **pick("ls_wave_select_kernelILi8E"),
                  **pick("ls_prep_f16_kernel")}.items():
         assert u["VGPRs"] <= 48 and u["ScratchSize [bytes/lane]"] == 0, (n, u)
+    # the selection workgroup must not touch scratch memory (a non-inlined finalize_body once copied the
+    # kernel's whole job array there: 984 bytes per lane)
+    for n, u in {**pick("ls_finalize_kernel"), **pick("ls_merge_kernel")}.items():
+        assert u["ScratchSize [bytes/lane]"] == 0, (n, u)

@@ -13,5 +13,6 @@ for _ in range(K): ix.retrieve(q,1000)
 dt=(time.perf_counter()-t0)/K
 print(f"bm25 N=200k query={q} postings={nnz}: {dt*1e6:.1f} us/query (host API, sync) {1/dt:.0f} QPS; bytes={nnz*8+200000*12}")
 print("selection left the fast path:", ix.debug_counter(0), "of", 320, "queries; general path:", ix.debug_counter(1))
-ph=[ix.debug_counter(i) for i in range(2,7)]
-if any(ph): print("finalize phases (100 MHz ticks): load", ph[0], "score-radix", ph[1], "row-radix+compact", ph[2], "sort", ph[3], "output", ph[4])
+ph=[ix.debug_counter(i)/100.0 for i in range(2,8)]
+if any(ph): print("selection phases of a -DLS_FIN_TIMING build (us): loads issued + pivot", ph[0], "| survivors to LDS", ph[1], "| sample ranked + bucket counts + scan", ph[2],
+                  "| scatter", ph[3], "| order", ph[4], "| output + done", ph[5])

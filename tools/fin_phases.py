@@ -2,8 +2,9 @@
 """Phases of the selection step (finalize_body) of a synchronous host search, variant build -DLS_FIN_TIMING:
   make -C lean-explore_amd/csrc variant NAME=ftime VFLAGS=-DLS_FIN_TIMING
   LEANSEARCH_LIB=lean-explore_amd/variants/libleansearch_ftime.so python tools/fin_phases.py
-100 MHz stamps of the selection workgroup: pivot found | pre-filtered keys in LDS | k-th key found (radix passes) |
-survivors compacted | ordered | outputs written + completion word."""
+100 MHz stamps of the selection workgroup: pivot found | pre-filtered keys in LDS | k-th key found (radix passes; lists of
+257..4096 keys: sample ranked + bucket counts + scan of the splitter buckets) | survivors compacted (scattered to their
+buckets) | ordered | outputs written + completion word."""
 import sys, time
 from pathlib import Path
 import numpy as np

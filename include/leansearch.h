@@ -228,9 +228,11 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * certified k-th sample score); option 6: several queries per corpus pass on the scan path
  * (default on); option 7: force the number of scan workgroups per launch (0 = automatic);
  * option 9: synchronous host searches (ls_search, nq <= 16) run the selection step inside the scan
- * launch of its own query, behind an arrival counter of the scan workgroups (fence-free hand-off of the
- * emitted keys; a query whose keys cannot be proven complete answers "retry" in its completion word
- * and the host launches the stand-alone selection): 0 off, 1 on (default);
+ * launch of its own query, sweeping the tagged 16-byte granules the scan workgroups write their keys as
+ * (no drain, no counter, no fence; a query whose keys cannot be proven complete answers "retry" in its
+ * completion word and the host launches the stand-alone selection): 0 off, 1 on (default);
+ * option 15: synchronous host searches bring the query to device memory with a copy command in front of
+ * the launch (1, default) or let the scan workgroups read the pinned host copy over PCIe (0: 4-5 us slower);
  * option 10: synchronous host searches (ls_search) that arrive while another one is running are
  * served together, up to 16 queries of equal k and flags per corpus pass (default on);
  * option 13: pipelined fp16 batches of stored rows of up to 768 bytes let the sample phase of the batch

@@ -148,8 +148,8 @@ class BM25Index:
         docs = np.empty(k, dtype=np.int64)
         scores = np.empty(k, dtype=np.float32)
         native.check(native.load().ls_bm25_search(
-            self._ensure(), ids.ctypes.data if ids.size else None, ids.size, int(k),
-            scores.ctypes.data, docs.ctypes.data))
+            self._ensure(), native.addr(ids), ids.size, int(k), native.addr(scores),
+            native.addr(docs)))
         return docs, scores
 
     def get_scores_host(self, query_tokens: list[str]) -> np.ndarray:

@@ -211,11 +211,11 @@ void ls_destroy(ls_index* ix) {
         (void)hipFree(st.d_S);
         (void)hipFree(st.d_cand);
         (void)hipFree(st.d_bound);
+        (void)hipFree(st.d_gran);
     }
     (void)hipFree(ix->d_out_s);
     (void)hipFree(ix->d_out_i);
     (void)hipFree(ix->d_counters);
-    (void)hipFree(ix->d_arrive);
     (void)hipFree(ix->d_qpad);
     for (hipStream_t cs : {ix->chain_main[0], ix->chain_main[1], ix->chain_sel})
         if (cs) (void)hipStreamSynchronize(cs);
@@ -393,9 +393,9 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         a.nfin = 0;
         // Synchronous host-API calls (ls_search: the reference's call, search/engine.py:250): the
         // selection jobs of THIS group ride on its own scan launch and wait inside the kernel for
-        // the scan workgroups' arrival counter - one launch per group instead of scan + selection,
-        // no kernel boundary and no second launch latency in front of the selection. The hand-off
-        // is fence-free (write-through keys, drained, relaxed counter: ls_fin_params::arrive); a job
+        // the scan workgroups' keys - one launch per group instead of scan + selection, no kernel
+        // boundary and no second launch latency in front of the selection. The hand-off is the
+        // data itself (tagged write-through granules, no drain, no counter: ls_fin_params::gran); a job
         // whose emitted keys cannot be proven complete answers LS_DONE_RETRY in its completion word
         // and the host launches the stand-alone finalize behind the scan (host_search_locked).
         // Only on the library's own stream and only with completion words to answer through: a
@@ -404,6 +404,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         const bool same_launch =
             !pipeline && ix->n > 0 && ix->opt_same_launch != 0 && ix->done_base != nullptr &&
             s == ix->own_stream && keff <= 256 &&  // (k > 256 orders its result on 1024 threads: own launch)
+            (int64_t)blocks * (kprime + 1) <= LS_GRAN_MAX &&
             ls_fin_lds_bytes_host(own_keys_cap, (int)std::max<int64_t>(keff, 1)) <= LS_PIGGY_LDS_MAX;
         if (ix->n_pending && same_launch) {  // left by an earlier pipelined call: its own launch
             rc = ls_i_flush_pending(ix);
@@ -443,17 +444,17 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         a.blocks = blocks;
         a.kprime = kprime;
         ls_fin_batch& jobs = same_launch ? a.fin : ix->pending;
-        // the device counter only moves when a launch runs: the host mirror follows it AFTER the
-        // launch call succeeded (a failed launch must not leave the target ahead of the counter)
-        const u32 arrive_target = ix->arrive_count + (u32)blocks;
         if (same_launch) {
-            if (!ix->d_arrive) {
-                LS_HIP(hipMalloc((void**)&ix->d_arrive, sizeof(u32)));
-                LS_HIP(hipMemsetAsync(ix->d_arrive, 0, sizeof(u32), s));
-                ix->arrive_count = 0;
+            if (!st.d_gran) {  // zeroed once: no granule of a later launch carries tag 0
+                const size_t bytes = (size_t)LS_QUERIES_PER_LAUNCH_MAX * LS_GRAN_MAX * 16;
+                LS_HIP(hipMalloc(&st.d_gran, bytes));
+                LS_HIP(hipMemsetAsync(st.d_gran, 0, bytes, s));
             }
+            if (++ix->gran_tag == 0) ix->gran_tag = 1;
             a.nfin = real;
-            a.arrive = ix->d_arrive;
+            a.d_gran = st.d_gran;
+            a.g_stride = LS_GRAN_MAX;
+            a.tag = ix->gran_tag;
         }
         for (int i = 0; i < real; ++i) {
             ls_fin_params& p = jobs.p[i];
@@ -472,14 +473,14 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             p.counters = ix->d_counters;
             p.done = ix->done_base ? ix->done_base + (q0 + i) : nullptr;
             p.done_val = ix->done_seq;
-            p.arrive = same_launch ? ix->d_arrive : nullptr;
-            p.arrive_target = same_launch ? ix->arrive_count + (u32)blocks : 0u;
+            p.gran = same_launch ? (const char*)st.d_gran + (size_t)i * LS_GRAN_MAX * 16 : nullptr;
+            p.tag = same_launch ? ix->gran_tag : 0u;
+            p.wait = same_launch ? 1u : 0u;
             if (same_launch) ix->retry_jobs.push_back(p);  // kept until the host has seen the answers
         }
         if (prof) LS_HIP(hipEventRecord(pe[0], s));
         rc = ls_launch_scan(ix->d_corpus, ix->n, g, a, s);
         if (rc != LS_OK) return rc;
-        if (same_launch) ix->arrive_count = arrive_target;
         ix->n_launches_total++;
         if (prof) {
             LS_HIP(hipEventRecord(pe[1], s));
@@ -1045,16 +1046,22 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
         if ((rc = ls_grow_pinned(&ix->h_out_i, &c2, on)) != LS_OK) return rc;
         ix->h_out_cap = std::min(c1, c2);
     }
-    // Pinned host buffers are device-visible: kernels read the queries from h_q and write the
-    // results into h_out_* over PCIe themselves, which saves the copy commands' serial latency
-    // (measured in tools/hostapi_time.py).
-    const bool in_direct = nq <= LS_SCAN_PATH_MAX_NQ;    // big batches: one bulk copy is better
+    // Pinned host buffers are device-visible. Results: the selection writes the output rows into
+    // h_out_* over PCIe itself (no copy command behind the kernel). Queries: a copy command in front
+    // of the launch. Round 3 let the scan workgroups read the pinned query themselves "to save the copy
+    // command's latency"; tools/host_roundtrip_probe.hip says otherwise: 448 workgroups reading 1.5 KB
+    // from pinned host memory start 7.4 us late, behind a copy command 2.7 us late (kernel arguments:
+    // 1.5 us, but 4 KB of them do not hold the reference's d = 1024 query), and the timeline of a call
+    // (tools/handoff_timeline.py) showed the last scan workgroup ending 50.1 us after the first
+    // started, against 46.5 us with the query in HBM. Debug option 15 = 0 brings the direct read back.
+    const bool small_call = nq <= LS_SCAN_PATH_MAX_NQ;
+    const bool in_direct = small_call && !ix->opt_query_copy;
     const bool out_direct = on <= (size_t)(1 << 16);
     // Small scan-path calls: the finalize workgroup of every query publishes a completion word
     // in pinned host memory once its (pinned) output rows are visible; the host spins on those
     // words instead of sleeping in hipStreamSynchronize (whose wake-up costs more than the
     // 47 us scan's launch). Falls back to the stream sync after 2 ms.
-    const bool spin = in_direct && out_direct && !ls_i_batched_eligible(ix, nq, k) && ix->n > 0;
+    const bool spin = small_call && out_direct && !ls_i_batched_eligible(ix, nq, k) && ix->n > 0;
     if (spin && !ix->h_done) {
         LS_HIP(hipHostMalloc((void**)&ix->h_done, sizeof(u32) * LS_SCAN_PATH_MAX_NQ, hipHostMallocDefault));
         memset(ix->h_done, 0, sizeof(u32) * LS_SCAN_PATH_MAX_NQ);
@@ -1127,7 +1134,7 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
                 const int64_t qi = p.done - ix->h_done;
                 if (qi < 0 || qi >= nq || ix->h_done[qi] != (ix->done_seq | LS_DONE_RETRY)) continue;
                 jobs.p[nj] = p;
-                jobs.p[nj].arrive = nullptr;
+                jobs.p[nj].wait = 0;  // behind the kernel boundary every granule is there
                 jobs.p[nj].keys_cap = LS_FINAL_CAP;
                 if (++nj == LS_QUERIES_PER_LAUNCH_MAX && (rc = flush()) != LS_OK) return rc;
             }
@@ -1530,6 +1537,10 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
     }
     if (which == 14) {  // one-wave select kernel (co-resident with a running pass): default on
         ix->opt_wave_select = value != 0;
+        return LS_OK;
+    }
+    if (which == 15) {  // synchronous host calls: copy command for the query (1, default) / kernels read pinned memory (0)
+        ix->opt_query_copy = value != 0;
         return LS_OK;
     }
     if (which == 9) {  // synchronous host calls: selection inside the scan launch of its own query (default on)

@@ -19,6 +19,7 @@
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 #define LS_WAVE 64
 #define LS_CORPUS_PAD_ROWS 128       // zero rows kept behind the stored corpus (whole-tile reads)
@@ -189,19 +190,25 @@ struct ls_fin_params {
     u32* done;             // optional: pinned host word that receives done_val once the outputs
     u32 done_val;          //           are visible to the host (the host API spins on it)
     // Same-launch selection (synchronous host API only): the job rides on the scan launch of ITS
-    // OWN query and waits until *arrive has reached arrive_target. The scan workgroups publish
-    // their k' keys + bound with write-through (sc1) stores, drain them (s_waitcnt vmcnt(0)) and
-    // add 1 - no release fence: nothing else has to become visible, because the score vector S is
-    // NOT part of the hand-off (plain stores, possibly still dirty in another XCD's L2). If the
-    // emitted keys cannot be proven complete (or the wait times out), the job does not fall back
-    // to S inside the launch: it publishes done_val | LS_DONE_RETRY and the host launches the
-    // stand-alone finalize behind the scan (a kernel boundary makes S visible). Null: the
-    // candidates were written by an earlier launch (stream order), nothing to wait for.
-    u32* arrive;
-    u32 arrive_target;
+    // OWN query. The hand-off is the data itself: every scan workgroup writes its k' keys and its
+    // bound as 16-byte granules {key, tag, 0} with ONE write-through (sc1) store each - no drain, no
+    // barrier, no arrival counter - and the selection workgroup sweeps the granule array (sc1
+    // loads) until every granule carries this launch's tag. Layout: rank-major,
+    // granule[r * blocks + b] = r-th best key of scan workgroup b, plane r = kprime = the bounds.
+    // The score vector S is NOT part of the hand-off (plain stores, possibly still dirty in another
+    // XCD's L2): if the emitted keys cannot be proven complete (or the sweep times out), the job
+    // does not fall back to S inside the launch: it publishes done_val | LS_DONE_RETRY and the host
+    // launches the stand-alone finalize behind the scan (a kernel boundary makes S visible), which
+    // reads the same granules with wait = 0.
+    const void* gran;      // non-null: the candidates are granules (cand / bound unused)
+    u32 tag;               // this launch's tag (never 0)
+    u32 wait;              // 1: the granules are being written by this very launch: sweep for the tag
 };
 #define LS_DONE_RETRY 0x80000000u        // completion word: "run the stand-alone finalize for this query"
 #define LS_ARRIVE_TIMEOUT_TICKS 20000000ull  // 200 ms of the 100 MHz clock: give up waiting, ask for a retry
+#define LS_GRAN_MAX 4096                 // granules per query: blocks * (kprime + 1) above this -> own launch
+#define LS_BUF_RSRC_FLAGS 0x00020000     // gfx950 raw buffer descriptor, dword 3 (32-bit data format)
+#define LS_AUX_SC1 16                    // buffer load / store cache policy: write-through / L1 bypass
 #define LS_QUERIES_PER_LAUNCH_MAX 8
 struct ls_fin_batch {
     ls_fin_params p[LS_QUERIES_PER_LAUNCH_MAX];
@@ -235,7 +242,9 @@ struct ls_scan_args {
     int blocks, kprime;
     int nfin;              // selection jobs riding on this launch
     ls_fin_batch fin;
-    u32* arrive;           // non-null: the jobs are this launch's own (see ls_fin_params::arrive)
+    void* d_gran;          // non-null: the jobs are this launch's own and the keys go out as
+    long long g_stride;    //           tagged granules (ls_fin_params::gran), g_stride granules per query
+    u32 tag;
 };
 int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const ls_scan_args& a,
                    hipStream_t s);

@@ -62,6 +62,8 @@ struct ls_index {
         float* d_S = nullptr;        // n floats
         u64* d_cand = nullptr;       // max_blocks * LS_KP_MAX
         u64* d_bound = nullptr;      // max_blocks
+        void* d_gran = nullptr;      // same-launch selection: LS_QUERIES_PER_LAUNCH_MAX * LS_GRAN_MAX tagged
+                                     // 16-byte granules (ls_fin_params::gran), allocated at first use
     } sets[LS_NSETS];
     hipStream_t last_scan_stream = nullptr;
     bool scan_used = false;
@@ -151,12 +153,13 @@ struct ls_index {
     float* d_qpad = nullptr; size_t qpad_cap = 0;  // padded query group (ragged last group)
     long long s_stride = 0;            // floats between the score vectors of one generation
     int32_t opt_multi_query = 1;       // several queries per corpus pass (groups of 8 / 4)
+    int32_t opt_query_copy = 0;        // synchronous host calls: 0 = the kernels read the pinned host copy over PCIe
+                                       // themselves, 1 = a copy command brings the query to device memory first
     int32_t opt_same_launch = 1;       // synchronous host calls: the selection rides on its own query's scan launch
     std::vector<ls_fin_params> retry_jobs;  // the same-launch jobs of the host call in flight (LS_DONE_RETRY)
     uint64_t n_forced_checks = 0;           // checks of pending batched calls the library ran on its own
     uint64_t n_same_launch_retries = 0;     // host calls that had to launch the stand-alone finalize
-    u32* d_arrive = nullptr;           // arrival counter of the scan workgroups (same-launch selection)
-    u32 arrive_count = 0;              // arrivals queued so far (host mirror; the kernels compare modulo 2^32)
+    u32 gran_tag = 0;                  // tag of the last same-launch selection (ls_fin_params::tag; never 0)
     int32_t max_blocks = 0;
     float* d_out_s = nullptr;  int64_t* d_out_i = nullptr;  size_t out_cap = 0;  // nq*k
     u32* d_counters = nullptr;                        // [0] finalize slow-path count

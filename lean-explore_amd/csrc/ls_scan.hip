@@ -220,43 +220,24 @@ __global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void l
     const f32x4* __restrict__ corpus, long long n, int chunks, const float* __restrict__ qraw,
     int d, int normalize, int reverse, float* __restrict__ S, long long s_stride,
     u64* __restrict__ cand, long long c_stride, u64* __restrict__ bound, long long b_stride,
-    int kprime, int nfin, ls_fin_batch fin, u32* __restrict__ arrive) {
+    int kprime, int nfin, ls_fin_batch fin, void* __restrict__ gran, long long g_stride, u32 tag) {
     // The first `nfin` workgroups of a launch run the PREVIOUS launch's selection jobs
     // (finalize_body, ls_select_dev.h) while every other workgroup scans for the current queries:
     // selection costs neither a launch nor a kernel boundary and hides under the scan.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     if ((int)blockIdx.x < nfin) {
-        const ls_fin_params& fp = fin.p[blockIdx.x];
-        bool arrived = true;
-        if (fp.arrive) {
-            // this launch's own scan workgroups produce the job's input: ONE lane polls (relaxed,
-            // sc1) until all of them have arrived; finalize_body then reads their keys with sc1
-            // loads (no acquire fence). The scan workgroups never wait for anything;
-            // should they not get to run while this workgroup holds its slot (a CU-masked stream, a
-            // partitioned device) the wait gives up after 200 ms and asks the host for a retry.
-            u32* flag = reinterpret_cast<u32*>(smem_dyn);
-            if (threadIdx.x == 0) {
-                const unsigned long long t0 = wall_clock64();
-                u32 ok = 1;
-                while ((int)(__hip_atomic_load(fp.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                             fp.arrive_target) < 0) {
-                    __builtin_amdgcn_s_sleep(4);
-                    if (wall_clock64() - t0 > LS_ARRIVE_TIMEOUT_TICKS) {
-                        ok = 0;
-                        break;
-                    }
-                }
-                *flag = ok;
-            }
-            __syncthreads();
-            arrived = *flag != 0;
-            __syncthreads();  // smem_dyn is finalize_body's from here on
-        }
-        finalize_body<LS_SCAN_THREADS>(fp, smem_dyn, threadIdx.x, arrived);
+        // (a job of this launch's OWN queries - ls_fin_params::wait - sweeps the tagged granules the
+        // scan workgroups below are writing; they never wait for anything. Should they not get to
+        // run while this workgroup holds its slot (a CU-masked stream, a partitioned device) the
+        // sweep gives up after 200 ms and asks the host for a retry.)
+        finalize_body<LS_SCAN_THREADS>(fin.p[blockIdx.x], smem_dyn, threadIdx.x);
         return;
     }
     const int bid = (int)blockIdx.x - nfin;
     const int nblk = (int)gridDim.x - nfin;
+#ifdef LS_HANDOFF_TIMING
+    if (threadIdx.x == 0) atomicMax(&g_ho[0], ~wall_clock64());
+#endif
 #ifdef LS_SCAN_TIMING  // developer instrumentation: phase stamps (100 MHz ticks) of one scan workgroup
     unsigned long long stamp[6];
 #define LS_SSTAMP(i) stamp[i] = wall_clock64()
@@ -476,28 +457,25 @@ __global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void l
                 rank += (o > mine) || (o == mine && i < lane);
             }
         }
-        if (arrive) {
-            // same-launch selection: the keys are the whole hand-off, written THROUGH (sc1) so that
-            // a workgroup behind another XCD's L2 reads them from memory; no release fence
-            if (rank < kprime)
-                __hip_atomic_store(&cand[qi * c_stride + (long long)bid * kprime + rank], mine,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (rank == kprime)
-                __hip_atomic_store(&bound[qi * b_stride + bid], mine, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+        if (gran) {
+            // same-launch selection: the keys are the whole hand-off - ONE 16-byte write-through
+            // (sc1) store per key, {key, tag}: the selection workgroup recognises this launch's data
+            // by the tag, so there is nothing to drain, no barrier and no counter behind the stores
+            // (ls_fin_params::gran; rank-major: granule [rank][workgroup], plane kprime = bounds)
+            if (rank <= kprime) {
+                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (char*)gran + (long long)qi * g_stride * 16, 0, nblk * (kprime + 1) * 16, LS_BUF_RSRC_FLAGS);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{(u32)mine, (u32)(mine >> 32), tag, 0u}, rsrc,
+                                                       (rank * nblk + bid) * 16, 0, LS_AUX_SC1);
+            }
         } else {
             if (rank < kprime) cand[qi * c_stride + (long long)bid * kprime + rank] = mine;
             if (rank == kprime) bound[qi * b_stride + bid] = mine;
         }
     }
-    if (arrive) {
-        // "drained sc1" hand-off (MI355X_MICROARCH.md, handoff-flag): every wave waits for its
-        // write-through stores, the workgroup meets, ONE lane adds 1 (relaxed, agent scope)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0)
-            __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+#ifdef LS_HANDOFF_TIMING
+    if (threadIdx.x == 0) atomicMax(&g_ho[1], wall_clock64());
+#endif
 #ifdef LS_SCAN_TIMING
     LS_SSTAMP(4);
     if (bid == nblk / 2 && threadIdx.x == 0)
@@ -576,7 +554,7 @@ static int launch_lvq(const void* corpus, int64_t n, const ls_geom& g, const ls_
                            (const f32x4*)corpus, (long long)n, g.chunks, a.d_q, g.d,               \
                            a.normalize ? 1 : 0, a.reverse ? 1 : 0, a.d_S, (long long)a.s_stride,   \
                            a.d_cand, (long long)a.c_stride, a.d_bound, (long long)a.b_stride,      \
-                           a.kprime, a.nfin, a.fin, a.arrive);                                     \
+                           a.kprime, a.nfin, a.fin, a.d_gran, (long long)a.g_stride, a.tag);                                     \
     }
     if constexpr (NQ == 1) {
         if (small) LS_SCAN_LAUNCH(true) else LS_SCAN_LAUNCH(false)

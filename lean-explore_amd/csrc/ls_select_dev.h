@@ -25,6 +25,8 @@
 #pragma once
 #include "ls_common.h"
 
+#include <type_traits>
+
 #define LS_RES_CAP 2048  // == LS_MAX_K
 
 // ---- a wave's running best-keys list (used by the scan and the BM25 candidate kernels) -----------
@@ -235,6 +237,23 @@ __device__ __forceinline__ u32 wave_min(u32 v) {
     return v;
 }
 
+// OR over the 64 lanes, in every lane, without the LDS crossbar: DPP inside 16-lane rows, then gfx950's
+// v_permlane16_swap / v_permlane32_swap across rows (whole wave active).
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_or(u32 v) {
+    return v | (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ u32 wave_or_dpp(u32 v) {
+    v = dpp_or<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_or<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_or<0x141>(v);  // row_half_mirror
+    v = dpp_or<0x140>(v);  // row_mirror
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = (u32)r[0] | (u32)r[1];
+    r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (u32)r[0] | (u32)r[1];
+}
+
 // The wave's histogram (256 bins, lane t holds bins 4t..4t+3 in LDS) -> the bin that holds the
 // krem-th largest counted element; krem becomes the rank inside that bin, *nbin its population.
 __device__ __forceinline__ u32 wave_find_bin(const u32* hist, u32& krem, u32* nbin, int lane) {
@@ -284,6 +303,12 @@ __device__ unsigned long long g_fin_stamp[8];
 #define LS_STAMP(i) do { if (tid == 0) g_fin_stamp[i] = wall_clock64(); } while (0)
 #else
 #define LS_STAMP(i) do {} while (0)
+#endif
+#ifdef LS_HANDOFF_TIMING  // developer instrumentation: timeline of a same-launch selection (tools/handoff_timeline.py)
+static __device__ unsigned long long g_ho[2];  // [0] ~(earliest scan workgroup start), [1] latest scan workgroup end
+#define LS_HO(i) do { if (tid == 0) ho[i] = wall_clock64(); } while (0)
+#else
+#define LS_HO(i) do {} while (0)
 #endif
 // splitter buckets (lds_topk): the sorted sample's every (LS_SS_SAMPLE/64)-th key is a splitter; bucket of a
 // key = number of splitters (j = 0..62, descending) above it
@@ -802,12 +827,14 @@ __host__ __device__ __forceinline__ size_t ls_fin_lds_bytes(int keys_cap, int ke
 }
 
 // One workgroup of NT threads produces the final (scores, rows)[k] of one query.
-// `arrived` = false: a same-launch job whose wait for the scan workgroups timed out.
 // (forced inline: as a call, `p` - an element of the kernel's by-value job array - would be copied to
 // scratch memory to have an address: 984 bytes per lane)
+// (Round 4 also tried a REHEARSAL for same-launch jobs - the whole fast path run once on the previous
+// call's granules while the scan runs, side effects off, then the same instructions again on the real
+// keys - on the theory that the job's code is cold: 61.6 vs 61.7 us per call, i.e. nothing. What the
+// timeline (tools/handoff_timeline.py) did show was branches: see the pivot search below.)
 template <int NT>
-static __device__ __forceinline__ void finalize_body(const ls_fin_params& p, unsigned char* smem, int tid,
-                                     bool arrived = true) {
+static __device__ __forceinline__ void finalize_body(const ls_fin_params& p, unsigned char* smem, int tid) {
     const int keff = (long long)p.k < p.n ? p.k : (int)p.n;
     u64* keys = reinterpret_cast<u64*>(smem);
     u64* res = keys + p.keys_cap;
@@ -817,139 +844,228 @@ static __device__ __forceinline__ void finalize_body(const ls_fin_params& p, uns
     u32* misc = hist + 8 * 256;
 
     LS_STAMP(0);
+#ifdef LS_HANDOFF_TIMING
+    unsigned long long ho[8] = {};
+#endif
+    LS_HO(0);
     const int mc = p.blocks * p.kprime;
     int nvalid = 0;
     bool done = (p.n <= 0);
     u64 T = 0;  // k-th best emitted key: a lower bound of the true k-th best key
 
-    if (!done && arrived && !p.force_slow && mc >= keff && mc <= p.keys_cap) {
-        // Same-launch jobs: the producers wrote these words through (sc1) and drained them before
-        // arriving; sc1 loads (L1 bypassed) stand in for the agent-scope acquire.
-        auto ld = [&](const u64* a) -> u64 {
-            return p.arrive ? __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *a;
-        };
+    if (!done && !p.force_slow && mc >= keff && mc <= p.keys_cap) {
         // ---- pivot: a lower bound of the k-th best key from ONE entry per workgroup ---------------------
         // Every scan workgroup emitted its keys best first. Take the m-th key of each (m = keys a
         // workgroup must contribute on average, ceil(k / blocks): 1 for k = 50 over 448 workgroups) and
         // let P be the r-th largest of these pivots, r = ceil(k / m): at least r workgroups then hold m
         // keys >= P, i.e. >= k keys >= P, so the k-th best key is >= P and everything below P can be
         // dropped before any selection work: ~60 of the 2240 candidates survive for config 2, a third
-        // for k = 1000. One wave finds P in registers (bit-wise search on the score half, counting by
-        // ballots); the other waves' candidate loads are in flight meanwhile.
+        // for k = 1000. The same holds for ANY subset of the workgroups, so every wave searches its own
+        // slice of them (blocks / waves pivots, 1-4 per lane, in registers: bit-wise search on the score
+        // half, counting by ballots) for the ceil(r / waves)-th largest, and P is the smallest of the
+        // waves' answers: waves * ceil(r / waves) >= r pivots are >= P. (One wave over all 448 pivots: 56
+        // dependent ballot-count-add chains, 1.7 us; a slice per wave: 16.)
         const int m_need = (keff + p.blocks - 1) / p.blocks;
         const bool prefilter = p.blocks >= 64 && p.blocks <= 1024 && m_need <= p.kprime;
-        // (loads return in order: the pivots go out first, so the wave that needs them does not wait
-        // for its share of the candidates as well)
-        u32 pv[16];
+        if (tid == 0) misc[7 * 8 + 4] = 0u;  // survivor count (a barrier follows before it is used)
+        constexpr int NW = NT / 64;
+        constexpr int PW = 1024 / NT < 1 ? 1 : 1024 / NT;  // pivots per lane at most (blocks <= 1024)
+        const int wv = tid >> 6, ln = tid & 63;
+        const int Q = (p.blocks + NW - 1) / NW;             // pivots of one wave's slice
+        u32 pv[PW];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int b = tid + 64 * j;
-            pv[j] = (prefilter && tid < 64 && b < p.blocks)
-                        ? (u32)(ld(&p.cand[(long long)b * p.kprime + (m_need - 1)]) >> 32) : 0u;
-        }
+        for (int j = 0; j < PW; ++j) pv[j] = 0u;
         u64 mb = 0;  // max over workgroups of the best key each one withheld
-        for (int i = tid; i < p.blocks; i += NT) {
-            const u64 b = ld(&p.bound[i]);
-            mb = b > mb ? b : mb;
-        }
         // candidate keys: CH per thread and round in registers (config 2: one round of 9 on 256
-        // threads), the first round's loads in flight while the pivot is being found
+        // threads)
         constexpr int CH = LS_FINAL_CAP / NT < 16 ? LS_FINAL_CAP / NT : 16;
         u64 mine[CH];
+        if (p.gran) {
+            // ---- tagged granules (same-launch jobs and their retries, ls_fin_params::gran) ----------
+            // Thread t owns granules t, t + NT, ...: it re-reads the ones that do not carry the tag yet
+            // (sc1 loads: L1 bypassed, nothing to invalidate) and the workgroup votes after every sweep.
+            // Before the first sweep ONE lane sleeps on one granule, so that a selection workgroup
+            // does not poll 40 KB per microsecond next to scan workgroups for the whole scan.
+            constexpr int CG = LS_GRAN_MAX / NT;
+            static_assert(CG <= CH, "granule slots must fit the candidate registers");
+            const int G = p.blocks * (p.kprime + 1);
+            __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.gran), 0, G * 16, LS_BUF_RSRC_FLAGS);
+            unsigned long long t0 = 0;
+            if (p.wait) {
+                t0 = wall_clock64();
+                if (tid == 0) {
+                    while (__builtin_amdgcn_raw_buffer_load_b128(rsrc, (G - p.blocks) * 16, 0, LS_AUX_SC1)[2] != p.tag) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (wall_clock64() - t0 > LS_ARRIVE_TIMEOUT_TICKS) break;
+                    }
+                }
+                __syncthreads();
+            }
+            LS_HO(1);
+            u32x4 gv[CG];
+            u32 need = 0;
+            bool complete = true;
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int i = tid + j * NT;
-            mine[j] = i < mc ? ld(&p.cand[i]) : 0ull;
+            for (int j = 0; j < CG; ++j) {
+                gv[j] = u32x4{0u, 0u, 0u, 0u};
+                if (tid + j * NT < G) need |= 1u << j;
+            }
+            for (unsigned it = 1;; ++it) {
+#pragma unroll
+                for (int j = 0; j < CG; ++j)
+                    if (need & (1u << j))
+                        gv[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + j * NT) * 16, 0, LS_AUX_SC1);
+#pragma unroll
+                for (int j = 0; j < CG; ++j)
+                    if (gv[j].z == p.tag) need &= ~(1u << j);
+                if (__syncthreads_and(need == 0u)) break;
+                // (the vote makes the exit uniform; the clock is read on the same sweeps by everyone)
+                if (!p.wait || ((it & 63u) == 0u &&
+                                __syncthreads_or(wall_clock64() - t0 > LS_ARRIVE_TIMEOUT_TICKS))) {
+                    complete = false;  // timed out (or, behind a kernel boundary, a granule is missing)
+                    break;
+                }
+            }
+            LS_HO(2);
+            // planes 0 .. kprime-1 are candidates, plane kprime the bounds; the pivot plane also goes
+            // to LDS for the wave that searches the pivot (hist is free until lds_topk)
+            const int nc = p.blocks * p.kprime;
+            const int pv0 = (m_need - 1) * p.blocks;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) mine[j] = 0ull;
+#pragma unroll
+            for (int j = 0; j < CG; ++j) {
+                const int i = tid + j * NT;
+                const u64 key = complete ? (((u64)gv[j].y << 32) | gv[j].x) : 0ull;
+                if (i < nc) mine[j] = key;
+                else if (i < G) mb = key > mb ? key : mb;
+                // (unconditional store, slot 2047 is nobody's: a guarded one is a branch per granule)
+                hist[(prefilter && i >= pv0 && i < pv0 + p.blocks) ? i - pv0 : 2047] = (u32)(key >> 32);
+            }
+            if (!complete) mb = ~0ull;  // no keys, an unbeatable bound: the proof below fails
+            __syncthreads();
+            LS_HO(6);
+            if (prefilter) {  // (clamped, unconditional reads: slot 2047 holds junk, masked)
+#pragma unroll
+                for (int j = 0; j < PW; ++j) {
+                    const int o = ln + 64 * j, b = wv * Q + o;
+                    const bool in = o < Q && b < p.blocks;
+                    const u32 v = hist[in ? b : 2047];
+                    pv[j] = in ? v : 0u;
+                }
+            }
+        } else {
+            // (loads return in order: the pivots go out first, so the wave that needs them does not
+            // wait for its share of the candidates as well)
+            if (prefilter) {
+#pragma unroll
+                for (int j = 0; j < PW; ++j) {
+                    const int o = ln + 64 * j, b = wv * Q + o;
+                    const bool in = o < Q && b < p.blocks;
+                    const u32 v = (u32)(p.cand[(long long)(in ? b : 0) * p.kprime + (m_need - 1)] >> 32);
+                    pv[j] = in ? v : 0u;
+                }
+            }
+            for (int i = tid; i < p.blocks; i += NT) {
+                const u64 b = p.bound[i];
+                mb = b > mb ? b : mb;
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int i = tid + j * NT;
+                mine[j] = i < mc ? p.cand[i] : 0ull;
+            }
         }
-        if (tid < 64) {
+        u32* const pw = reinterpret_cast<u32*>(red);  // one answer per wave (red[] = 16 free u64)
+        {
+            // No LDS shuffles on the critical path (a ds_bpermute round trip is ~120 cycles and a wave is
+            // alone on its SIMD here: the max / min / sum butterflies and the bound reduction of the first
+            // version were 3 of the 5.8 us between "every key is here" and "survivors in LDS").
             u32 t0 = 0;
             if (prefilter) {
                 const u32 r = (u32)((keff + m_need - 1) / m_need);
-                u32 vmax = 0, vmin = 0xffffffffu, nnz = 0;
+                const u32 rw = (r + NW - 1) / NW;  // this wave's share
+                // Straight-line on purpose: pv[j] is 0 beyond the slice and 0 counts nowhere, so no step
+                // is guarded by "j < slots in use" - the guarded version compiled to two scalar branches
+                // per ballot and spent 3.2 us here (tools/handoff_timeline.py).
+                // ref: any real pivot; diff: every bit in which some real pivot differs from it
+                const u64 has = __ballot(pv[0] != 0u);
+                const u32 ref = has ? (u32)__builtin_amdgcn_readlane((int)pv[0], __ffsll((long long)has) - 1) : 0u;
+                auto search = [&](auto width) -> u32 {
+                    constexpr int W = decltype(width)::value;
+                    u32 diff = 0, nnz = 0;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    vmax = pv[j] > vmax ? pv[j] : vmax;
-                    if (pv[j]) {
-                        vmin = pv[j] < vmin ? pv[j] : vmin;
-                        ++nnz;
+                    for (int j = 0; j < W; ++j) {
+                        diff |= pv[j] ? (pv[j] ^ ref) : 0u;
+                        nnz += (u32)__popcll(__ballot(pv[j] != 0u));
                     }
-                }
-                vmax = wave_max(vmax);
-                vmin = wave_min(vmin);
-                nnz = wave_sum(nnz);
+                    diff = wave_or_dpp(diff);
+                    if (!has || nnz < rw) return 0u;
+                    if (!diff) return ref;
+                    // ANY value with >= rw pivots at or above it will do: the 8 bits below the highest
+                    // differing one are resolved (a slightly lower pivot lets a few more keys through)
+                    const int hb = 31 - __clz((int)diff);
+                    u32 t = hb == 31 ? 0u : (ref >> (hb + 1) << (hb + 1));  // the bits all pivots share
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        const int bit = hb - s8;
+                        const u32 cand = t | (bit >= 0 ? 1u << bit : 0u);  // (below bit 0: cand = t, which passes)
+                        u32 c = 0;
+#pragma unroll
+                        for (int j = 0; j < W; ++j) c += (u32)__popcll(__ballot(pv[j] >= cand));
+                        t = c >= rw ? cand : t;
+                    }
+                    return t;
+                };
+                if constexpr (PW >= 4)
+                    t0 = Q <= 128 ? search(std::integral_constant<int, 2>{}) : search(std::integral_constant<int, PW>{});
+                else
+                    t0 = search(std::integral_constant<int, PW>{});
                 LS_STAMP(7);  // (developer stamp: the pivot loads have landed)
-                if (nnz >= r) {
-                    const u32 diff = vmax ^ vmin;
-                    t0 = vmax;
-                    if (diff) {
-                        // ANY value with >= r pivots at or above it will do: the 8 bits below the highest
-                        // differing one are resolved (a slightly lower pivot lets a few more keys through)
-                        const int hb = 31 - __clz((int)diff);
-                        const int lowest = hb >= 7 ? hb - 7 : 0;
-                        const int npl = (p.blocks + 63) >> 6;
-                        t0 = hb == 31 ? 0u : (vmax >> (hb + 1) << (hb + 1));  // the bits all pivots share
-#pragma unroll 1
-                        for (int bit = hb; bit >= lowest; --bit) {
-                            const u32 cand = t0 | (1u << bit);
-                            u32 c = 0;
-#pragma unroll
-                            for (int j = 0; j < 16; ++j)
-                                if (j < npl) c += (u32)__popcll(__ballot(pv[j] >= cand));
-                            if (c >= r) t0 = cand;
-                        }
-                    }
-                }
             }
-            if (tid == 0) misc[7 * 8 + 5] = t0;
+            if (ln == 0) pw[wv] = t0;
         }
+        LS_HO(7);
         LS_STAMP(1);
-        for (int o = 32; o >= 1; o >>= 1) {
-            const u64 other = __shfl_xor(mb, o, 64);
-            mb = other > mb ? other : mb;
-        }
-        if ((tid & 63) == 0) red[tid >> 6] = mb;
-        if (tid == 0) misc[7 * 8 + 4] = 0u;  // survivor count
-        __syncthreads();
-        mb = 0;
-        for (int w = 0; w < NT / 64; ++w) mb = red[w] > mb ? red[w] : mb;
-        const u32 T0 = misc[7 * 8 + 5];
-        for (int c0 = 0;; c0 += CH * NT) {  // survivors -> LDS: ONE atomic per wave and round of CH keys
+        __syncthreads();  // the pivot and the zeroed survivor counter
+        u32 T0 = pw[0];  // the smallest of the waves' answers (0 = no pre-filter)
+#pragma unroll
+        for (int w = 1; w < NW; ++w) T0 = pw[w] < T0 ? pw[w] : T0;
+        for (int c0 = 0;; c0 += CH * NT) {  // survivors -> LDS: one LDS atomic per thread that keeps any
             u32 nkeep = 0;
 #pragma unroll
             for (int j = 0; j < CH; ++j) nkeep += mine[j] != 0ull && (u32)(mine[j] >> 32) >= T0;
-            u32 inc = nkeep;  // inclusive prefix over the wave's lanes
-            for (int o = 1; o < 64; o <<= 1) {
-                const u32 t = (u32)__shfl_up((int)inc, o, 64);
-                if ((tid & 63) >= o) inc += t;
-            }
-            const u32 wave_total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
-            u32 base = 0;
-            if (wave_total) {
-                if ((tid & 63) == 0) base = atomicAdd(&misc[7 * 8 + 4], wave_total);
-                base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-            }
-            u32 at = base + inc - nkeep;
+            if (nkeep) {
+                u32 at = atomicAdd(&misc[7 * 8 + 4], nkeep);
 #pragma unroll
-            for (int j = 0; j < CH; ++j)
-                if (mine[j] != 0ull && (u32)(mine[j] >> 32) >= T0) keys[at++] = mine[j];
+                for (int j = 0; j < CH; ++j) {  // (a dropped key goes to tmp[0], a slot nobody reads: no branch per key)
+                    const bool keep = mine[j] != 0ull && (u32)(mine[j] >> 32) >= T0;
+                    u64* dst = keep ? &keys[at] : &tmp[0];
+                    *dst = mine[j];
+                    at += keep;
+                }
+            }
             if (c0 + CH * NT >= mc) break;
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const int i = c0 + CH * NT + tid + j * NT;
-                mine[j] = i < mc ? ld(&p.cand[i]) : 0ull;
+                mine[j] = i < mc ? p.cand[i] : 0ull;  // (granule jobs fit one round)
             }
         }
         __syncthreads();
-        const int nsurv = (int)misc[7 * 8 + 4];
-        __syncthreads();  // (lds_topk reuses misc)
+        const int nsurv = (int)misc[7 * 8 + 4];  // (lds_topk leaves misc[60..61] alone)
         LS_STAMP(2);
+        LS_HO(3);
         nvalid = lds_topk(keys, nsurv, keff, res, tmp, hist, misc, tid, NT);
+        LS_HO(4);
         T = (nvalid == keff && keff > 0) ? res[keff - 1] : 0ull;
-        done = (mb == 0ull) || (T != 0ull && mb < T);
-        __syncthreads();
+        // proof: every withheld key is below the k-th best emitted one. mb = the largest bound THIS
+        // thread saw; the vote replaces a reduction of the bounds
+        done = __syncthreads_and(mb == 0ull || (T != 0ull && mb < T)) != 0;
     }
-    if (!done && p.arrive) {
-        // same-launch job: S is not part of the hand-off (see ls_fin_params::arrive). Ask the host
+    if (!done && p.wait) {
+        // same-launch job: S is not part of the hand-off (see ls_fin_params::gran). Ask the host
         // for the stand-alone finalize behind this launch instead of reading S here.
         if (tid == 0) {  // (the stand-alone finalize counts the slow path in counters[0])
             if (p.done)
@@ -1009,6 +1125,17 @@ static __device__ __forceinline__ void finalize_body(const ls_fin_params& p, uns
         }
     }
     LS_STAMP(6);
+    LS_HO(5);
+#ifdef LS_HANDOFF_TIMING
+    if (tid == 0 && p.counters && p.wait) {  // ticks after this workgroup's entry, + 10000
+        p.counters[1] = (u32)(~__hip_atomic_load(&g_ho[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ho[0] + 10000);
+        p.counters[2] = (u32)(__hip_atomic_load(&g_ho[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ho[0] + 10000);
+        const int which[5] = {2, 6, 7, 3, 5};  // swept | pivot plane in registers | pivot found | survivors in LDS | done
+        for (int i = 0; i < 5; ++i) p.counters[3 + i] = (u32)(ho[which[i]] - ho[0] + 10000);
+        __hip_atomic_store(&g_ho[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&g_ho[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
 #ifdef LS_FIN_TIMING
     if (tid == 0 && p.counters)
         for (int i = 0; i < 6; ++i) p.counters[2 + i] = (u32)(g_fin_stamp[i + 1] - g_fin_stamp[i]);

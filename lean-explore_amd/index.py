@@ -271,9 +271,8 @@ class FlatIPIndex:
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
         flags = native.LS_FLAG_NORMALIZE if normalize else 0
-        native.check(native.load().ls_search(h, x.ctypes.data if nq else None, nq, k, flags,
-                                             D.ctypes.data if nq else None,
-                                             I.ctypes.data if nq else None))
+        native.check(native.load().ls_search(h, native.addr(x), nq, k, flags, native.addr(D),
+                                             native.addr(I)))
         return D, I
 
     def search_device(self, q, k: int, out_scores=None, out_indices=None, *,

@@ -125,6 +125,23 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+_c_char_from_buffer = ctypes.c_char.from_buffer
+_addressof = ctypes.addressof
+
+
+def addr(a) -> int | None:
+    """Base address of a C-contiguous numpy array for a pointer argument (None if it is empty).
+    ``ndarray.ctypes.data`` builds a helper object per access (1.4 us; three of them were most of
+    the interpreter's share of a 64 us ``ls_search``); the buffer protocol gives the same address
+    in 0.4 us. Read-only arrays do not export a writable buffer and take the slow way."""
+    if not a.size:
+        return None
+    try:
+        return _addressof(_c_char_from_buffer(a))
+    except (TypeError, ValueError):
+        return a.ctypes.data
+
+
 def check(rc: int) -> None:
     if rc == LS_OK:
         return

@@ -44,8 +44,9 @@ int main(int argc, char** argv) {
         for (int i = 0; i < d; ++i) q[i] = gauss(&s);
         ls_index* ix = NULL;
         if (create(&ix, corpus, n, d, 0, 0)) { printf("ls_create: %s\n", lasterr()); return 1; }
-        for (int mode = 1; mode >= 0; --mode) {
-            option(ix, 9, mode);
+        for (int mode = 2; mode >= 0; --mode) {  /* 2: defaults, 1: query by copy command, 0: selection as its own launch */
+            option(ix, 15, mode == 1);       /* (libraries older than option 15 answer "unknown option": ignored) */
+            option(ix, 9, mode >= 1);
             double lat[300];
             for (int i = 0; i < 30; ++i) search(ix, q, 1, k, 1u, D, I);
             for (int i = 0; i < calls; ++i) {
@@ -56,7 +57,8 @@ int main(int argc, char** argv) {
             qsort(lat, calls, sizeof(double), cmp);
             printf("C harness N=%lld d=%d k=%d nq=1 ls_search(host arrays, normalize): selection %s: p50 %.1f us, p10 %.1f, p90 %.1f "
                    "(same-launch retries so far %lld; top row %lld)\n", (long long)n, d, k,
-                   mode ? "inside the scan launch" : "as its own launch", lat[calls / 2], lat[calls / 10], lat[9 * calls / 10],
+                   mode == 2 ? "inside the scan launch, query read from pinned host memory (defaults)"
+                             : (mode ? "inside the scan launch, query by copy command" : "as its own launch, query read from pinned host memory"), lat[calls / 2], lat[calls / 10], lat[9 * calls / 10],
                    (long long)counter(ix, 20), (long long)I[0]);
         }
         destroy(ix);

@@ -235,6 +235,7 @@ void ls_destroy(ls_index* ix) {
     if (ix->h_overflow) (void)hipHostFree(ix->h_overflow);
     if (ix->h_q) (void)hipHostFree(ix->h_q);
     if (ix->h_done) (void)hipHostFree(ix->h_done);
+    if (ix->h_out_g) (void)hipHostFree(ix->h_out_g);
     if (ix->h_out_s) (void)hipHostFree(ix->h_out_s);
     if (ix->h_out_i) (void)hipHostFree(ix->h_out_i);
     for (hipEvent_t e : ix->prof_ev) (void)hipEventDestroy(e);
@@ -472,6 +473,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             p.out_indices = (long long*)(d_out_i + (q0 + i) * k);
             p.counters = ix->d_counters;
             p.done = ix->done_base ? ix->done_base + (q0 + i) : nullptr;
+            p.out_gran = ix->gran_out_base && k <= LS_OUT_GRAN_MAX_K ? ix->gran_out_base + (size_t)(q0 + i) * k : nullptr;
             p.done_val = ix->done_seq;
             p.gran = same_launch ? (const char*)st.d_gran + (size_t)i * LS_GRAN_MAX * 16 : nullptr;
             p.tag = same_launch ? ix->gran_tag : 0u;
@@ -1071,33 +1073,63 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
         LS_HIP(hipMemcpyAsync(ix->d_qraw, ix->h_q, qn * sizeof(float), hipMemcpyHostToDevice, s));
     ix->retry_jobs.clear();
     if (spin) {
+        if (on > ix->h_out_g_cap) {
+            if (ix->h_out_g) (void)hipHostFree(ix->h_out_g);
+            ix->h_out_g = nullptr;
+            ix->h_out_g_cap = 0;
+            const size_t cap = std::max<size_t>(on, 4096);
+            LS_HIP(hipHostMalloc((void**)&ix->h_out_g, cap * sizeof(ls_out_gran), hipHostMallocDefault));
+            memset(ix->h_out_g, 0, cap * sizeof(ls_out_gran));
+            ix->h_out_g_cap = cap;
+        }
         if (++ix->done_seq >= LS_DONE_RETRY) ix->done_seq = 1;  // the top bit is the retry answer
         ix->done_base = ix->h_done;
+        ix->gran_out_base = ix->h_out_g;
     }
     rc = ls_i_search_on_stream(ix, in_direct ? ix->h_q : ix->d_qraw, nq, k, flags & LS_FLAG_NORMALIZE,
                           out_direct ? ix->h_out_s : ix->d_out_s,
                           out_direct ? ix->h_out_i : ix->d_out_i, s, true);
     ix->done_base = nullptr;
+    ix->gran_out_base = nullptr;
     if (rc != LS_OK) return rc;
     if (!out_direct) {
         LS_HIP(hipMemcpyAsync(ix->h_out_s, ix->d_out_s, on * sizeof(float), hipMemcpyDeviceToHost, s));
         LS_HIP(hipMemcpyAsync(ix->h_out_i, ix->d_out_i, on * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     }
-    // spin until every completion word is final (the call's sequence number, or - if accepted -
-    // the retry answer); gives up after 2 ms and lets the caller sleep in hipStreamSynchronize
+    // spin until every query is final: all k of its result granules carry the call's sequence number
+    // in both halves (ls_fin_params::out_gran), or - if accepted - its completion word holds the retry
+    // answer; gives up after 2 ms and lets the caller sleep in hipStreamSynchronize
     auto wait_words = [&](bool accept_retry, bool* retry) -> bool {
         const auto t0 = std::chrono::steady_clock::now();
+        const u32 seq = ix->done_seq;
+        int64_t i = 0;   // queries below i are final (granules never change back)
+        int32_t j = 0;   // granules below j of query i carry the tag
+        bool any_retry = false;
+        const bool granules = k <= LS_OUT_GRAN_MAX_K;
         for (unsigned it = 0;; ++it) {
-            bool any_retry = false;
-            int64_t i = 0;
-            for (; i < nq; ++i) {
+            for (; i < nq; ++i, j = 0) {
                 const u32 w = __atomic_load_n(&ix->h_done[i], __ATOMIC_ACQUIRE);
-                if (w == ix->done_seq) continue;
-                if (accept_retry && w == (ix->done_seq | LS_DONE_RETRY)) {
+                if (accept_retry && w == (seq | LS_DONE_RETRY)) {
                     any_retry = true;
                     continue;
                 }
-                break;
+                if (!granules) {  // drained rows + completion word
+                    if (w == seq) continue;
+                    break;
+                }
+                // (decoded as they are recognised: at k = 1000 a second pass over 16 KB of granules would
+                // cost the host more than the drain + completion word it replaces cost the GPU)
+                const ls_out_gran* g = ix->h_out_g + (size_t)i * k;
+                float* os = out_scores + (size_t)i * k;
+                int64_t* oi = out_indices + (size_t)i * k;
+                for (; j < k; ++j) {
+                    if (__atomic_load_n(&g[j].tag_lo, __ATOMIC_ACQUIRE) != seq ||
+                        __atomic_load_n(&g[j].tag_hi, __ATOMIC_ACQUIRE) != seq)
+                        break;
+                    os[j] = g[j].score;
+                    oi[j] = g[j].row == 0xffffffffu ? (int64_t)-1 : ix->base + (int64_t)g[j].row;
+                }
+                if (j < k) break;
             }
             if (i == nq) {
                 if (retry) *retry = any_retry;
@@ -1145,6 +1177,16 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
     }
     ix->retry_jobs.clear();
     if (!done) LS_HIP(hipStreamSynchronize(s));
+    if (spin && k <= LS_OUT_GRAN_MAX_K) {
+        if (done) return LS_OK;  // (unpacked while waiting)
+        std::atomic_thread_fence(std::memory_order_acquire);  // behind the drained stream
+        for (size_t e = 0; e < on; ++e) {
+            const ls_out_gran& g = ix->h_out_g[e];
+            out_scores[e] = g.score;
+            out_indices[e] = g.row == 0xffffffffu ? (int64_t)-1 : ix->base + (int64_t)g.row;
+        }
+        return LS_OK;
+    }
     memcpy(out_scores, ix->h_out_s, on * sizeof(float));
     memcpy(out_indices, ix->h_out_i, on * sizeof(int64_t));
     return LS_OK;

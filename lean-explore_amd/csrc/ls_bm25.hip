@@ -20,7 +20,10 @@
 // - a latency-bound problem at this size, which is why the launch count is what matters.
 #include "ls_select_dev.h"
 
+#include <immintrin.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -35,8 +38,8 @@ struct ls_bm25 {
     uint2* d_entries = nullptr;  // (token id, float bits)
     float* d_F = nullptr;   // scores of the last search (partial sums between the launches of a
                             // > LS_BM25_QTOK-token query; the finalize step's rescue path reads it)
-    float* h_out_s = nullptr;    // pinned, device-visible: the finalize step writes results here
-    int64_t* h_out_i = nullptr;
+    ls_out_gran* h_out_g = nullptr;  // pinned, device-visible: the finalize step writes its result granules here
+    u32 out_seq = 0;                 // (ls_fin_params::out_gran) and the host polls their tags
     u64* d_cand = nullptr;
     u64* d_bound = nullptr;
     u32* d_counters = nullptr;
@@ -168,8 +171,7 @@ void ls_bm25_destroy(ls_bm25* ix) {
     (void)hipFree(ix->d_doc_ptr);
     (void)hipFree(ix->d_entries);
     (void)hipFree(ix->d_F);
-    if (ix->h_out_s) (void)hipHostFree(ix->h_out_s);
-    if (ix->h_out_i) (void)hipHostFree(ix->h_out_i);
+    if (ix->h_out_g) (void)hipHostFree(ix->h_out_g);
     (void)hipFree(ix->d_cand);
     (void)hipFree(ix->d_bound);
     (void)hipFree(ix->d_counters);
@@ -254,10 +256,9 @@ int ls_bm25_create(ls_bm25** out, const int64_t* indptr, const int32_t* indices,
     if (hipMalloc((void**)&ix->d_doc_ptr, (nd + 1) * 4) != hipSuccess) return fail("hipMalloc");
     if (hipMalloc((void**)&ix->d_entries, nz * 8) != hipSuccess) return fail("hipMalloc");
     if (hipMalloc((void**)&ix->d_F, nd * 4) != hipSuccess) return fail("hipMalloc");
-    if (hipHostMalloc((void**)&ix->h_out_s, LS_MAX_K * 4, hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc((void**)&ix->h_out_g, LS_MAX_K * sizeof(ls_out_gran), hipHostMallocDefault) != hipSuccess)
         return fail("hipHostMalloc");
-    if (hipHostMalloc((void**)&ix->h_out_i, LS_MAX_K * 8, hipHostMallocDefault) != hipSuccess)
-        return fail("hipHostMalloc");
+    memset(ix->h_out_g, 0, LS_MAX_K * sizeof(ls_out_gran));
     if (hipMalloc((void**)&ix->d_cand, (size_t)ix->blocks * LS_KP_MAX * 8) != hipSuccess) return fail("hipMalloc");
     if (hipMalloc((void**)&ix->d_bound, (size_t)ix->blocks * 8) != hipSuccess) return fail("hipMalloc");
     if (hipMalloc((void**)&ix->d_counters, 32) != hipSuccess) return fail("hipMalloc");
@@ -358,8 +359,14 @@ int ls_bm25_search(ls_bm25* ix, const int32_t* token_ids, int32_t n_tokens, int3
         p.keys_cap = LS_FINAL_CAP;
         p.force_slow = 0;
         p.base = 0;
-        p.out_scores = ix->h_out_s;  // pinned host memory, written by the kernel over PCIe
-        p.out_indices = (long long*)ix->h_out_i;
+        // results: tagged granules in pinned host memory, written by the kernel over PCIe; the host
+        // polls the tags instead of sleeping in hipStreamSynchronize (its wake-up alone costs more than
+        // the selection kernel) and falls back to the stream sync after 2 ms
+        // (the name indices are always asked for their top 1000: the granule form's host cost at that k
+        // is paid here too, but it replaces hipStreamSynchronize, not a completion word)
+        if (++ix->out_seq >= LS_DONE_RETRY) ix->out_seq = 1;
+        p.out_gran = ix->h_out_g;
+        p.done_val = ix->out_seq;
         p.counters = ix->d_counters;
         if (k > LS_MAX_K) {  // only possible when k > n_docs: select LS_MAX_K >= n_docs, pad on host
             p.k = LS_MAX_K;
@@ -367,9 +374,28 @@ int ls_bm25_search(ls_bm25* ix, const int32_t* token_ids, int32_t n_tokens, int3
         int rc = ls_launch_finalize(jobs, 1, s);
         if (rc != LS_OK) return rc;
         const int kk = std::min(k, LS_MAX_K);
-        LS_HIP(hipStreamSynchronize(s));
-        memcpy(out_scores, ix->h_out_s, (size_t)kk * 4);
-        memcpy(out_docs, ix->h_out_i, (size_t)kk * 8);
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            const u32 seq = ix->out_seq;
+            int j = 0;
+            for (unsigned it = 0; j < kk; ++it) {
+                for (; j < kk; ++j)
+                    if (__atomic_load_n(&ix->h_out_g[j].tag_lo, __ATOMIC_ACQUIRE) != seq ||
+                        __atomic_load_n(&ix->h_out_g[j].tag_hi, __ATOMIC_ACQUIRE) != seq)
+                        break;
+                if (j == kk) break;
+                _mm_pause();
+                if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                    LS_HIP(hipStreamSynchronize(s));
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    break;
+                }
+            }
+        }
+        for (int i = 0; i < kk; ++i) {
+            out_scores[i] = ix->h_out_g[i].score;
+            out_docs[i] = ix->h_out_g[i].row == 0xffffffffu ? (int64_t)-1 : (int64_t)ix->h_out_g[i].row;
+        }
         for (int i = kk; i < k; ++i) {
             out_scores[i] = -FLT_MAX;
             out_docs[i] = -1;

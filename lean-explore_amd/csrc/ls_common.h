@@ -187,8 +187,18 @@ struct ls_fin_params {
     float* out_scores;     // [k]
     long long* out_indices;  // [k]
     u32* counters;         // [0] left the fast path, [1] took the general path
-    u32* done;             // optional: pinned host word that receives done_val once the outputs
-    u32 done_val;          //           are visible to the host (the host API spins on it)
+    // Host API (synchronous calls that spin instead of sleeping in hipStreamSynchronize), k <= 256:
+    // the results go to pinned host memory as k self-validating 16-byte granules {score bits, tag,
+    // local row (~0 = none), tag}, one system-scope store each - the host polls the tags (both halves
+    // carry one, so the pair is valid however the write is split on its way) and adds the base.
+    // Nothing is drained and no completion word follows: the host sees a result one PCIe write after
+    // it was stored instead of after write + acknowledge + flag write (-1.5 us per call at k = 50).
+    // Larger k keeps the drained rows + completion word: a thousand granules cost the host more to
+    // recognise and unpack (+3.5 us at k = 1000) than the drain costs the GPU.
+    void* out_gran;        // optional: pinned host memory, k granules (out_scores / out_indices unused)
+    u32* done;             // optional: pinned host word; receives done_val once out_scores / out_indices are
+    u32 done_val;          //           visible to the host (out_gran null), or done_val | LS_DONE_RETRY when
+                           //           a same-launch job must be re-run by the host; the granules' tag
     // Same-launch selection (synchronous host API only): the job rides on the scan launch of ITS
     // OWN query. The hand-off is the data itself: every scan workgroup writes its k' keys and its
     // bound as 16-byte granules {key, tag, 0} with ONE write-through (sc1) store each - no drain, no
@@ -204,6 +214,11 @@ struct ls_fin_params {
     u32 tag;               // this launch's tag (never 0)
     u32 wait;              // 1: the granules are being written by this very launch: sweep for the tag
 };
+struct ls_out_gran {   // host view of one result granule
+    float score;
+    u32 tag_lo, row, tag_hi;
+};
+#define LS_OUT_GRAN_MAX_K 256
 #define LS_DONE_RETRY 0x80000000u        // completion word: "run the stand-alone finalize for this query"
 #define LS_ARRIVE_TIMEOUT_TICKS 20000000ull  // 200 ms of the 100 MHz clock: give up waiting, ask for a retry
 #define LS_GRAN_MAX 4096                 // granules per query: blocks * (kprime + 1) above this -> own launch

@@ -166,6 +166,8 @@ struct ls_index {
     u32* h_done = nullptr;     // pinned [LS_SCAN_PATH_MAX_NQ]: completion words of the host API
     u32 done_seq = 0;
     u32* done_base = nullptr;  // set by ls_search around its scan-path call, else null
+    ls_out_gran* h_out_g = nullptr;  size_t h_out_g_cap = 0;  // pinned: result granules of a spinning host call
+    ls_out_gran* gran_out_base = nullptr;                      // set together with done_base
     float* h_q = nullptr;      size_t h_q_cap = 0;    // pinned
     float* h_out_s = nullptr;  int64_t* h_out_i = nullptr;  size_t h_out_cap = 0;
 

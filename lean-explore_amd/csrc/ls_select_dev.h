@@ -868,8 +868,10 @@ static __device__ __forceinline__ void finalize_body(const ls_fin_params& p, uns
         const int m_need = (keff + p.blocks - 1) / p.blocks;
         const bool prefilter = p.blocks >= 64 && p.blocks <= 1024 && m_need <= p.kprime;
         if (tid == 0) misc[7 * 8 + 4] = 0u;  // survivor count (a barrier follows before it is used)
-        constexpr int NW = NT / 64;
-        constexpr int PW = 1024 / NT < 1 ? 1 : 1024 / NT;  // pivots per lane at most (blocks <= 1024)
+        // (at most 4 slices: with 16 waves of 28 pivots each the minimum of 16 small-sample answers let a
+        // fifth more keys through at k = 1000)
+        constexpr int NW = NT / 64 < 4 ? NT / 64 : 4;       // waves that search a slice
+        constexpr int PW = 1024 / (64 * NW);                // pivots per lane at most (blocks <= 1024)
         const int wv = tid >> 6, ln = tid & 63;
         const int Q = (p.blocks + NW - 1) / NW;             // pivots of one wave's slice
         u32 pv[PW];
@@ -946,7 +948,7 @@ static __device__ __forceinline__ void finalize_body(const ls_fin_params& p, uns
             if (!complete) mb = ~0ull;  // no keys, an unbeatable bound: the proof below fails
             __syncthreads();
             LS_HO(6);
-            if (prefilter) {  // (clamped, unconditional reads: slot 2047 holds junk, masked)
+            if (prefilter && wv < NW) {  // (clamped, unconditional reads: slot 2047 holds junk, masked)
 #pragma unroll
                 for (int j = 0; j < PW; ++j) {
                     const int o = ln + 64 * j, b = wv * Q + o;
@@ -958,7 +960,7 @@ static __device__ __forceinline__ void finalize_body(const ls_fin_params& p, uns
         } else {
             // (loads return in order: the pivots go out first, so the wave that needs them does not
             // wait for its share of the candidates as well)
-            if (prefilter) {
+            if (prefilter && wv < NW) {
 #pragma unroll
                 for (int j = 0; j < PW; ++j) {
                     const int o = ln + 64 * j, b = wv * Q + o;
@@ -977,8 +979,8 @@ static __device__ __forceinline__ void finalize_body(const ls_fin_params& p, uns
                 mine[j] = i < mc ? p.cand[i] : 0ull;
             }
         }
-        u32* const pw = reinterpret_cast<u32*>(red);  // one answer per wave (red[] = 16 free u64)
-        {
+        u32* const pw = reinterpret_cast<u32*>(red);  // one answer per searching wave (red[] = 16 free u64)
+        if (wv < NW) {
             // No LDS shuffles on the critical path (a ds_bpermute round trip is ~120 cycles and a wave is
             // alone on its SIMD here: the max / min / sum butterflies and the bound reduction of the first
             // version were 3 of the 5.8 us between "every key is here" and "survivors in LDS").
@@ -1102,12 +1104,24 @@ static __device__ __forceinline__ void finalize_body(const ls_fin_params& p, uns
         }
     }
     __syncthreads();
-    if (p.done) {
-        // Host API: the outputs are pinned host rows and the host spins on a completion word. The
-        // rows are written THROUGH at system scope, every wave drains them, the workgroup meets and
-        // ONE lane publishes - the drained write-through hand-off with the host as the consumer. No
-        // system-scope release fence: it would write back this XCD's whole L2, which inside a scan
-        // launch holds ~100 KB of freshly written score vector nobody is waiting for.
+    if (p.out_gran) {
+        // Host API: tagged result granules in pinned host memory (ls_fin_params::out_gran), one 16-byte
+        // system-scope (sc0 sc1) store per result, nothing behind them. No system-scope release fence
+        // either: it would write back this XCD's whole L2, which inside a scan launch holds ~100 KB of
+        // freshly written score vector nobody is waiting for.
+        __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out_gran, 0, p.k * 16, LS_BUF_RSRC_FLAGS);
+        for (int i = tid; i < p.k; i += NT) {
+            const u64 key = (i < nvalid) ? res[i] : 0ull;
+            const u32 row = key ? 0xffffffffu - (u32)key : 0xffffffffu;
+            __builtin_amdgcn_raw_buffer_store_b128(
+                u32x4{__builtin_bit_cast(u32, ls_key_score(key)), p.done_val, row, p.done_val}, orsrc, i * 16, 0,
+                LS_AUX_SC1 | 1 /* sc0 */);
+        }
+    } else if (p.done) {
+        // Host API, k > LS_OUT_GRAN_MAX_K: the outputs are pinned host rows and the host spins on a
+        // completion word. The rows are written THROUGH at system scope, every wave drains them, the
+        // workgroup meets and ONE lane publishes - the drained write-through hand-off with the host as
+        // the consumer (no system-scope release fence, for the reason above).
         for (int i = tid; i < p.k; i += NT) {
             const u64 key = (i < nvalid) ? res[i] : 0ull;
             __hip_atomic_store(&p.out_scores[i], ls_key_score(key), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -260,19 +260,24 @@ class FlatIPIndex:
         x: float32 [nq, d]. Returns (D float32 [nq, k], I int64 [nq, k]) best first under
         (score desc, row asc); unfilled slots are (-FLT_MAX, -1).
         """
-        x = np.ascontiguousarray(x, dtype=np.float32)
+        # (this wrapper is ~2 us of a 62 us call: no conversion call for the usual float32 row-major
+        # query, no helper objects for the three pointers - native.addr)
+        if type(x) is not np.ndarray or x.dtype != np.float32 or not x.flags.c_contiguous:
+            x = np.ascontiguousarray(x, dtype=np.float32)
         if x.ndim != 2 or x.shape[1] != self.d:
             raise ValueError(f"search expects [nq, {self.d}] float32, got {x.shape}")
         k = int(k)
         if k <= 0:
             raise ValueError("k must be positive")
-        h = self._ensure_built()
+        h = self._handle if self._handle is not None else self._ensure_built()
         nq = x.shape[0]
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
-        flags = native.LS_FLAG_NORMALIZE if normalize else 0
-        native.check(native.load().ls_search(h, native.addr(x), nq, k, flags, native.addr(D),
-                                             native.addr(I)))
+        addr = native.addr
+        rc = native.load().ls_search(h, addr(x), nq, k, native.LS_FLAG_NORMALIZE if normalize else 0,
+                                     addr(D), addr(I))
+        if rc:
+            native.check(rc)
         return D, I
 
     def search_device(self, q, k: int, out_scores=None, out_indices=None, *,

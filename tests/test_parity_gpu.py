@@ -255,6 +255,41 @@ def test_forced_slow_path_equals_fast_path(dtype):
     ix.close()
 
 
+def test_synchronous_call_hand_off_variants_agree():
+    """The synchronous host call (the reference's index.search, search/engine.py:250) in its four shapes:
+    selection inside the scan launch over tagged granules (default), too many granules for the
+    in-launch sweep (k' forced to 12: 448 x 13 > LS_GRAN_MAX, the selection gets its own launch), the
+    query brought over by a copy command (debug option 15), selection as its own launch (option 9 = 0).
+    Same bits from all of them, one launch for the first, results through the tagged result granules
+    (a base offset is applied by the host when it decodes the keys)."""
+    c = H.gauss(41, 200_000, 384)
+    q = H.gauss(42, 5, 384)
+    ix = FlatIPIndex.from_array(c, base=1_000_000_007)
+    ref = None
+    for opts in ([], [(0, 12)], [(15, 1)], [(9, 0)]):
+        for which, value in opts:
+            ix.debug_option(which, value)
+        before = ix.debug_counter(11)
+        outs = [ix.search(q[i:i + 1], 50, normalize=True) for i in range(5)]
+        launches = ix.debug_counter(11) - before
+        D = np.concatenate([o[0] for o in outs]); I = np.concatenate([o[1] for o in outs])
+        if ref is None:
+            ref = (D, I)
+            assert launches == 5 + ix.debug_counter(20), launches   # one launch per call
+            qn = q / np.linalg.norm(q, axis=1, keepdims=True)
+            Dr, Ir = oracle.c_search(c, qn.astype(np.float32), 50)
+            _, _, S = oracle.np_search(c, qn.astype(np.float32), 50)
+            rep = oracle.compare_topk(D, I - 1_000_000_007, Dr, Ir, S, score_tol=1e-5, tie_eps=2e-6)
+            assert rep["recall"] == 1.0, rep
+        else:
+            assert np.array_equal(D, ref[0]) and np.array_equal(I, ref[1]), opts
+            if opts[0][0] in (0, 9):
+                assert launches == 10, (opts, launches)               # scan + its own selection launch
+        for which, _ in opts:
+            ix.debug_option(which, 1 if which == 9 else 0)
+    ix.close()
+
+
 def test_negative_zero_nan():
     c = H.gauss(8, 5000, 64)
     check(-np.abs(c), np.abs(c[:2]), 20)

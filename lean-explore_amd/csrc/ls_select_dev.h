@@ -254,6 +254,19 @@ __device__ __forceinline__ u32 wave_or_dpp(u32 v) {
     return (u32)r[0] | (u32)r[1];
 }
 
+// Inclusive prefix sum over the 64 lanes in pure VALU (whole wave active): Hillis-Steele inside the
+// 16-lane rows (row_shr 1, 2, 4, 8; lanes shifted in from outside a row read 0), then lane 15 of a
+// row to the next row (row_bcast15 into rows 1 and 3), then lane 31 to the upper half (row_bcast31).
+__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast15 -> rows 1, 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast31 -> rows 2, 3
+    return v;
+}
+
 // The wave's histogram (256 bins, lane t holds bins 4t..4t+3 in LDS) -> the bin that holds the
 // krem-th largest counted element; krem becomes the rank inside that bin, *nbin its population.
 __device__ __forceinline__ u32 wave_find_bin(const u32* hist, u32& krem, u32* nbin, int lane) {
@@ -1034,12 +1047,18 @@ static __device__ __forceinline__ void finalize_body(const ls_fin_params& p, uns
         u32 T0 = pw[0];  // the smallest of the waves' answers (0 = no pre-filter)
 #pragma unroll
         for (int w = 1; w < NW; ++w) T0 = pw[w] < T0 ? pw[w] : T0;
-        for (int c0 = 0;; c0 += CH * NT) {  // survivors -> LDS: one LDS atomic per thread that keeps any
+        for (int c0 = 0;; c0 += CH * NT) {  // survivors -> LDS: ONE LDS atomic per wave and round
+            // (one per keeping thread was tried: fine for the ~60 survivors of k = 50, but at k = 1000
+            // most of 1024 threads keep something and a thousand atomics on one LDS word took 3.8 us)
             u32 nkeep = 0;
 #pragma unroll
             for (int j = 0; j < CH; ++j) nkeep += mine[j] != 0ull && (u32)(mine[j] >> 32) >= T0;
-            if (nkeep) {
-                u32 at = atomicAdd(&misc[7 * 8 + 4], nkeep);
+            const u32 inc = wave_incl_scan_dpp(nkeep);  // prefix over the lanes, no LDS crossbar
+            const u32 wave_total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+            if (wave_total) {
+                u32 base = 0;
+                if ((tid & 63) == 0) base = atomicAdd(&misc[7 * 8 + 4], wave_total);
+                u32 at = (u32)__builtin_amdgcn_readfirstlane((int)base) + inc - nkeep;
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {  // (a dropped key goes to tmp[0], a slot nobody reads: no branch per key)
                     const bool keep = mine[j] != 0ull && (u32)(mine[j] >> 32) >= T0;

@@ -273,9 +273,13 @@ class FlatIPIndex:
         nq = x.shape[0]
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
-        addr = native.addr
-        rc = native.load().ls_search(h, addr(x), nq, k, native.LS_FLAG_NORMALIZE if normalize else 0,
-                                     addr(D), addr(I))
+        flags = native.LS_FLAG_NORMALIZE if normalize else 0
+        fast = native.fast_search()
+        if fast is not None:  # csrc/lsfast.c: the same ls_search, bound without ctypes' argument conversion
+            rc = fast[0].search(fast[1], h.value, x, nq, k, flags, D, I)
+        else:
+            addr = native.addr
+            rc = native.load().ls_search(h, addr(x), nq, k, flags, addr(D), addr(I))
         if rc:
             native.check(rc)
         return D, I

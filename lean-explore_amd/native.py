@@ -125,6 +125,24 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+_fast = None
+_fast_tried = False
+
+
+def fast_search():
+    """(module, address of ls_search) of the CPython binding csrc/lsfast.c, or None: the same symbol
+    of the same library as the ctypes binding, minus ~1.5 us of argument conversion per call."""
+    global _fast, _fast_tried
+    if not _fast_tried:
+        _fast_tried = True
+        try:
+            from . import _lsfast
+            _fast = (_lsfast, ctypes.cast(load().ls_search, ctypes.c_void_p).value)
+        except ImportError:
+            _fast = None
+    return _fast
+
+
 _c_char_from_buffer = ctypes.c_char.from_buffer
 _addressof = ctypes.addressof
 

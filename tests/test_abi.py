@@ -121,3 +121,30 @@ def test_register_budget_of_the_co_resident_kernels(tmp_path):
     # kernel's whole job array there: 984 bytes per lane)
     for n, u in {**pick("ls_finalize_kernel"), **pick("ls_merge_kernel")}.items():
         assert u["ScratchSize [bytes/lane]"] == 0, (n, u)
+
+
+def test_fast_binding_loads_and_checks_buffers():
+    """csrc/lsfast.c (the CPython binding of ls_search behind FlatIPIndex.search) is built, resolves
+    the same symbol as the ctypes binding, and refuses a null handle or output buffers that are too
+    short for nq * k results instead of letting the library write past them (no compute call)."""
+    import ctypes
+
+    import numpy as np
+    import pytest
+
+    from lean_explore_amd import native
+
+    fast = native.fast_search()
+    assert fast is not None, "lean-explore_amd/_lsfast*.so missing: run __graft_entry__.build()"
+    mod, fn = fast
+    assert fn == ctypes.cast(native.load().ls_search, ctypes.c_void_p).value
+    x = np.zeros((1, 8), np.float32)
+    D = np.empty((1, 4), np.float32)
+    I = np.empty((1, 4), np.int64)
+    with pytest.raises(ValueError):
+        mod.search(fn, 0, x, 1, 4, 0, D, I)          # null handle
+    with pytest.raises(ValueError):
+        mod.search(fn, 1, x, 1, 50, 0, D, I)         # 50 results do not fit 4 slots
+    with pytest.raises((TypeError, BufferError, ValueError)):
+        mod.search(fn, 1, x, 1, 4, 0, b"read-only", I)
+

@@ -290,6 +290,22 @@ def test_synchronous_call_hand_off_variants_agree():
     ix.close()
 
 
+def test_fast_binding_equals_ctypes_binding():
+    """FlatIPIndex.search goes through csrc/lsfast.c when it is built; the raw ctypes call of the same
+    ls_search on the same handle returns the same bits."""
+    c = H.gauss(51, 30_000, 128)
+    q = H.gauss(52, 3, 128)
+    ix = FlatIPIndex.from_array(c)
+    assert native.fast_search() is not None
+    D, I = ix.search(q, 20, normalize=True)
+    D2 = np.empty((3, 20), np.float32)
+    I2 = np.empty((3, 20), np.int64)
+    native.check(native.load().ls_search(ix._handle, q.ctypes.data, 3, 20, native.LS_FLAG_NORMALIZE,
+                                         D2.ctypes.data, I2.ctypes.data))
+    assert np.array_equal(D, D2) and np.array_equal(I, I2)
+    ix.close()
+
+
 def test_negative_zero_nan():
     c = H.gauss(8, 5000, 64)
     check(-np.abs(c), np.abs(c[:2]), 20)

@@ -231,8 +231,9 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * launch of its own query, sweeping the tagged 16-byte granules the scan workgroups write their keys as
  * (no drain, no counter, no fence; a query whose keys cannot be proven complete answers "retry" in its
  * completion word and the host launches the stand-alone selection): 0 off, 1 on (default);
- * option 15: synchronous host searches bring the query to device memory with a copy command in front of
- * the launch (1, default) or let the scan workgroups read the pinned host copy over PCIe (0: 4-5 us slower);
+ * option 15: synchronous host searches let the scan workgroups read the pinned host copy of the query
+ * over PCIe (0, default: the read hides under the first corpus tile) or bring it to device memory with a
+ * copy command in front of the launch (1: measured 1.6-2 us slower per call);
  * option 10: synchronous host searches (ls_search) that arrive while another one is running are
  * served together, up to 16 queries of equal k and flags per corpus pass (default on);
  * option 13: pipelined fp16 batches of stored rows of up to 768 bytes let the sample phase of the batch

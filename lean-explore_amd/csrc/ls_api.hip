@@ -1049,19 +1049,18 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
         ix->h_out_cap = std::min(c1, c2);
     }
     // Pinned host buffers are device-visible. Results: the selection writes the output rows into
-    // h_out_* over PCIe itself (no copy command behind the kernel). Queries: a copy command in front
-    // of the launch. Round 3 let the scan workgroups read the pinned query themselves "to save the copy
-    // command's latency"; tools/host_roundtrip_probe.hip says otherwise: 448 workgroups reading 1.5 KB
-    // from pinned host memory start 7.4 us late, behind a copy command 2.7 us late (kernel arguments:
-    // 1.5 us, but 4 KB of them do not hold the reference's d = 1024 query), and the timeline of a call
-    // (tools/handoff_timeline.py) showed the last scan workgroup ending 50.1 us after the first
-    // started, against 46.5 us with the query in HBM. Debug option 15 = 0 brings the direct read back.
+    // h_out_* over PCIe itself (no copy command behind the kernel). Queries: the scan workgroups read
+    // the pinned copy themselves (small calls). A stand-alone probe (tools/host_roundtrip_probe.hip)
+    // prices that read at 7.4 us for 448 idle workgroups against 2.7 us behind a copy command and
+    // 1.5 us through the kernel arguments - but in the scan kernel the first corpus tile's loads are
+    // in flight before the query is touched, so the read hides, and the copy command measured 1.6-2 us
+    // SLOWER per call (profiles/ab/r04_hostapi_selection.txt). Debug option 15 = 1 selects the copy.
     const bool small_call = nq <= LS_SCAN_PATH_MAX_NQ;
     const bool in_direct = small_call && !ix->opt_query_copy;
     const bool out_direct = on <= (size_t)(1 << 16);
-    // Small scan-path calls: the finalize workgroup of every query publishes a completion word
-    // in pinned host memory once its (pinned) output rows are visible; the host spins on those
-    // words instead of sleeping in hipStreamSynchronize (whose wake-up costs more than the
+    // Small scan-path calls: the finalize workgroup of every query writes tagged result granules
+    // (k <= LS_OUT_GRAN_MAX_K) or drained rows + a completion word into pinned host memory; the host
+    // spins on those instead of sleeping in hipStreamSynchronize (whose wake-up costs more than the
     // 47 us scan's launch). Falls back to the stream sync after 2 ms.
     const bool spin = small_call && out_direct && !ls_i_batched_eligible(ix, nq, k) && ix->n > 0;
     if (spin && !ix->h_done) {

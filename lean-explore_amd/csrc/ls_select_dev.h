@@ -243,6 +243,21 @@ template <int CTRL>
 __device__ __forceinline__ u32 dpp_or(u32 v) {
     return v | (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_max(u32 v) {
+    const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ u32 wave_max_dpp(u32 v) {  // max over the 64 lanes, in every lane
+    v = dpp_max<0xB1>(v);
+    v = dpp_max<0x4E>(v);
+    v = dpp_max<0x141>(v);
+    v = dpp_max<0x140>(v);
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = (u32)r[0] > (u32)r[1] ? (u32)r[0] : (u32)r[1];
+    r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (u32)r[0] > (u32)r[1] ? (u32)r[0] : (u32)r[1];
+}
 __device__ __forceinline__ u32 wave_or_dpp(u32 v) {
     v = dpp_or<0xB1>(v);   // quad_perm [1,0,3,2]
     v = dpp_or<0x4E>(v);   // quad_perm [2,3,0,1]
@@ -361,7 +376,7 @@ static __device__ __forceinline__ int lds_topk(const u64* keys, int cnt, int k, 
         LS_STAMP(5);
         return k < nnz ? k : nnz;
     }
-    if (cnt <= LS_SS_MAX_KEYS && nt >= 256 && nt % 256 == 0) {  // (nt / LS_SS_SAMPLE: a power of two <= 64)
+    if (cnt <= LS_SS_MAX_KEYS && (nt == 256 || nt == 512 || nt == 1024)) {  // (nt / LS_SS_SAMPLE: a power of two <= 64)
         // ---- splitter buckets (round 4): one bucketing by DATA QUANTILES instead of radix digits ----------
         // 128 of the keys (an even stride through the list) are ranked by counting; every 2nd of them is
         // a splitter, which cuts the key space into 64 buckets of ~cnt/64 keys WHATEVER the values look
@@ -395,7 +410,10 @@ static __device__ __forceinline__ int lds_topk(const u64* keys, int cnt, int k, 
             int rank = 0;
 #pragma unroll 8
             for (int j = part; j < NS; j += G) rank += tmp[j] > mine;
-            for (int o = 1; o < G; o <<= 1) rank += __shfl_xor(rank, o, 64);
+            // sum over the G = 2, 4 or 8 neighbouring lanes that share a sample key: DPP, no LDS crossbar
+            if (G >= 2) rank += __builtin_amdgcn_update_dpp(0, rank, 0xB1, 0xf, 0xf, true);   // + lane ^ 1
+            if (G >= 4) rank += __builtin_amdgcn_update_dpp(0, rank, 0x4E, 0xf, 0xf, true);   // + lane ^ 2
+            if (G >= 8) rank += __builtin_amdgcn_update_dpp(0, rank, 0x141, 0xf, 0xf, true);  // + the other quad of each 8
             if (part == 0) ssort[rank] = mine;
         }
         __syncthreads();
@@ -410,21 +428,14 @@ static __device__ __forceinline__ int lds_topk(const u64* keys, int cnt, int k, 
         __syncthreads();
         if (tid < 64) {
             const u32 c = bcnt[tid];
-            u32 inc = c;
-            for (int o = 1; o < 64; o <<= 1) {
-                const u32 t = (u32)__shfl_up((int)inc, o, 64);
-                if (tid >= o) inc += t;
-            }
+            const u32 inc = wave_incl_scan_dpp(c);
             const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
             const u32 kq = (u32)k < total ? (u32)k : total;  // min(k, #non-zero keys)
             const u32 start = inc - c;
             bstart[tid] = start;
             bcur[tid] = 0u;
             u32 big = start < kq ? c : 0u;  // only the buckets that reach into the top kq are walked
-            for (int o = 32; o >= 1; o >>= 1) {
-                const u32 t = (u32)__shfl_xor((int)big, o, 64);
-                big = t > big ? t : big;
-            }
+            big = wave_max_dpp(big);
             if (kq > 0 && start < kq && kq <= inc) {  // exactly one lane: the bucket that holds the kq-th key
                 misc[0] = (u32)tid;
                 misc[1] = start;

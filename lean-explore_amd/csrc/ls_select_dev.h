@@ -218,23 +218,27 @@ __device__ __forceinline__ void wave_hist_add(u32* hist, u32 digit, bool active,
 }
 
 // ---- single-wave helpers (ls_wsel.hip, the in-launch tau of ls_gemm.hip): no workgroup barrier ------
+// (whole wave active; pure VALU: DPP inside the 16-lane rows, v_permlane16_swap / v_permlane32_swap across
+// them - a ds_bpermute butterfly is six LDS round trips of ~120 cycles for a wave that is alone on its SIMD)
+template <class OP>
+__device__ __forceinline__ u32 wave_allreduce_dpp(u32 v, OP op) {
+    v = op(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));   // lane ^ 1
+    v = op(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));   // lane ^ 2
+    v = op(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v = op(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));  // row_mirror
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = op((u32)r[0], (u32)r[1]);
+    r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return op((u32)r[0], (u32)r[1]);
+}
 __device__ __forceinline__ u32 wave_sum(u32 v) {
-    for (int o = 32; o >= 1; o >>= 1) v += (u32)__shfl_xor((int)v, o, 64);
-    return v;
+    return wave_allreduce_dpp(v, [](u32 a, u32 b) { return a + b; });
 }
 __device__ __forceinline__ u32 wave_max(u32 v) {
-    for (int o = 32; o >= 1; o >>= 1) {
-        const u32 t = (u32)__shfl_xor((int)v, o, 64);
-        v = t > v ? t : v;
-    }
-    return v;
+    return wave_allreduce_dpp(v, [](u32 a, u32 b) { return a > b ? a : b; });
 }
 __device__ __forceinline__ u32 wave_min(u32 v) {
-    for (int o = 32; o >= 1; o >>= 1) {
-        const u32 t = (u32)__shfl_xor((int)v, o, 64);
-        v = t < v ? t : v;
-    }
-    return v;
+    return wave_allreduce_dpp(v, [](u32 a, u32 b) { return a < b ? a : b; });
 }
 
 // OR over the 64 lanes, in every lane, without the LDS crossbar: DPP inside 16-lane rows, then gfx950's
@@ -243,21 +247,7 @@ template <int CTRL>
 __device__ __forceinline__ u32 dpp_or(u32 v) {
     return v | (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
-template <int CTRL>
-__device__ __forceinline__ u32 dpp_max(u32 v) {
-    const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
-    return o > v ? o : v;
-}
-__device__ __forceinline__ u32 wave_max_dpp(u32 v) {  // max over the 64 lanes, in every lane
-    v = dpp_max<0xB1>(v);
-    v = dpp_max<0x4E>(v);
-    v = dpp_max<0x141>(v);
-    v = dpp_max<0x140>(v);
-    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    v = (u32)r[0] > (u32)r[1] ? (u32)r[0] : (u32)r[1];
-    r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return (u32)r[0] > (u32)r[1] ? (u32)r[0] : (u32)r[1];
-}
+__device__ __forceinline__ u32 wave_max_dpp(u32 v) { return wave_max(v); }
 __device__ __forceinline__ u32 wave_or_dpp(u32 v) {
     v = dpp_or<0xB1>(v);   // quad_perm [1,0,3,2]
     v = dpp_or<0x4E>(v);   // quad_perm [2,3,0,1]

@@ -84,6 +84,9 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 #ifndef LS_ABL_NODMA
 #define LS_ABL_NODMA 0     // no tile DMA after the first tile: the MFMA stream alone
 #endif
+#ifndef LS_ABL_LDSREADS
+#define LS_ABL_LDSREADS 1  // 2 / 4: the two-accumulator pass reads only 1/2, 1/4 of its A fragments from LDS
+#endif
 #ifndef LS_GEMM_LEAN
 #define LS_GEMM_LEAN 0               // 1: every geometry recomputes DMA offsets / queue bases (fewer registers)
 #endif

@@ -534,25 +534,32 @@ __device__ __forceinline__ void gemm_filter_body(
             for (int e = 0; e < NV; ++e) check(ph, prev, e, prev_row0);
         }
         half8 a[2][NRB];  // A fragments are read one k-step ahead of their MFMAs
+        // (LS_ABL_LDSREADS, timing ablation with wrong results: only the first NRB / LS_ABL_LDSREADS
+        // row blocks are read from LDS, the other blocks' MFMAs reuse those registers - their chains
+        // start from 1, 2, 4 instead of 0 so that the compiler cannot merge them: no extra instruction.
+        // Build it together with LS_ABL_NOPASS (the shifted scores would all pass the filter): what a
+        // tile shape with that many times fewer LDS reads per MFMA could gain at most)
+        constexpr int NRD = LS_ABL_LDSREADS > 1 ? (NRB / LS_ABL_LDSREADS > 0 ? NRB / LS_ABL_LDSREADS : 1) : NRB;  // row blocks really read
+        auto a_load = [&](half8 (&dst)[NRB], int kk) {
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) a[0][rb] = a_frag(bufoff, rb, 0);
+            for (int rb = 0; rb < NRD; ++rb) dst[rb] = a_frag(bufoff, rb, kk);
+        };
+        a_load(a[0], 0);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            if (kk + 1 < KS) {
-#pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) a[(kk + 1) & 1][rb] = a_frag(bufoff, rb, kk + 1);
-            }
+            if (kk + 1 < KS) a_load(a[(kk + 1) & 1], kk + 1);
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
 #pragma unroll
                 for (int g2 = 0; g2 < QG; ++g2) {
                     f32x4v c;
                     if (kk == 0) {
-                        c[0] = 0.0f; c[1] = 0.0f; c[2] = 0.0f; c[3] = 0.0f;
+                        const float c0 = rb / NRD == 0 ? 0.0f : rb / NRD == 1 ? 1.0f : rb / NRD == 2 ? 2.0f : 4.0f;  // inline constants
+                        c[0] = c0; c[1] = c0; c[2] = c0; c[3] = c0;
                     } else {
                         c = cur[rb][g2];
                     }
-                    cur[rb][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk & 1][rb], bq[g2][kk],
+                    cur[rb][g2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk & 1][rb % NRD], bq[g2][kk],
                                                                         c, 0, 0, 0);
                 }
             }

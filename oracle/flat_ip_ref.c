@@ -25,7 +25,10 @@
  * checks this file against those. FAISS's own summation order and tie behaviour cannot be
  * observed here (no faiss), so they are fixed by definition:
  *   summation  : scores: plain left-to-right fp32, one rounding per multiply and one per add
- *                (compiled with -ffp-contract=off so no FMA contraction sneaks in);
+ *                (compiled with -ffp-contract=off so no FMA contraction sneaks in) - ORDER_STRICT,
+ *                the definition; ORDER_SCAN / ORDER_FMA restate the HIP kernels' own fp32 orders
+ *                (explicit fmaf calls, so -ffp-contract=off does not touch them) for the
+ *                zero-excuse index checks;
  *                squared norm of normalize_L2: see oracle_normalize_l2 below
  *   total order: score descending, then row index ascending
  *   not returned: rows whose score is NaN or <= -FLT_MAX (a FAISS heap never admits them:
@@ -135,6 +138,73 @@ static inline float dot_f32(const float* a, const float* b, int32_t d) {
     return acc;
 }
 
+/* ---- the HIP kernels' own fp32 summation orders (parity modes; see the header of oracle.py) ----
+ * The strict left-to-right order above is the DEFINITION the 1e-5 score bound is checked against.
+ * The fp32 kernels sum in two other, fully documented orders; restating them lets the parity tests
+ * demand bit-identical scores AND indices (no near-tie excuse) on continuous data:
+ *
+ * ORDER_SCAN (lean-explore_amd/csrc/ls_scan.hip:66-77 QueryRegs::dot, :129-145 group_sum; the
+ * multi-query reduce-scatter :158-186 and the f32 MFMA small-batch kernel ls_mq.hip add the same
+ * operands in the same order): a stored row is `chunks` 16-byte chunks (4 floats), chunks = L*V
+ * (ls_pick_geom, csrc/ls_prep.hip:123-142, restated in geom_f32 below; zero padded). Lane `sub` of the
+ * L lanes sharing a row runs ONE fmaf chain, starting from +0, over its chunks sub, sub+L, ..,
+ * sub+(V-1)L in that order, the four floats of a chunk in memory order:
+ *     p[sub] = fmaf(x[e], q[e], p[sub]),  e = 4*(sub + L*v) + 0..3,  v = 0..V-1
+ * and the L partial sums are combined by the balanced xor tree with strides 1, 2, 4, .., L/2
+ * (p[i] = p[i] + p[i ^ o]; fp32 addition is commutative, so every lane holds the same value).
+ *
+ * ORDER_FMA (lean-explore_amd/csrc/ls_gemm32.hip: v_mfma_f32_16x16x4_f32 over k = 0..d_pad-1; measured
+ * on gfx950 by tools/arith_probe.hip to be bit for bit a sequential fmaf chain in increasing k):
+ *     acc = fmaf(x[k], q[k], acc),  k = 0..d-1, starting from +0.
+ * (zero padding adds fmaf(0, 0, acc) = acc in both orders and is skipped here.)
+ */
+enum { ORDER_STRICT = 0, ORDER_SCAN = 1, ORDER_FMA = 2 };
+
+/* fp32 row geometry: chunks padded up to one of the supported sizes, L lanes x V chunks per lane */
+static int geom_f32(int32_t d, int* L, int* V) {
+    static const int sizes[8][3] = {{16, 16, 1}, {32, 16, 2}, {48, 16, 3},  {64, 16, 4},
+                                    {96, 32, 3}, {128, 32, 4}, {192, 64, 3}, {256, 64, 4}};
+    const int raw = (d + 3) / 4;
+    for (int i = 0; i < 8; ++i)
+        if (sizes[i][0] >= raw) { *L = sizes[i][1]; *V = sizes[i][2]; return 0; }
+    return -1;
+}
+int oracle_geom_f32(int32_t d, int32_t* L, int32_t* V) {
+    int l = 0, v = 0;
+    if (geom_f32(d, &l, &v)) return -1;
+    *L = l; *V = v;
+    return 0;
+}
+
+static inline float dot_scan_order(const float* a, const float* b, int32_t d, int L, int V) {
+    float p[64];
+    for (int sub = 0; sub < L; ++sub) {
+        float acc = 0.0f;
+        for (int v = 0; v < V; ++v) {
+            const int32_t e0 = 4 * (sub + L * v);
+            for (int j = 0; j < 4; ++j) {
+                const int32_t e = e0 + j;
+                const float x = e < d ? a[e] : 0.0f, y = e < d ? b[e] : 0.0f;
+                acc = fmaf(x, y, acc);
+            }
+        }
+        p[sub] = acc;
+    }
+    for (int o = 1; o < L; o <<= 1)
+        for (int i = 0; i < L; i += 2 * o) p[i] = p[i] + p[i + o];
+    return p[0];
+}
+static inline float dot_fma_order(const float* a, const float* b, int32_t d) {
+    float acc = 0.0f;
+    for (int32_t j = 0; j < d; ++j) acc = fmaf(a[j], b[j], acc);
+    return acc;
+}
+static inline float dot_order(const float* a, const float* b, int32_t d, int order, int L, int V) {
+    if (order == ORDER_SCAN) return dot_scan_order(a, b, d, L, V);
+    if (order == ORDER_FMA) return dot_fma_order(a, b, d);
+    return dot_f32(a, b, d);
+}
+
 /* all scores of one query: out[r] = <corpus[r], q> */
 void oracle_scores(const float* corpus, int64_t n, int32_t d, const float* q, float* out) {
 #pragma omp parallel for schedule(static)
@@ -192,17 +262,21 @@ static void select_topk(const float* scores, int64_t n, int32_t k, int64_t base,
  * result because every score is one sequential dot product.
  * Returns 0, or -1 on bad arguments / allocation failure.
  */
-int oracle_flat_ip_topk(const float* corpus, int64_t n, int32_t d, const float* q, int64_t nq,
-                        int32_t k, int64_t base, float* D, int64_t* I) {
+int oracle_flat_ip_topk_order(const float* corpus, int64_t n, int32_t d, const float* q, int64_t nq,
+                              int32_t k, int64_t base, int32_t order, float* D, int64_t* I) {
     if (n < 0 || d <= 0 || nq < 0 || k <= 0 || (n > 0 && !corpus) || (nq > 0 && (!q || !D || !I)))
         return -1;
+    if (order < ORDER_STRICT || order > ORDER_FMA) return -1;
+    int L = 0, V = 0;
+    if (order == ORDER_SCAN && geom_f32(d, &L, &V)) return -1;
     if (nq == 0) return 0;
     int fail = 0;
     if (nq == 1) {
         float* s = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
         uint64_t* heap = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)k);
         if (!s || !heap) { free(s); free(heap); return -1; }
-        oracle_scores(corpus, n, d, q, s);
+#pragma omp parallel for schedule(static)
+        for (int64_t r = 0; r < n; ++r) s[r] = dot_order(corpus + r * (int64_t)d, q, d, order, L, V);
         select_topk(s, n, k, base, D, I, heap);
         free(s); free(heap);
         return 0;
@@ -218,13 +292,26 @@ int oracle_flat_ip_topk(const float* corpus, int64_t n, int32_t d, const float* 
 #pragma omp for schedule(dynamic, 1)
             for (int64_t i = 0; i < nq; ++i) {
                 const float* qi = q + i * (int64_t)d;
-                for (int64_t r = 0; r < n; ++r) s[r] = dot_f32(corpus + r * (int64_t)d, qi, d);
+                for (int64_t r = 0; r < n; ++r) s[r] = dot_order(corpus + r * (int64_t)d, qi, d, order, L, V);
                 select_topk(s, n, k, base, D + i * (int64_t)k, I + i * (int64_t)k, heap);
             }
         }
         free(s); free(heap);
     }
     return fail ? -1 : 0;
+}
+int oracle_flat_ip_topk(const float* corpus, int64_t n, int32_t d, const float* q, int64_t nq,
+                        int32_t k, int64_t base, float* D, int64_t* I) {
+    return oracle_flat_ip_topk_order(corpus, n, d, q, nq, k, base, ORDER_STRICT, D, I);
+}
+/* all scores of one query in a given order (tests: the score vector S the scan kernels write) */
+int oracle_scores_order(const float* corpus, int64_t n, int32_t d, const float* q, int32_t order, float* out) {
+    int L = 0, V = 0;
+    if (order < ORDER_STRICT || order > ORDER_FMA) return -1;
+    if (order == ORDER_SCAN && geom_f32(d, &L, &V)) return -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r) out[r] = dot_order(corpus + r * (int64_t)d, q, d, order, L, V);
+    return 0;
 }
 
 /*

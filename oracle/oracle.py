@@ -6,6 +6,9 @@ Two independent restatements of the reference's dense-retrieval arithmetic
 * ``c_*``  : ctypes bindings of oracle/flat_ip_ref.c (strict left-to-right fp32).
 * ``np_*`` : a numpy twin (float64 accumulate, ``np.lexsort``) used to cross-check the C file
   and as the "ground truth" when a near-tie makes fp32 summation order matter.
+* ``order="scan" / "fma"`` of the C file + ``compare_kernel_order``: the fp32 kernels' own documented
+  summation orders restated on the CPU, so that fp32 results are checked BIT FOR BIT (scores and
+  indices, no near-tie excuse) in addition to the 1e-5 / near-tie check against the strict order.
 
 Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg may import this
 module. The product package (lean-explore_amd/) never does.
@@ -48,6 +51,15 @@ def _load(name: str) -> ctypes.CDLL:
         _f32p, ctypes.c_int64, ctypes.c_int32, _f32p, ctypes.c_int64, ctypes.c_int32,
         ctypes.c_int64, _f32p, _i64p,
     ]
+    lib.oracle_flat_ip_topk_order.restype = ctypes.c_int
+    lib.oracle_flat_ip_topk_order.argtypes = [
+        _f32p, ctypes.c_int64, ctypes.c_int32, _f32p, ctypes.c_int64, ctypes.c_int32,
+        ctypes.c_int64, ctypes.c_int32, _f32p, _i64p,
+    ]
+    lib.oracle_scores_order.restype = ctypes.c_int
+    lib.oracle_scores_order.argtypes = [_f32p, ctypes.c_int64, ctypes.c_int32, _f32p, ctypes.c_int32, _f32p]
+    lib.oracle_geom_f32.restype = ctypes.c_int
+    lib.oracle_geom_f32.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     lib.oracle_merge_topk.restype = ctypes.c_int
     lib.oracle_merge_topk.argtypes = [
         _f32p, _i64p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, _f32p, _i64p,
@@ -97,18 +109,47 @@ def c_round_f16(x: np.ndarray) -> np.ndarray:
     return y
 
 
-def c_scores(corpus: np.ndarray, q: np.ndarray) -> np.ndarray:
+# fp32 summation orders of oracle_flat_ip_topk_order (flat_ip_ref.c):
+#   "strict": left to right, one rounding per multiply and per add - the DEFINITION scores are held to
+#             (1e-5, BASELINE.json) and what compare_topk's near-tie excuse refers to;
+#   "scan"  : the fp32 scan kernels' own order (per-lane fmaf chains over chunks sub, sub+L, .. then the
+#             xor tree; csrc/ls_scan.hip, and the f32 MFMA small-batch kernel csrc/ls_mq.hip reproduces
+#             it) - every fp32 search of nq < LS_GEMM32_MIN_NQ queries must match it BIT FOR BIT;
+#   "fma"   : one sequential fmaf chain in increasing k (csrc/ls_gemm32.hip's v_mfma_f32_16x16x4_f32,
+#             measured bit-identical to that chain by tools/arith_probe.hip) - fp32 batches of
+#             >= LS_GEMM32_MIN_NQ queries (a query repaired through the scan path follows "scan").
+ORDERS = {"strict": 0, "scan": 1, "fma": 2}
+SCAN_PATH_MAX_NQ_F32 = 23  # LS_GEMM32_MIN_NQ - 1 (csrc/ls_common.h)
+
+
+def kernel_order(nq: int) -> str:
+    """The summation order the library uses for an fp32 index and a call of nq queries."""
+    return "scan" if nq <= SCAN_PATH_MAX_NQ_F32 else "fma"
+
+
+def geom_f32(d: int) -> tuple[int, int]:
+    L, V = ctypes.c_int32(), ctypes.c_int32()
+    if lib().oracle_geom_f32(d, ctypes.byref(L), ctypes.byref(V)) != 0:
+        raise ValueError(f"no fp32 row geometry for d={d}")
+    return L.value, V.value
+
+
+def c_scores(corpus: np.ndarray, q: np.ndarray, *, order: str = "strict") -> np.ndarray:
     corpus = _f32(corpus)
     q = _f32(q).reshape(-1)
     out = np.empty(corpus.shape[0], dtype=np.float32)
-    lib().oracle_scores(_ptr(corpus, _f32p), corpus.shape[0], corpus.shape[1], _ptr(q, _f32p),
-                        _ptr(out, _f32p))
+    rc = lib().oracle_scores_order(_ptr(corpus, _f32p), corpus.shape[0], corpus.shape[1], _ptr(q, _f32p),
+                                   ORDERS[order], _ptr(out, _f32p))
+    if rc != 0:
+        raise RuntimeError("oracle_scores_order failed")
     return out
 
 
 def c_search(corpus: np.ndarray, q: np.ndarray, k: int, *, base: int = 0, f16: bool = False,
-             normalize: bool = False, fast: bool = False) -> tuple[np.ndarray, np.ndarray]:
-    """Exact inner-product top-k: (D f32 [nq,k], I i64 [nq,k]), best first, -1 padded."""
+             normalize: bool = False, fast: bool = False, order: str = "strict"
+             ) -> tuple[np.ndarray, np.ndarray]:
+    """Exact inner-product top-k: (D f32 [nq,k], I i64 [nq,k]), best first, -1 padded.
+    ``order`` picks the fp32 summation order (see ORDERS above; fp32 storage only)."""
     corpus = _f32(corpus)
     q = _f32(q)
     if q.ndim == 1:
@@ -124,10 +165,12 @@ def c_search(corpus: np.ndarray, q: np.ndarray, k: int, *, base: int = 0, f16: b
     nq = q.shape[0]
     D = np.empty((nq, k), dtype=np.float32)
     I = np.empty((nq, k), dtype=np.int64)
-    rc = lib(fast).oracle_flat_ip_topk(_ptr(corpus, _f32p), n, d, _ptr(q, _f32p), nq, k, base,
-                                       _ptr(D, _f32p), _ptr(I, _i64p))
+    if order != "strict" and (f16 or fast):
+        raise ValueError("kernel-order modes restate the fp32 kernels only (strict build)")
+    rc = lib(fast).oracle_flat_ip_topk_order(_ptr(corpus, _f32p), n, d, _ptr(q, _f32p), nq, k, base,
+                                             ORDERS[order], _ptr(D, _f32p), _ptr(I, _i64p))
     if rc != 0:
-        raise RuntimeError("oracle_flat_ip_topk failed")
+        raise RuntimeError("oracle_flat_ip_topk_order failed")
     return D, I
 
 
@@ -241,3 +284,39 @@ def compare_topk(D_a: np.ndarray, I_a: np.ndarray, D_ref: np.ndarray, I_ref: np.
         recall = hits / int(ok.sum())
     return {"max_score_err": max_ds, "index_mismatches": n_diff, "near_ties_excused": n_excused,
             "boundary_ties": n_boundary, "recall": recall}
+
+
+def compare_kernel_order(D_a: np.ndarray, I_a: np.ndarray, corpus: np.ndarray, q: np.ndarray, k: int, *,
+                         base: int = 0, orders: tuple[str, ...] | None = None) -> dict:
+    """ZERO-EXCUSE check for an fp32 index: every query's scores AND indices must be bit-identical to the
+    oracle run in the library's own documented summation order - no tolerance, no near-tie excuse.
+
+    ``q`` is the query as the kernels see it (already normalised if the call normalised). ``orders`` names
+    the admissible orders per query; default: what the library documents for a call of this size - "scan"
+    for nq <= 23, and for larger batches "fma" (the f32 MFMA pass) or, per query, "scan" (a query the
+    batched path re-ran through its exact scan path, or a batch it handed to the scan path whole).
+    Returns how many queries matched each order; raises AssertionError on the first query that matches
+    none, naming the first differing rank."""
+    q = _f32(q)
+    if q.ndim == 1:
+        q = q[None, :]
+    nq = q.shape[0]
+    if orders is None:
+        orders = ("scan",) if nq <= SCAN_PATH_MAX_NQ_F32 else ("fma", "scan")
+    refs = {o: c_search(corpus, q, k, base=base, order=o) for o in orders}
+    matched = {o: 0 for o in orders}
+    for i in range(nq):
+        for o in orders:
+            Dr, Ir = refs[o]
+            if np.array_equal(I_a[i], Ir[i]) and np.array_equal(D_a[i], Dr[i]):
+                matched[o] += 1
+                break
+        else:
+            Dr, Ir = refs[orders[0]]
+            bad = np.nonzero((I_a[i] != Ir[i]) | (D_a[i] != Dr[i]))[0]
+            j = int(bad[0])
+            raise AssertionError(
+                f"query {i}: not bit-identical to the {'/'.join(orders)} order: first difference at rank {j}: "
+                f"got (row {I_a[i, j]}, score {D_a[i, j]!r}) want (row {Ir[i, j]}, score {Dr[i, j]!r}); "
+                f"{bad.size} of {k} ranks differ")
+    return {"kernel_order_queries": matched, "kernel_order_mismatches": 0}

@@ -186,3 +186,64 @@ def test_normalize_order_is_the_documented_one():
             o >>= 1
         inv = np.float32(1.0) / np.sqrt(p[0], dtype=np.float32)
         assert np.array_equal(got[r], x[r] * inv)
+
+
+@pytest.mark.parametrize("order", ["scan", "fma"])
+def test_kernel_order_modes_against_the_twin_and_on_exact_data(order):
+    """The oracle's kernel-order modes (flat_ip_ref.c ORDER_SCAN / ORDER_FMA: the fp32 HIP kernels' own
+    documented summation orders) are still the same inner product: within 1e-6 of the float64 twin on
+    continuous data for every row geometry, near-tie-equivalent to the strict order, bit-identical to it on
+    integer data (every order is exact there), and they pass the reference's known-answer test."""
+    emb, q = H.kat_inputs(5)
+    D, I = oracle.c_search(emb, q, 1, order=order)
+    assert I[0, 0] == 0 and D[0, 0] == 1.0
+    for d in (17, 64, 100, 200, 384, 500, 768, 1024):
+        c = H.gauss(d, 3000, d)
+        qq = H.gauss(d + 1, 3, d)
+        D, I = oracle.c_search(c, qq, 40, order=order)
+        Ds, Is = oracle.c_search(c, qq, 40)
+        _, _, S = oracle.np_search(c, qq, 40)
+        rep = oracle.compare_topk(D, I, Ds, Is, S, score_tol=1e-6)
+        assert rep["recall"] == 1.0, (d, rep)
+        got = oracle.c_scores(c, qq[0], order=order)
+        assert np.abs(got.astype(np.float64) - S[0]).max() < 1e-6
+        ci = H.int_corpus(d, 2000, d)
+        qi = H.int_corpus(d + 1, 2, d)
+        Di, Ii = oracle.c_search(ci, qi, 100, order=order)
+        Dx, Ix = oracle.c_search(ci, qi, 100)
+        assert np.array_equal(Di, Dx) and np.array_equal(Ii, Ix), d
+
+
+def test_scan_order_is_the_documented_lane_tree():
+    """ORDER_SCAN spelled out independently in numpy float32 for one geometry (d = 384 -> 96 chunks,
+    L = 32 lanes x V = 3 chunks): per-lane fused chains over chunks sub, sub + 32, sub + 64, then the
+    balanced tree - csrc/ls_scan.hip:66-77,129-145. math.fma is not available on Python 3.10, so the
+    fused multiply-add is emulated exactly in float64 (a product of two floats is exact in float64; the
+    sum of that product and a float rounds once to float64 and then to float32 - double rounding can
+    differ from a true fma only when the float64 sum lands exactly on a float32 tie, which the assert
+    below tolerates for at most a handful of rows)."""
+    assert oracle.geom_f32(384) == (32, 3) and oracle.geom_f32(1024) == (64, 4) and oracle.geom_f32(100) == (16, 2)
+    c = H.gauss(3, 500, 384)
+    q = H.gauss(4, 1, 384)[0]
+    want = oracle.c_scores(c, q, order="scan")
+    L, V = 32, 3
+    p = np.zeros((500, L), np.float32)
+    for v in range(V):
+        for j in range(4):
+            e = 4 * (np.arange(L) + L * v) + j
+            p = (c[:, e].astype(np.float64) * q[e].astype(np.float64) + p.astype(np.float64)).astype(np.float32)
+    o = 1
+    while o < L:
+        p = (p[:, 0::2] + p[:, 1::2]).astype(np.float32)
+        o *= 2
+    assert (p[:, 0] != want).sum() <= 2, (p[:, 0] != want).sum()
+
+
+def test_compare_kernel_order_rejects_the_wrong_order():
+    c = H.gauss(1, 20_000, 384)
+    q = H.gauss(2, 3, 384)
+    D, I = oracle.c_search(c, q, 50, order="scan")
+    assert oracle.compare_kernel_order(D, I, c, q, 50)["kernel_order_queries"] == {"scan": 3}
+    Ds, Is = oracle.c_search(c, q, 50)  # the strict order is NOT the kernels' order: last-bit differences
+    with pytest.raises(AssertionError):
+        oracle.compare_kernel_order(Ds, Is, c, q, 50)

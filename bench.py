@@ -55,6 +55,8 @@ WORKLOADS = {
     "c2": (200_000, 384, "f32", 1, 50),
     "c2p": (200_000, 1024, "f32", 1, 1000),
     "c2m": (1_000_000, 384, "f32", 1, 50),      # c2's shape past the 256 MiB Infinity Cache
+    "c2x8": (200_000, 384, "f32", 8, 50),       # 8 queries share one corpus pass (csrc/ls_mq.hip: what combined
+    "c2px8": (200_000, 1024, "f32", 8, 1000),   # concurrent callers produce); the reference's shape likewise
     "c3": (200_000, 384, "f16", 1024, 100),
     "c4": (12_500_000, 768, "f16", 256, 100),  # rows PER GPU
 }
@@ -394,6 +396,8 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
     # ---- verification on the very arrays AND the very code path that were timed. It runs AFTER
     # the timed region: the oracle's OpenMP / BLAS worker threads keep spinning for a while after
     # a call and were measured to double the host's launch cost of the steps that follow.
+    parity = {}
+
     def verify_fn():
         if not verify:
             step()
@@ -424,7 +428,17 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         nv = min(nq, 16)
         Dr, Ir = oracle.c_search(corpus, queries[:nv], k, f16=(dtype == "f16"))
         _, _, S = oracle.np_search(corpus, queries[:nv], k, f16=(dtype == "f16"))
-        rep = oracle.compare_topk(s[:nv].cpu().numpy(), i[:nv].cpu().numpy(), Dr, Ir, S)
+        got_s, got_i = s[:nv].cpu().numpy(), i[:nv].cpu().numpy()
+        rep = oracle.compare_topk(got_s, got_i, Dr, Ir, S)
+        parity.update({"checked_queries": nv, "max_score_err_vs_strict": rep["max_score_err"],
+                       "index_mismatches_vs_strict": rep["index_mismatches"],
+                       "near_ties_excused": rep["near_ties_excused"]})
+        if dtype == "f32" and nq <= 16 and world == 1 and not inlib:
+            # zero excuse: bit-identical (scores and indices) to the oracle run in the scan kernels' own
+            # documented fp32 summation order (oracle/flat_ip_ref.c ORDER_SCAN); raises on any difference
+            ko = oracle.compare_kernel_order(got_s, got_i, corpus, queries[:nv], k, orders=("scan",))
+            parity.update({"kernel_order": "scan", "kernel_order_mismatches": ko["kernel_order_mismatches"],
+                           "bit_identical_queries": ko["kernel_order_queries"]["scan"]})
         return rep["recall"]
 
     # untimed pre-warm: a 20-step driver run is ~1 ms of GPU time, shorter than the clock ramp.
@@ -521,11 +535,12 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         ach = ab / (scan_ms_avg * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-    roof["kernel"] = "ls_gemm_filter_kernel" if mfma_path else "ls_scan_kernel"
+    mq_path = dtype == "f32" and 2 <= nq <= 16
+    roof["kernel"] = "ls_gemm_filter_kernel" if mfma_path else ("ls_mq_kernel" if mq_path else "ls_scan_kernel")
     roof["kernel_ms"] = round(scan_ms_avg, 5)
     roof["kernel_ms_source"] = roof_src
     roof["kernel_ms_bracketed"] = round(ev_ms, 5)
-    roof["launches_timed"] = steps if (pipelined and nq == 1) else n_prof * (nq if nq <= 16 else 1)
+    roof["launches_timed"] = steps if (pipelined and nq == 1) else n_prof * (1 if mq_path else nq if nq <= 16 else 1)
     pmc = ROOT / "profiles" / f"pmc_{workload}.json"
     if pmc.exists():  # HBM bytes per launch from rocprofv3 --pmc (profiles/collect.sh)
         try:
@@ -564,7 +579,10 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
                                          round(1 + 2.0 / EXCHANGE_EVERY, 3) if sharded_pipe else
                                          (local.debug_counter(9) if mfma_path else 2 * nq)
                                          + (2 if world > 1 else 0)),
-                   "note": "each launch = scan(step i) + one workgroup finalising step i-1"
+                   "note": (f"each launch = one corpus pass for the {nq} queries on the f32 matrix cores (ls_mq_kernel, "
+                            "bit-identical to the single-query scan) + the workgroups finalising step i-1"
+                            if (pipelined and mq_path) else
+                            "each launch = scan(step i) + one workgroup finalising step i-1")
                    if (pipelined or sharded_pipe) else
                    ("batched MFMA path, pipelined: query prep, MFMA pass (+ the sample phase of the "
                     "batch two calls ahead), tau, select - on two lanes + a select stream"
@@ -578,6 +596,8 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         "repaired_queries": repaired,
         "roofline": roof,
     }
+    if parity:
+        res["parity"] = parity
     if want_cpu and rank == 0 and world == 1 and not inlib:
         cb = cpu_baseline(corpus, queries, k, dtype == "f16", budget_s=cpu_budget_s)
         if c4:  # timed on the first 200k rows; a flat scan is linear in the row count
@@ -726,7 +746,8 @@ def main():
         if args.workload == "c2":  # the default, driver-timed run carries both halves of the metric,
             # the reference's real call shape and the per-GPU shard of config 4
             # ... and (1 GPU) config 2's shape at N = 1 M rows: 1.5 GB, six times the Infinity Cache
-            sec = ["c3", "c2p", "c2m", "c4"] if env.n_gpus == 1 else ["c3", "c4"]
+            # ... and the small-batch shapes (8 queries per corpus pass on the f32 matrix cores)
+            sec = ["c3", "c2p", "c2m", "c2x8", "c2px8", "c4"] if env.n_gpus == 1 else ["c3", "c4"]
     elif args.secondary in ("none", ""):
         sec = []
     else:
@@ -736,7 +757,7 @@ def main():
         nq = WORKLOADS[w][3]
         # (c3: 1000 pipelined batches = 0.15 s: the chain's fill and drain and its per-128-calls check are amortised)
         st, wu = (1000, 50) if nq <= 16 else ((1000, 50) if w == "c3" else (30, 3))
-        secondary[w] = run_dense(env, w, st, wu, want_cpu=not args.no_cpu_baseline and w != "c2m",
+        secondary[w] = run_dense(env, w, st, wu, want_cpu=not args.no_cpu_baseline and w not in ("c2m", "c2x8", "c2px8"),
                                  verify=not args.no_verify, c4_rows=args.c4_rows, cpu_budget_s=9.0)
     if (args.secondary == "auto" and args.workload == "c2" and env.n_gpus == 1) or \
             "c5" in args.secondary.split(","):

@@ -345,9 +345,27 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
     int rc = LS_OK;
     const bool normalize = (flags & LS_FLAG_NORMALIZE) != 0;
     const int64_t keff = std::min<int64_t>(k, ix->n);
-    const int blocks = ix->opt_blocks > 0 ? std::min(ix->opt_blocks, ix->max_blocks)
-                                          : ls_scan_blocks(ix->n > 0 ? ix->n : 1, g, ix->n_cu);
-    const int kprime = pick_kprime(ix, blocks, (int)std::max<int64_t>(keff, 1));
+    const int scan_blocks = ix->opt_blocks > 0 ? std::min(ix->opt_blocks, ix->max_blocks)
+                                               : ls_scan_blocks(ix->n > 0 ? ix->n : 1, g, ix->n_cu);
+    const int scan_kprime = pick_kprime(ix, scan_blocks, (int)std::max<int64_t>(keff, 1));
+    // fp32 index, two or more queries left: up to 16 of them share one pass on the f32 matrix cores
+    // (ls_mq.hip; same bits as the scan kernel, so a query's results do not depend on its company)
+    const int mq_blocks = ix->opt_blocks > 0 ? std::min(ix->opt_blocks, ix->max_blocks)
+                                             : ls_mq_blocks(ix->n > 0 ? ix->n : 1, ix->n_cu);
+    const int mq_kprime = pick_kprime(ix, mq_blocks, (int)std::max<int64_t>(keff, 1));
+    int mq_keys = ls_mq_lane_keys(mq_blocks, (int)std::max<int64_t>(keff, 1));
+    if (mq_keys == 3 && mq_kprime + 1 > 4 * 3) mq_keys = 5;  // the workgroup ranks 4 x keys: k' + 1 of them go out
+
+    const bool mq_ok = ix->opt_mq && ix->opt_multi_query && ix->dtype == LS_DTYPE_F32 && ix->n >= LS_MQ_MIN_ROWS &&
+                       mq_keys > 0;
+    // scratch generations this call will use: a same-launch job's retry reads its generation's S and
+    // granules after the host has seen its answer, so such a call must not wrap around the LS_NSETS
+    // generations (one query per launch - debug option 6 - and 3+ queries would: ADVICE r4)
+    int64_t n_groups = 0;
+    for (int64_t left = nq; left > 0; ++n_groups) {
+        if (mq_ok && left >= 2) left -= std::min<int64_t>(left, LS_QUERIES_PER_LAUNCH_MAX);
+        else left -= !ix->opt_multi_query ? 1 : (left >= 5 ? std::min<int64_t>(left, 8) : (left >= 2 ? std::min<int64_t>(left, 4) : 1));
+    }
     // Everything is queued on the caller's stream. Queries go out in groups of 8, 4 or 1 that
     // share one pass over the corpus:
     //     launch i = { scan(group i)  +  one extra workgroup per query of group i-1: finalize }
@@ -372,8 +390,12 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
     for (int64_t q0 = 0; q0 < nq;) {
         const int64_t left = nq - q0;
         // queries per launch: 8 or 4 with the last real query repeated as padding, or 1
-        const int NQ = !ix->opt_multi_query ? 1 : (left >= 5 ? 8 : (left >= 2 ? 4 : 1));
+        const bool use_mq = mq_ok && left >= 2;
+        const int NQ = use_mq ? (int)std::min<int64_t>(left, LS_QUERIES_PER_LAUNCH_MAX)
+                              : (!ix->opt_multi_query ? 1 : (left >= 5 ? 8 : (left >= 2 ? 4 : 1)));
         const int real = (int)std::min<int64_t>(NQ, left);
+        const int blocks = use_mq ? mq_blocks : scan_blocks;
+        const int kprime = use_mq ? mq_kprime : scan_kprime;
         const bool prof = ix->profiling && ix->prof_n < LS_PROF_MAX;
         hipEvent_t* pe = nullptr;
         if (prof) {
@@ -404,6 +426,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         const int own_keys_cap = std::max(256, blocks * kprime);
         const bool same_launch =
             !pipeline && ix->n > 0 && ix->opt_same_launch != 0 && ix->done_base != nullptr &&
+            n_groups <= LS_NSETS &&
             s == ix->own_stream && keff <= 256 &&  // (k > 256 orders its result on 1024 threads: own launch)
             (int64_t)blocks * (kprime + 1) <= LS_GRAN_MAX &&
             ls_fin_lds_bytes_host(own_keys_cap, (int)std::max<int64_t>(keff, 1)) <= LS_PIGGY_LDS_MAX;
@@ -423,7 +446,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         }
         // padded query slots re-read the last real query (their results are never finalised)
         const float* qsrc = d_q + q0 * g.d;
-        if (real < NQ) {
+        if (real < NQ) {  // (never for an ls_mq launch: it takes the real count)
             rc = ls_grow(&ix->d_qpad, &ix->qpad_cap, (size_t)LS_QUERIES_PER_LAUNCH_MAX * g.d);
             if (rc != LS_OK) return rc;
             for (int i = 0; i < NQ; ++i)
@@ -444,6 +467,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         a.b_stride = ix->max_blocks;
         a.blocks = blocks;
         a.kprime = kprime;
+        a.mq_keys = mq_keys;
         ls_fin_batch& jobs = same_launch ? a.fin : ix->pending;
         if (same_launch) {
             if (!st.d_gran) {  // zeroed once: no granule of a later launch carries tag 0
@@ -481,9 +505,10 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             if (same_launch) ix->retry_jobs.push_back(p);  // kept until the host has seen the answers
         }
         if (prof) LS_HIP(hipEventRecord(pe[0], s));
-        rc = ls_launch_scan(ix->d_corpus, ix->n, g, a, s);
+        rc = use_mq ? ls_launch_mq(ix->d_corpus, ix->n, g, a, s) : ls_launch_scan(ix->d_corpus, ix->n, g, a, s);
         if (rc != LS_OK) return rc;
         ix->n_launches_total++;
+        if (use_mq) ix->n_mq_launches++;
         if (prof) {
             LS_HIP(hipEventRecord(pe[1], s));
             ix->prof_n++;
@@ -1056,7 +1081,8 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
     // in flight before the query is touched, so the read hides, and the copy command measured 1.6-2 us
     // SLOWER per call (profiles/ab/r04_hostapi_selection.txt). Debug option 15 = 1 selects the copy.
     const bool small_call = nq <= LS_SCAN_PATH_MAX_NQ;
-    const bool in_direct = small_call && !ix->opt_query_copy;
+    // (only single queries: every workgroup reads the whole query block, 448 x 16 x 4 KB over PCIe otherwise)
+    const bool in_direct = small_call && nq == 1 && !ix->opt_query_copy;
     const bool out_direct = on <= (size_t)(1 << 16);
     // Small scan-path calls: the finalize workgroup of every query writes tagged result granules
     // (k <= LS_OUT_GRAN_MAX_K) or drained rows + a completion word into pinned host memory; the host
@@ -1592,6 +1618,10 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->opt_blocks = value;
         return LS_OK;
     }
+    if (which == 16) {  // fp32 index: small batches on the f32 matrix cores, 16 queries per pass (ls_mq.hip; default on)
+        ix->opt_mq = value != 0;
+        return LS_OK;
+    }
     if (which == 6) {  // several queries per corpus pass on the scan path (default on)
         ix->opt_multi_query = value != 0;
         return LS_OK;
@@ -1653,14 +1683,14 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
             return -1;
         return (int64_t)v;
     }
-    if (ix && which >= 10 && which < 14) {  // phase stamps of the last scan launch (ls_scan.hip)
+    if (ix && which >= 10 && which < 18) {  // phase stamps of the last scan launch (ls_scan.hip: 4; ls_mq.hip: 7)
         u64 v = 0;
         if (hipMemcpy(&v, ix->sets[ix->last_set].d_cand + (size_t)ix->max_blocks * LS_KP_MAX - 8 + (which - 10),
                       sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 22) return -1;
+    if (!ix || which < 0 || which > 23) return -1;
     if (which == 16 || which == 17) {
         std::lock_guard<std::mutex> ql(ix->q_mu);
         return (int64_t)(which == 16 ? ix->n_combined_batches : ix->n_combined_requests);
@@ -1674,6 +1704,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
     if (which == 12) return (int64_t)ix->n_chunked_calls;
     if (which == 20) return (int64_t)ix->n_same_launch_retries;
     if (which == 22) return (int64_t)ix->n_forced_checks;
+    if (which == 23) return (int64_t)ix->n_mq_launches;
     if (which > 9) return 0;  // 13..15, 18, 19 and 21 are group counters
     if (hipSetDevice(ix->device) != hipSuccess) return -1;
     u32 v = 0;

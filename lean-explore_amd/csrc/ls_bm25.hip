@@ -62,10 +62,15 @@ struct ls_bm25_query {
 // the k-th score is usually shared by thousands of documents and the total order picks the ones
 // with the LOWEST row numbers: with 64-row tiles dealt to waves those all sit in a few workgroups,
 // each of which may emit only k' keys, the selection's proof fails and every query pays the rescue
-// sweep. Rows are therefore dealt in granules of 4: granule j (rows 4j .. 4j+3) belongs to
-// workgroup j mod B, so ANY run of low rows spreads evenly over all B workgroups (a lane quad reads
-// 16 contiguous bytes of doc_ptr; neighbouring quads are 4 B rows apart - an 8x over-fetch of a
-// 0.8 MB array that neighbouring workgroups share in L2).
+// sweep. Rows are therefore dealt in granules of 4 (rows 4j .. 4j+3) so that ANY run of low rows
+// spreads evenly over all B workgroups (a lane quad reads 16 contiguous bytes of doc_ptr).
+// Round 5: WHICH workgroup gets granule j is XCD-aware. Round 3/4 dealt granule j to workgroup j mod B;
+// workgroups go round-robin over the 8 XCDs (blockIdx % 8), so the 8 granules of every 128-byte line
+// of doc_ptr - and the entries runs they point at - were fetched by 8 different L2s: 19.8 MB of HBM
+// traffic per launch for 7.4 MB of data (profiles/pmc_bm25.json, round 4). Now runs of 8 consecutive
+// granules (32 rows = one doc_ptr line) go to ONE XCD (run r -> XCD r mod 8) and are dealt there to that
+// XCD's workgroups (blockIdx = xcd + 8 m) round-robin in run order: the tie-spreading is unchanged (any
+// prefix of the rows is spread over all B workgroups to within one granule), every line has one L2.
 #define LS_BM25_U 4  // documents per lane in flight
 #ifndef LS_BM25_ABL
 #define LS_BM25_ABL 0  // timing ablations (wrong results): 1 no candidate emission, 2 also no entry loads
@@ -78,7 +83,12 @@ __global__ __launch_bounds__(256) void bm25_score_kernel(
     const int kp = kprime + 1;
     const long long B = gridDim.x;
     const long long NG = (n + 3) / 4;                      // granules
-    const long long steps = (NG + 64 * B - 1) / (64 * B);  // 64 granules per workgroup and step
+    const bool xcd_aware = (B & 7) == 0;                   // (the host launches a multiple of 8 workgroups)
+    const long long Bx = xcd_aware ? B >> 3 : B;           // workgroups that share this one's granule sequence
+    const long long xcd = blockIdx.x & 7, m = xcd_aware ? blockIdx.x >> 3 : blockIdx.x;
+    // granules of one sequence: an XCD owns every 8th run of 8 granules
+    const long long NGx = xcd_aware ? ((NG + 63) / 64) * 8 : NG;
+    const long long steps = (NGx + 64 * Bx - 1) / (64 * Bx);  // 64 granules per workgroup and step
     u64 lst = 0, thr = 0;
     for (long long s0 = 0; s0 < steps; s0 += LS_BM25_U) {
         long long row[LS_BM25_U];
@@ -87,7 +97,8 @@ __global__ __launch_bounds__(256) void bm25_score_kernel(
         bool valid[LS_BM25_U];
 #pragma unroll
         for (int u = 0; u < LS_BM25_U; ++u) {
-            const long long j = blockIdx.x + B * ((s0 + u) * 64 + (threadIdx.x >> 2));
+            const long long l = m + Bx * ((s0 + u) * 64 + (threadIdx.x >> 2));  // number in the sequence
+            const long long j = xcd_aware ? ((l >> 3) * 8 + xcd) * 8 + (l & 7) : l;
             row[u] = 4 * j + (threadIdx.x & 3);
             valid[u] = (s0 + u) < steps && row[u] < n;
             a[u] = b[u] = 0;
@@ -221,6 +232,7 @@ int ls_bm25_create(ls_bm25** out, const int64_t* indptr, const int32_t* indices,
         ix->n_cu = cu;
     // one workgroup per CU: with k' <= 15 keys each the selection step sees <= 4 k candidate keys
     ix->blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_docs + 255) / 256, ix->n_cu));
+    if (ix->blocks > 8) ix->blocks &= ~7;  // a multiple of the 8 XCDs: the score kernel's XCD-aware row deal
     auto fail = [&](const char* what) {
         ls_set_error("ls_bm25_create: %s failed", what);
         ls_bm25_destroy(ix);

@@ -227,7 +227,7 @@ struct ls_out_gran {   // host view of one result granule
 #define LS_GRAN_MAX 4096                 // granules per query: blocks * (kprime + 1) above this -> own launch
 #define LS_BUF_RSRC_FLAGS 0x00020000     // gfx950 raw buffer descriptor, dword 3 (32-bit data format)
 #define LS_AUX_SC1 16                    // buffer load / store cache policy: write-through / L1 bypass
-#define LS_QUERIES_PER_LAUNCH_MAX 8
+#define LS_QUERIES_PER_LAUNCH_MAX 16  // (8 per VALU scan launch; 16 per f32 MFMA small-batch launch, ls_mq.hip)
 struct ls_fin_batch {
     ls_fin_params p[LS_QUERIES_PER_LAUNCH_MAX];
 };
@@ -263,9 +263,16 @@ struct ls_scan_args {
     void* d_gran;          // non-null: the jobs are this launch's own and the keys go out as
     long long g_stride;    //           tagged granules (ls_fin_params::gran), g_stride granules per query
     u32 tag;
+    int mq_keys;           // ls_launch_mq only: keys every lane keeps (ls_mq_lane_keys)
 };
 int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const ls_scan_args& a,
                    hipStream_t s);
+// Small batches on an fp32 index (ls_mq.hip): a.nq = 2..16 REAL queries share one corpus pass on the f32
+// matrix cores, bit-identical to ls_launch_scan's results; same outputs, same riding selection jobs.
+#define LS_MQ_MIN_ROWS 4096              // shards below this stay on the VALU scan groups
+int ls_mq_blocks(int64_t n, int32_t n_cu);
+int ls_mq_lane_keys(int blocks, int keff);   // 3, 5, or 0 = not for this (k, shard)
+int ls_launch_mq(const void* d_corpus, int64_t n, const ls_geom& g, const ls_scan_args& a, hipStream_t s);
 // LDS bytes a piggy-backed finalize may use without lowering the scan's occupancy below 2/CU
 #define LS_PIGGY_LDS_MAX (72 * 1024)
 // finalize: exact top-k from the scan's candidates (or, if they cannot be proven complete,

@@ -153,6 +153,8 @@ struct ls_index {
     float* d_qpad = nullptr; size_t qpad_cap = 0;  // padded query group (ragged last group)
     long long s_stride = 0;            // floats between the score vectors of one generation
     int32_t opt_multi_query = 1;       // several queries per corpus pass (groups of 8 / 4)
+    int32_t opt_mq = 1;                // fp32 index: 2..16 queries per pass on the f32 matrix cores (ls_mq.hip)
+    uint64_t n_mq_launches = 0;
     int32_t opt_query_copy = 0;        // synchronous host calls: 0 = the kernels read the pinned host copy over PCIe
                                        // themselves, 1 = a copy command brings the query to device memory first
     int32_t opt_same_launch = 1;       // synchronous host calls: the selection rides on its own query's scan launch

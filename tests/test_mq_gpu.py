@@ -1,0 +1,151 @@
+"""Small batches on an fp32 index (csrc/ls_mq.hip): 2..16 queries share one corpus pass on the f32 matrix
+cores. The kernel is built to reproduce the single-query scan kernel's summation order, so the bar is not a
+tolerance: scores AND indices are `array_equal` to (a) the same queries served one by one and (b) the CPU
+oracle in the documented "scan" order (oracle.compare_kernel_order), in addition to the usual 1e-5 /
+near-tie check against the strict oracle. Reference call being replaced: `index.search(x, k)`,
+src/lean_explore/search/engine.py:250 (issued concurrently by several MCP clients, mcp/server.py:147-151)."""
+
+import numpy as np
+import pytest
+
+from lean_explore_amd.index import FlatIPIndex
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def one_by_one(ix, q, k, normalize):
+    outs = [ix.search(q[j:j + 1], k, normalize=normalize) for j in range(q.shape[0])]
+    return np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs])
+
+
+# (k against the shard size decides how many keys a lane keeps - 3, 5 or 8, ls_mq_lane_keys - or whether the
+# VALU scan groups take the call: same bits either way)
+@pytest.mark.parametrize("d,k,normalize", [(384, 50, True), (1024, 1000, True), (100, 10, False), (64, 100, False),
+                                           (768, 200, True), (200, 50, False), (512, 50, True), (36, 7, False)])
+def test_mq_equals_single_queries_and_the_scan_order_oracle(d, k, normalize):
+    n = 40_000 if d <= 512 else 24_000
+    c = H.gauss(100 + d, n, d)
+    q = H.gauss(200 + d, 20, d, normalize=not normalize) * (1.0 if not normalize else 3.0)
+    ix = FlatIPIndex.from_array(c)
+    D1, I1 = one_by_one(ix, q[:16], k, normalize)
+    qn = oracle.c_normalize_l2(q) if normalize else q
+    for nq in (2, 3, 5, 8, 13, 16, 17, 20):
+        before = ix.debug_counter(23)
+        D, I = ix.search(q[:nq], k, normalize=normalize)
+        if k < 1000:  # (k = 1000 of 24 k rows may or may not fit the lanes' key lists: same bits either way)
+            assert ix.debug_counter(23) > before, "the small batch did not take the f32 MFMA kernel"
+        m = min(nq, 16)
+        assert np.array_equal(D[:m], D1[:m]) and np.array_equal(I[:m], I1[:m]), (d, k, nq)
+        rep = oracle.compare_kernel_order(D, I, c, qn[:nq], k, orders=("scan",))
+        assert rep["kernel_order_mismatches"] == 0
+        Dr, Ir = oracle.c_search(c, qn[:nq], k)
+        _, _, S = oracle.np_search(c, qn[:nq], k)
+        rep = oracle.compare_topk(D, I, Dr, Ir, S, score_tol=1e-5)
+        assert rep["recall"] == 1.0, rep
+    ix.close()
+
+
+def test_mq_full_size_config2_shapes():
+    """N = 200 k: d = 384 k = 50 (config 2's shape, 16 queries per pass) and d = 1024 k = 1000 (the
+    reference's call shape, engine.py:538): bit-identical to the scan-order oracle."""
+    for d, k in ((384, 50), (1024, 1000)):
+        c = H.gauss(1234, 200_000, d)
+        q = H.gauss(5678, 16, d)
+        ix = FlatIPIndex.from_array(c)
+        D, I = ix.search(q, k)
+        assert ix.debug_counter(23) >= 1
+        rep = oracle.compare_kernel_order(D, I, c, q, k, orders=("scan",))
+        D8, I8 = ix.search(q[:8], k)
+        assert np.array_equal(D8, D[:8]) and np.array_equal(I8, I[:8])
+        ix.debug_option(16, 0)   # the VALU scan groups of 8 / 4 / 1: same bits
+        Dv, Iv = ix.search(q, k)
+        assert np.array_equal(Dv, D) and np.array_equal(Iv, I)
+        if k <= 50:  # (at k = 1000 a lane holding 5 of a top-1000 is a 3e-3 event per query: exact either way)
+            assert ix.debug_counter(0) == 0, "random data must stay on the selection's fast path"
+        ix.close()
+        print("mq full size", d, k, rep)
+
+
+@pytest.mark.parametrize("n", [4096, 4097, 5000, 8191, 16_400, 33_333])
+def test_mq_ragged_shards_and_padding(n):
+    c = H.gauss(n, n, 384)
+    q = H.gauss(n + 1, 7, 384)
+    ix = FlatIPIndex.from_array(c, base=10_000_000_000)
+    for k in (1, 50, 300):
+        D, I = ix.search(q, k)
+        oracle.compare_kernel_order(D, I, c, q, k, base=10_000_000_000, orders=("scan",))
+    ix.close()
+
+
+def test_mq_integer_corpus_ties_and_clusters():
+    """Exact arithmetic with thousands of ties, a clustered (sorted) corpus whose best rows are adjacent
+    - the per-lane key lists overflow, the proof fails, the rescue over S must still give the exact answer -
+    and NaN / inf rows."""
+    c = H.int_corpus(7, 60_000, 128)
+    q = H.int_corpus(8, 9, 128)
+    ix = FlatIPIndex.from_array(c)
+    for k in (50, 1000):
+        D, I = ix.search(q, k)
+        Dr, Ir = oracle.c_search(c, q, k)
+        assert np.array_equal(D, Dr) and np.array_equal(I, Ir)
+    ix.close()
+    c = H.gauss(3, 60_000, 384)
+    q = H.gauss(4, 6, 384)
+    order = np.argsort(c @ q[0])
+    c = np.ascontiguousarray(c[order])
+    ix = FlatIPIndex.from_array(c)
+    D, I = ix.search(q, 200)
+    oracle.compare_kernel_order(D, I, c, q, 200, orders=("scan",))
+    assert ix.debug_counter(0) >= 1, "the sorted corpus should have forced the exact slow path"
+    ix.close()
+    c2 = H.gauss(8, 10_000, 64)
+    c2[10, 0] = np.nan
+    c2[11, 0] = -np.inf
+    c2[12, 0] = np.inf
+    ix = FlatIPIndex.from_array(c2)
+    qq = np.ones((3, 64), np.float32)
+    D, I = ix.search(qq, 100)
+    Dr, Ir = oracle.c_search(c2, qq, 100)
+    assert np.array_equal(I, Ir) and 10 not in I[0] and 11 not in I[0] and I[0, 0] == 12
+    ix.close()
+
+
+def test_mq_device_api_pipelined_and_async():
+    import torch
+
+    c = H.gauss(41, 50_000, 384)
+    q = H.gauss(42, 40, 384)
+    ix = FlatIPIndex.from_array(c)
+    tq = torch.from_numpy(q).cuda()
+    outs = []
+    sizes = [2, 16, 5, 1, 9, 7]
+    at = 0
+    for m in sizes:
+        outs.append((at, m, ix.search_device(tq[at:at + m], 50, pipeline=True)))
+        at += m
+    ix.check()
+    for at, m, (Dt, It) in outs:
+        oracle.compare_kernel_order(Dt.cpu().numpy(), It.cpu().numpy(), c, q[at:at + m], 50, orders=("scan",))
+    Dt, It = ix.search_device(tq[:12], 100, asynchronous=True)
+    ix.check()
+    oracle.compare_kernel_order(Dt.cpu().numpy(), It.cpu().numpy(), c, q[:12], 100, orders=("scan",))
+    ix.close()
+
+
+def test_one_query_per_launch_with_many_groups_keeps_its_retries_straight():
+    """with one query per launch (debug option 6 = 0) a synchronous call of 3+ queries used more
+    scratch generations than exist while same-launch retry jobs still pointed at them; a retry (k' = 1 on a
+    clustered corpus forces one) then read another query's score vector. Such calls now take the
+    selection's own launch; the answers must be those of the oracle."""
+    c = H.gauss(3, 60_000, 384)
+    q = H.gauss(4, 6, 384)
+    order = np.argsort(c @ q[0])
+    c = np.ascontiguousarray(c[order])
+    ix = FlatIPIndex.from_array(c)
+    ix.debug_option(6, 0)
+    ix.debug_option(0, 1)
+    D, I = ix.search(q, 100)
+    oracle.compare_kernel_order(D, I, c, q, 100, orders=("scan",))
+    ix.close()

@@ -1,0 +1,16 @@
+import sys; sys.path.insert(0, '/root/repo')
+import torch
+from lean_explore_amd.index import FlatIPIndex
+from tests import helpers as H
+for (n, d) in ((200_000, 384), (200_000, 768), (200_000, 1024)):
+    c = H.gauss(1234, n, d)
+    ix = FlatIPIndex.from_array(c)
+    q = torch.from_numpy(H.gauss(5678, 16, d)).cuda()
+    for blocks in (0, 256, 320, 448, 480, 512, 640, 768):
+        ix.debug_option(7, blocks)
+        for _ in range(30): ix.search_device(q, 50, pipeline=True)
+        ix.check(); ix.set_profiling(True)
+        for _ in range(200): ix.search_device(q, 50, pipeline=True)
+        ix.check(); ms, _ = ix.last_kernel_ms(); ix.set_profiling(False)
+        print(f"N={n} d={d} nq=16 blocks={blocks}: {ms*1e3:.1f} us/launch", flush=True)
+    ix.close()

@@ -206,15 +206,22 @@ void ls_destroy(ls_index* ix) {
     (void)hipSetDevice(ix->device);
     if (ix->own_stream) (void)hipStreamSynchronize(ix->own_stream);
     (void)hipFree(ix->d_corpus);
-    (void)hipFree(ix->d_qraw);
+    for (auto& h : ix->hs) {
+        (void)hipFree(h.d_qraw);
+        (void)hipFree(h.d_out_s);
+        (void)hipFree(h.d_out_i);
+        if (h.h_q) (void)hipHostFree(h.h_q);
+        if (h.h_done) (void)hipHostFree(h.h_done);
+        if (h.h_out_g) (void)hipHostFree(h.h_out_g);
+        if (h.h_out_s) (void)hipHostFree(h.h_out_s);
+        if (h.h_out_i) (void)hipHostFree(h.h_out_i);
+    }
     for (auto& st : ix->sets) {
         (void)hipFree(st.d_S);
         (void)hipFree(st.d_cand);
         (void)hipFree(st.d_bound);
         (void)hipFree(st.d_gran);
     }
-    (void)hipFree(ix->d_out_s);
-    (void)hipFree(ix->d_out_i);
     (void)hipFree(ix->d_counters);
     (void)hipFree(ix->d_qpad);
     for (hipStream_t cs : {ix->chain_main[0], ix->chain_main[1], ix->chain_sel})
@@ -233,11 +240,6 @@ void ls_destroy(ls_index* ix) {
     for (float* b : ix->d_qkeep_blk) (void)hipFree(b);
     (void)hipFree(ix->d_overflow);
     if (ix->h_overflow) (void)hipHostFree(ix->h_overflow);
-    if (ix->h_q) (void)hipHostFree(ix->h_q);
-    if (ix->h_done) (void)hipHostFree(ix->h_done);
-    if (ix->h_out_g) (void)hipHostFree(ix->h_out_g);
-    if (ix->h_out_s) (void)hipHostFree(ix->h_out_s);
-    if (ix->h_out_i) (void)hipHostFree(ix->h_out_i);
     for (hipEvent_t e : ix->prof_ev) (void)hipEventDestroy(e);
     for (hipStream_t cs : {ix->chain_main[0], ix->chain_main[1], ix->chain_sel})
         if (cs) (void)hipStreamDestroy(cs);
@@ -300,7 +302,7 @@ int ls_set_base(ls_index* ix, int64_t base) {
         ls_set_error("ls_set_base: bad argument");
         return LS_ERR_INVALID_ARG;
     }
-    std::lock_guard<std::mutex> lk(ix->mu);
+    ls_quiesce lk(ix);  // (no synchronous host call in flight, then the handle's mutex)
     if (ix->group) return ls_group_set_base(ix, base);
     ix->base = base;
     return LS_OK;
@@ -406,7 +408,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             }
             pe = &ix->prof_ev[2 * ix->prof_n];
         }
-        const int gen = (int)(ix->set_rr++ % LS_NSETS);
+        const int gen = ix->force_gen >= 0 ? ix->force_gen : (int)(ix->set_rr++ % LS_NSETS);
         ls_index::scratch_set& st = ix->sets[gen];
         if (ix->n_pending && ix->n <= 0) {  // an empty index launches no scan to ride on
             rc = ls_i_flush_pending(ix);
@@ -498,11 +500,11 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             p.counters = ix->d_counters;
             p.done = ix->done_base ? ix->done_base + (q0 + i) : nullptr;
             p.out_gran = ix->gran_out_base && k <= LS_OUT_GRAN_MAX_K ? ix->gran_out_base + (size_t)(q0 + i) * k : nullptr;
-            p.done_val = ix->done_seq;
+            p.done_val = ix->cur_done_seq;
             p.gran = same_launch ? (const char*)st.d_gran + (size_t)i * LS_GRAN_MAX * 16 : nullptr;
             p.tag = same_launch ? ix->gran_tag : 0u;
             p.wait = same_launch ? 1u : 0u;
-            if (same_launch) ix->retry_jobs.push_back(p);  // kept until the host has seen the answers
+            if (same_launch && ix->cur_retry) ix->cur_retry->push_back(p);  // kept until the host has seen the answers
         }
         if (prof) LS_HIP(hipEventRecord(pe[0], s));
         rc = use_mq ? ls_launch_mq(ix->d_corpus, ix->n, g, a, s) : ls_launch_scan(ix->d_corpus, ix->n, g, a, s);
@@ -1047,93 +1049,197 @@ int ls_i_check_search_args(const ls_index* ix, const void* q, int64_t nq, int32_
 }
 
 
-// One synchronous host search with the handle's mutex taken: what ls_search was before calls could
-// be combined (below).
-static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flags,
-                              float* out_scores, int64_t* out_indices) {
+// ---- the synchronous host search (ls_search: the reference's index.search, search/engine.py:250) -----
+// A call runs in two phases on one of the handle's two host slots (ls_host_slot, ls_index.h):
+//   begin  - under the slot's mutex AND the handle's mutex: stage the query, queue the launch(es);
+//   finish - under the slot's mutex only: poll the pinned completion words / result granules (or sleep in
+//            hipStreamSynchronize), run the rare same-launch retry, hand the results back.
+// Between the two the handle's mutex is free, so the NEXT call can queue its launch behind this one while
+// this one still waits for its answer ("overlapped": single-group scan-path calls that the host can poll;
+// everything else - batched calls, several query groups, group handles - is "exclusive": it waits for both
+// slots and keeps the handle's mutex to the end, exactly the round-4 behaviour). Two single-query callers
+// used to alternate as lone launches with the GPU idle from the end of one call's selection to the next
+// call's launch (~15 us of every 65: profiles/ab/r04_concurrent_callers_replicas.txt); overlapped, the
+// second launch is already queued when the first one's scan ends.
+static int64_t scan_group_count(const ls_index* ix, int64_t nq, int32_t k) {
+    const int64_t keff = std::min<int64_t>(k, ix->n);
+    const int mq_blocks = ix->opt_blocks > 0 ? std::min(ix->opt_blocks, ix->max_blocks)
+                                             : ls_mq_blocks(ix->n > 0 ? ix->n : 1, ix->n_cu);
+    const bool mq_ok = ix->opt_mq && ix->opt_multi_query && ix->dtype == LS_DTYPE_F32 && ix->n >= LS_MQ_MIN_ROWS &&
+                       ls_mq_lane_keys(mq_blocks, (int)std::max<int64_t>(keff, 1)) > 0;
+    int64_t groups = 0;
+    for (int64_t left = nq; left > 0; ++groups) {
+        if (mq_ok && left >= 2) left -= std::min<int64_t>(left, LS_QUERIES_PER_LAUNCH_MAX);
+        else left -= !ix->opt_multi_query ? 1 : (left >= 5 ? std::min<int64_t>(left, 8) : (left >= 2 ? std::min<int64_t>(left, 4) : 1));
+    }
+    return groups;
+}
+
+struct ls_host_call {
+    ls_index* ix = nullptr;
+    ls_host_slot* S = nullptr;
+    std::unique_lock<std::mutex> slot_lk, other_lk, mu_lk;
+    const float* q = nullptr;
+    int64_t nq = 0;
+    int32_t k = 0;
+    uint32_t flags = 0;
+    float* out_scores = nullptr;
+    int64_t* out_indices = nullptr;
+    bool group = false, spin = false, out_direct = false, queued = false;
     int rc = LS_OK;
-    std::lock_guard<std::mutex> lk(ix->mu);
-    if (ix->group)
-        return ls_group_search(ix, q, true, nq, k, flags & LS_FLAG_NORMALIZE, out_scores, out_indices,
-                               nullptr);
-    LS_HIP(hipSetDevice(ix->device));
-    hipStream_t s = ix->own_stream;
+};
+
+static int host_call_begin_impl(ls_host_call& c) {
+    ls_index* ix = c.ix;
+    const int64_t nq = c.nq;
+    const int32_t k = c.k;
+    int rc = LS_OK;
+    if (ix->group) {  // the group handle has its own host path (ls_shard.hip); nothing to overlap here
+        c.group = true;
+        c.mu_lk = std::unique_lock<std::mutex>(ix->mu);
+        return c.rc = ls_group_search(ix, c.q, true, nq, k, c.flags & LS_FLAG_NORMALIZE, c.out_scores,
+                                      c.out_indices, nullptr);
+    }
+    // a slot: the one whose turn it is, or the other one if that is free right now
+    unsigned si = ix->hs_rr.fetch_add(1, std::memory_order_relaxed) % LS_HOST_SLOTS;
+    c.slot_lk = std::unique_lock<std::mutex>(ix->hs[si].mu, std::try_to_lock);
+    if (!c.slot_lk.owns_lock()) {
+        const unsigned sj = (si + 1) % LS_HOST_SLOTS;
+        c.slot_lk = std::unique_lock<std::mutex>(ix->hs[sj].mu, std::try_to_lock);
+        if (c.slot_lk.owns_lock()) si = sj;
+        else c.slot_lk = std::unique_lock<std::mutex>(ix->hs[si].mu);
+    }
+    c.mu_lk = std::unique_lock<std::mutex>(ix->mu);
     const size_t qn = (size_t)nq * ix->g.d, on = (size_t)nq * k;
-    if ((rc = ls_grow(&ix->d_qraw, &ix->qraw_cap, qn)) != LS_OK) return rc;
-    if ((rc = ls_grow_pinned(&ix->h_q, &ix->h_q_cap, qn)) != LS_OK) return rc;
-    if (on > ix->out_cap) {
-        size_t c1 = ix->out_cap, c2 = ix->out_cap;
-        if ((rc = ls_grow(&ix->d_out_s, &c1, on)) != LS_OK) return rc;
-        if ((rc = ls_grow(&ix->d_out_i, &c2, on)) != LS_OK) return rc;
-        ix->out_cap = std::min(c1, c2);
-    }
-    if (on > ix->h_out_cap) {
-        size_t c1 = ix->h_out_cap, c2 = ix->h_out_cap;
-        if ((rc = ls_grow_pinned(&ix->h_out_s, &c1, on)) != LS_OK) return rc;
-        if ((rc = ls_grow_pinned(&ix->h_out_i, &c2, on)) != LS_OK) return rc;
-        ix->h_out_cap = std::min(c1, c2);
-    }
-    // Pinned host buffers are device-visible. Results: the selection writes the output rows into
-    // h_out_* over PCIe itself (no copy command behind the kernel). Queries: the scan workgroups read
-    // the pinned copy themselves (small calls). A stand-alone probe (tools/host_roundtrip_probe.hip)
-    // prices that read at 7.4 us for 448 idle workgroups against 2.7 us behind a copy command and
-    // 1.5 us through the kernel arguments - but in the scan kernel the first corpus tile's loads are
-    // in flight before the query is touched, so the read hides, and the copy command measured 1.6-2 us
-    // SLOWER per call (profiles/ab/r04_hostapi_selection.txt). Debug option 15 = 1 selects the copy.
     const bool small_call = nq <= LS_SCAN_PATH_MAX_NQ;
-    // (only single queries: every workgroup reads the whole query block, 448 x 16 x 4 KB over PCIe otherwise)
-    const bool in_direct = small_call && nq == 1 && !ix->opt_query_copy;
-    const bool out_direct = on <= (size_t)(1 << 16);
+    c.out_direct = on <= (size_t)(1 << 16);
     // Small scan-path calls: the finalize workgroup of every query writes tagged result granules
     // (k <= LS_OUT_GRAN_MAX_K) or drained rows + a completion word into pinned host memory; the host
     // spins on those instead of sleeping in hipStreamSynchronize (whose wake-up costs more than the
     // 47 us scan's launch). Falls back to the stream sync after 2 ms.
-    const bool spin = small_call && out_direct && !ls_i_batched_eligible(ix, nq, k) && ix->n > 0;
-    if (spin && !ix->h_done) {
-        LS_HIP(hipHostMalloc((void**)&ix->h_done, sizeof(u32) * LS_SCAN_PATH_MAX_NQ, hipHostMallocDefault));
-        memset(ix->h_done, 0, sizeof(u32) * LS_SCAN_PATH_MAX_NQ);
+    c.spin = small_call && c.out_direct && !ls_i_batched_eligible(ix, nq, k) && ix->n > 0;
+    const bool overlapped = ix->opt_overlap_calls && c.spin && scan_group_count(ix, nq, k) == 1;
+    if (!overlapped) {
+        // exclusive: no other host call in flight (lock order: both slots, then the handle)
+        c.mu_lk.unlock();
+        c.slot_lk.unlock();
+        std::lock(ix->hs[0].mu, ix->hs[1].mu);
+        c.slot_lk = std::unique_lock<std::mutex>(ix->hs[0].mu, std::adopt_lock);
+        c.other_lk = std::unique_lock<std::mutex>(ix->hs[1].mu, std::adopt_lock);
+        c.mu_lk.lock();
+        si = 0;
     }
-    memcpy(ix->h_q, q, qn * sizeof(float));
+    ls_host_slot& S = ix->hs[si];
+    c.S = &S;
+    LS_HIP(hipSetDevice(ix->device));
+    hipStream_t s = ix->own_stream;
+    if ((rc = ls_grow(&S.d_qraw, &S.qraw_cap, qn)) != LS_OK) return c.rc = rc;
+    if ((rc = ls_grow_pinned(&S.h_q, &S.h_q_cap, qn)) != LS_OK) return c.rc = rc;
+    if (on > S.out_cap) {
+        size_t c1 = S.out_cap, c2 = S.out_cap;
+        if ((rc = ls_grow(&S.d_out_s, &c1, on)) != LS_OK) return c.rc = rc;
+        if ((rc = ls_grow(&S.d_out_i, &c2, on)) != LS_OK) return c.rc = rc;
+        S.out_cap = std::min(c1, c2);
+    }
+    if (on > S.h_out_cap) {
+        size_t c1 = S.h_out_cap, c2 = S.h_out_cap;
+        if ((rc = ls_grow_pinned(&S.h_out_s, &c1, on)) != LS_OK) return c.rc = rc;
+        if ((rc = ls_grow_pinned(&S.h_out_i, &c2, on)) != LS_OK) return c.rc = rc;
+        S.h_out_cap = std::min(c1, c2);
+    }
+    // Pinned host buffers are device-visible. Results: the selection writes the output rows into
+    // h_out_* over PCIe itself (no copy command behind the kernel). Queries: the scan workgroups read
+    // the pinned copy themselves (single queries). A stand-alone probe (tools/host_roundtrip_probe.hip)
+    // prices that read at 7.4 us for 448 idle workgroups against 2.7 us behind a copy command and
+    // 1.5 us through the kernel arguments - but in the scan kernel the first corpus tile's loads are
+    // in flight before the query is touched, so the read hides, and the copy command measured 1.6-2 us
+    // SLOWER per call (profiles/ab/r04_hostapi_selection.txt). Debug option 15 = 1 selects the copy.
+    // (only single queries: every workgroup reads the whole query block - 256 x 16 x 4 KB over PCIe otherwise)
+    const bool in_direct = small_call && nq == 1 && !ix->opt_query_copy;
+    if (c.spin && !S.h_done) {
+        LS_HIP(hipHostMalloc((void**)&S.h_done, sizeof(u32) * LS_SCAN_PATH_MAX_NQ, hipHostMallocDefault));
+        memset(S.h_done, 0, sizeof(u32) * LS_SCAN_PATH_MAX_NQ);
+    }
+    memcpy(S.h_q, c.q, qn * sizeof(float));
     if (!in_direct)
-        LS_HIP(hipMemcpyAsync(ix->d_qraw, ix->h_q, qn * sizeof(float), hipMemcpyHostToDevice, s));
-    ix->retry_jobs.clear();
-    if (spin) {
-        if (on > ix->h_out_g_cap) {
-            if (ix->h_out_g) (void)hipHostFree(ix->h_out_g);
-            ix->h_out_g = nullptr;
-            ix->h_out_g_cap = 0;
+        LS_HIP(hipMemcpyAsync(S.d_qraw, S.h_q, qn * sizeof(float), hipMemcpyHostToDevice, s));
+    S.retry_jobs.clear();
+    if (c.spin) {
+        if (on > S.h_out_g_cap) {
+            if (S.h_out_g) (void)hipHostFree(S.h_out_g);
+            S.h_out_g = nullptr;
+            S.h_out_g_cap = 0;
             const size_t cap = std::max<size_t>(on, 4096);
-            LS_HIP(hipHostMalloc((void**)&ix->h_out_g, cap * sizeof(ls_out_gran), hipHostMallocDefault));
-            memset(ix->h_out_g, 0, cap * sizeof(ls_out_gran));
-            ix->h_out_g_cap = cap;
+            LS_HIP(hipHostMalloc((void**)&S.h_out_g, cap * sizeof(ls_out_gran), hipHostMallocDefault));
+            memset(S.h_out_g, 0, cap * sizeof(ls_out_gran));
+            S.h_out_g_cap = cap;
         }
-        if (++ix->done_seq >= LS_DONE_RETRY) ix->done_seq = 1;  // the top bit is the retry answer
-        ix->done_base = ix->h_done;
-        ix->gran_out_base = ix->h_out_g;
+        if (++S.done_seq >= LS_DONE_RETRY) S.done_seq = 1;  // the top bit is the retry answer
+        ix->done_base = S.h_done;
+        ix->gran_out_base = S.h_out_g;
     }
-    rc = ls_i_search_on_stream(ix, in_direct ? ix->h_q : ix->d_qraw, nq, k, flags & LS_FLAG_NORMALIZE,
-                          out_direct ? ix->h_out_s : ix->d_out_s,
-                          out_direct ? ix->h_out_i : ix->d_out_i, s, true);
+    ix->cur_retry = &S.retry_jobs;
+    ix->cur_done_seq = S.done_seq;
+    ix->force_gen = overlapped ? (int)si : -1;
+    rc = ls_i_search_on_stream(ix, in_direct ? S.h_q : S.d_qraw, nq, k, c.flags & LS_FLAG_NORMALIZE,
+                               c.out_direct ? S.h_out_s : S.d_out_s, c.out_direct ? S.h_out_i : S.d_out_i, s, true);
     ix->done_base = nullptr;
     ix->gran_out_base = nullptr;
-    if (rc != LS_OK) return rc;
-    if (!out_direct) {
-        LS_HIP(hipMemcpyAsync(ix->h_out_s, ix->d_out_s, on * sizeof(float), hipMemcpyDeviceToHost, s));
-        LS_HIP(hipMemcpyAsync(ix->h_out_i, ix->d_out_i, on * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    ix->cur_retry = nullptr;
+    ix->force_gen = -1;
+    if (rc != LS_OK) return c.rc = rc;
+    if (!c.out_direct) {
+        LS_HIP(hipMemcpyAsync(S.h_out_s, S.d_out_s, on * sizeof(float), hipMemcpyDeviceToHost, s));
+        LS_HIP(hipMemcpyAsync(S.h_out_i, S.d_out_i, on * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     }
+    c.queued = true;
+    if (overlapped) {
+        if (ix->hs[(si + 1) % LS_HOST_SLOTS].mu.try_lock()) ix->hs[(si + 1) % LS_HOST_SLOTS].mu.unlock();
+        else ix->n_overlapped_calls++;  // (the other slot's call is still in flight)
+        c.mu_lk.unlock();  // the next call may queue its launch now
+    }
+    return LS_OK;
+}
+
+static int host_call_begin(ls_host_call& c) {
+    const int rc = host_call_begin_impl(c);  // (LS_HIP returns straight out of it)
+    if (rc != LS_OK) {
+        c.rc = rc;
+        if (c.ix && !c.ix->group) {
+            c.ix->done_base = nullptr;
+            c.ix->gran_out_base = nullptr;
+            c.ix->cur_retry = nullptr;
+            c.ix->force_gen = -1;
+        }
+    }
+    return rc;
+}
+
+static int host_call_finish(ls_host_call& c) {
+    if (c.group || c.rc != LS_OK || !c.queued) return c.rc;
+    ls_index* ix = c.ix;
+    ls_host_slot& S = *c.S;
+    const int64_t nq = c.nq;
+    const int32_t k = c.k;
+    const size_t on = (size_t)nq * k;
+    hipStream_t s = ix->own_stream;
+    float* out_scores = c.out_scores;
+    int64_t* out_indices = c.out_indices;
+    const int64_t base = ix->base;  // (ls_set_base waits for the calls in flight)
+    int rc = LS_OK;
     // spin until every query is final: all k of its result granules carry the call's sequence number
     // in both halves (ls_fin_params::out_gran), or - if accepted - its completion word holds the retry
     // answer; gives up after 2 ms and lets the caller sleep in hipStreamSynchronize
     auto wait_words = [&](bool accept_retry, bool* retry) -> bool {
         const auto t0 = std::chrono::steady_clock::now();
-        const u32 seq = ix->done_seq;
+        const u32 seq = S.done_seq;
         int64_t i = 0;   // queries below i are final (granules never change back)
         int32_t j = 0;   // granules below j of query i carry the tag
         bool any_retry = false;
         const bool granules = k <= LS_OUT_GRAN_MAX_K;
         for (unsigned it = 0;; ++it) {
             for (; i < nq; ++i, j = 0) {
-                const u32 w = __atomic_load_n(&ix->h_done[i], __ATOMIC_ACQUIRE);
+                const u32 w = __atomic_load_n(&S.h_done[i], __ATOMIC_ACQUIRE);
                 if (accept_retry && w == (seq | LS_DONE_RETRY)) {
                     any_retry = true;
                     continue;
@@ -1144,7 +1250,7 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
                 }
                 // (decoded as they are recognised: at k = 1000 a second pass over 16 KB of granules would
                 // cost the host more than the drain + completion word it replaces cost the GPU)
-                const ls_out_gran* g = ix->h_out_g + (size_t)i * k;
+                const ls_out_gran* g = S.h_out_g + (size_t)i * k;
                 float* os = out_scores + (size_t)i * k;
                 int64_t* oi = out_indices + (size_t)i * k;
                 for (; j < k; ++j) {
@@ -1152,7 +1258,7 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
                         __atomic_load_n(&g[j].tag_hi, __ATOMIC_ACQUIRE) != seq)
                         break;
                     os[j] = g[j].score;
-                    oi[j] = g[j].row == 0xffffffffu ? (int64_t)-1 : ix->base + (int64_t)g[j].row;
+                    oi[j] = g[j].row == 0xffffffffu ? (int64_t)-1 : base + (int64_t)g[j].row;
                 }
                 if (j < k) break;
             }
@@ -1167,7 +1273,7 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
         }
     };
     bool done = false;
-    if (spin) {
+    if (c.spin) {
         bool retry = false;
         done = wait_words(true, &retry);
         if (!done) {  // slow launch: sleep until the stream has drained, then every word is final
@@ -1178,6 +1284,11 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
             // Same-launch selection jobs that could not prove their emitted keys complete (clustered
             // rows, ties) or gave up waiting: the stand-alone finalize behind the scan - the kernel
             // boundary makes the score vector visible - answering through the same completion words.
+            // (Queued under the handle's mutex: another call may be queueing its launch right now. This
+            // call still owns its slot, i.e. its scratch generation: the retry's inputs are intact.)
+            std::unique_lock<std::mutex> relock;
+            if (!c.mu_lk.owns_lock()) relock = std::unique_lock<std::mutex>(ix->mu);
+            LS_HIP(hipSetDevice(ix->device));
             ls_fin_batch jobs{};
             int nj = 0;
             auto flush = [&]() -> int {
@@ -1187,9 +1298,9 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
                 nj = 0;
                 return r;
             };
-            for (const ls_fin_params& p : ix->retry_jobs) {
-                const int64_t qi = p.done - ix->h_done;
-                if (qi < 0 || qi >= nq || ix->h_done[qi] != (ix->done_seq | LS_DONE_RETRY)) continue;
+            for (const ls_fin_params& p : S.retry_jobs) {
+                const int64_t qi = p.done - S.h_done;
+                if (qi < 0 || qi >= nq || S.h_done[qi] != (S.done_seq | LS_DONE_RETRY)) continue;
                 jobs.p[nj] = p;
                 jobs.p[nj].wait = 0;  // behind the kernel boundary every granule is there
                 jobs.p[nj].keys_cap = LS_FINAL_CAP;
@@ -1197,36 +1308,48 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
             }
             if ((rc = flush()) != LS_OK) return rc;
             ix->n_same_launch_retries++;
+            if (relock.owns_lock()) relock.unlock();
             done = wait_words(false, nullptr);
         }
     }
-    ix->retry_jobs.clear();
+    S.retry_jobs.clear();
     if (!done) LS_HIP(hipStreamSynchronize(s));
-    if (spin && k <= LS_OUT_GRAN_MAX_K) {
+    if (c.spin && k <= LS_OUT_GRAN_MAX_K) {
         if (done) return LS_OK;  // (unpacked while waiting)
         std::atomic_thread_fence(std::memory_order_acquire);  // behind the drained stream
         for (size_t e = 0; e < on; ++e) {
-            const ls_out_gran& g = ix->h_out_g[e];
+            const ls_out_gran& g = S.h_out_g[e];
             out_scores[e] = g.score;
-            out_indices[e] = g.row == 0xffffffffu ? (int64_t)-1 : ix->base + (int64_t)g.row;
+            out_indices[e] = g.row == 0xffffffffu ? (int64_t)-1 : base + (int64_t)g.row;
         }
         return LS_OK;
     }
-    memcpy(out_scores, ix->h_out_s, on * sizeof(float));
-    memcpy(out_indices, ix->h_out_i, on * sizeof(int64_t));
+    memcpy(out_scores, S.h_out_s, on * sizeof(float));
+    memcpy(out_indices, S.h_out_i, on * sizeof(int64_t));
     return LS_OK;
+}
+
+// One synchronous host search, begin + finish (callers that do not go through the combining queue)
+static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flags,
+                              float* out_scores, int64_t* out_indices) {
+    ls_host_call c;
+    c.ix = ix; c.q = q; c.nq = nq; c.k = k; c.flags = flags; c.out_scores = out_scores; c.out_indices = out_indices;
+    host_call_begin(c);
+    return host_call_finish(c);
 }
 
 // ---- combining concurrent callers ---------------------------------------------------------------
 // The reference's event loop makes one blocking index.search per query (search/engine.py:250), but
-// an MCP server with several clients, or a threaded caller, has several of them in flight. The
-// scan path serves up to 8 queries per corpus pass (8 queries: 135 us; 8 passes of one: 8 x 72 us),
-// so requests that arrive while a search is running are not queued behind the mutex one by one:
-// they wait in a queue, and whoever holds the leadership serves ALL compatible waiters (same k, same
+// an MCP server with several clients, or a threaded caller, has several of them in flight. The scan
+// path serves up to 16 queries per corpus pass (fp32: ls_mq.hip, ~60 us for 16 at N = 200 k; one query
+// alone: 47 us), so requests that arrive while a search is running are not queued behind the mutex one by
+// one: they wait in a queue, and whoever holds the leadership serves ALL compatible waiters (same k, same
 // flags, <= LS_SCAN_PATH_MAX_NQ queries in total) as ONE batch, then hands their results back. A lone
 // caller becomes leader at once and pays nothing; waiters sleep on a condition variable (no
-// spinning on the mutex). Results are those of the separate calls: every query's arithmetic is
-// the same whatever group it rides in.
+// spinning on the mutex). Round 5: the leadership is released as soon as the batch's launch is QUEUED
+// (host_call_begin), so the next leader queues the requests that arrived meanwhile behind it while the
+// first one polls for its answers. Results are those of the separate calls: every query's arithmetic
+// is the same whatever group it rides in.
 struct ls_req {
     const float* q;
     int64_t nq;
@@ -1235,43 +1358,69 @@ struct ls_req {
     float* out_s;
     int64_t* out_i;
     int rc = LS_OK;
-    bool done = false;
+    bool done = false, taken = false;  // taken: popped into a batch some leader is serving
     char err[256] = "";
 };
 
-static void serve_requests(ls_index* ix, std::vector<ls_req*>& batch) {
+struct ls_served {  // one batch between its begin and its finish
+    ls_host_call call;
+    std::vector<ls_req*> batch;
+    bool combined = false;
+};
+
+static void serve_begin(ls_index* ix, ls_served& sv) {
+    std::vector<ls_req*>& batch = sv.batch;
+    ls_host_call& c = sv.call;
+    c.ix = ix;
+    c.k = batch[0]->k;
+    c.flags = batch[0]->flags;
     if (batch.size() == 1) {
         ls_req* r = batch[0];
-        r->rc = host_search_locked(ix, r->q, r->nq, r->k, r->flags, r->out_s, r->out_i);
-        if (r->rc != LS_OK) snprintf(r->err, sizeof(r->err), "%s", g_err);
+        c.q = r->q; c.nq = r->nq; c.out_scores = r->out_s; c.out_indices = r->out_i;
+        host_call_begin(c);
         return;
     }
-    const int32_t d = ix->g.d, k = batch[0]->k;
+    sv.combined = true;
     int64_t total = 0;
     for (ls_req* r : batch) total += r->nq;
-    ix->comb_q.resize((size_t)total * d);
-    ix->comb_s.resize((size_t)total * k);
-    ix->comb_i.resize((size_t)total * k);
+    c.nq = total;
+    // (the staging lives in the call's slot, which is only known inside begin: stage in a temporary
+    // vector of the batch first - a few KB)
+    static thread_local std::vector<float> tq;
+    const int32_t d = ix->g.d;
+    tq.resize((size_t)total * d);
     int64_t at = 0;
     for (ls_req* r : batch) {
-        memcpy(ix->comb_q.data() + at * d, r->q, (size_t)r->nq * d * sizeof(float));
+        memcpy(tq.data() + at * d, r->q, (size_t)r->nq * d * sizeof(float));
         at += r->nq;
     }
-    const int rc = host_search_locked(ix, ix->comb_q.data(), total, k, batch[0]->flags,
-                                      ix->comb_s.data(), ix->comb_i.data());
-    at = 0;
-    for (ls_req* r : batch) {
+    static thread_local std::vector<float> ts;
+    static thread_local std::vector<int64_t> ti;
+    ts.resize((size_t)total * c.k);
+    ti.resize((size_t)total * c.k);
+    c.q = tq.data(); c.out_scores = ts.data(); c.out_indices = ti.data();
+    host_call_begin(c);  // (copies the queries into the slot's pinned buffer before it returns)
+}
+
+static void serve_finish(ls_index* ix, ls_served& sv) {
+    ls_host_call& c = sv.call;
+    const int rc = host_call_finish(c);
+    const int32_t k = c.k;
+    int64_t at = 0;
+    for (ls_req* r : sv.batch) {
         r->rc = rc;
-        if (rc == LS_OK) {
-            memcpy(r->out_s, ix->comb_s.data() + at * k, (size_t)r->nq * k * sizeof(float));
-            memcpy(r->out_i, ix->comb_i.data() + at * k, (size_t)r->nq * k * sizeof(int64_t));
-        } else {
-            snprintf(r->err, sizeof(r->err), "%s", g_err);
+        if (rc != LS_OK) snprintf(r->err, sizeof(r->err), "%s", g_err);
+        else if (sv.combined) {
+            memcpy(r->out_s, c.out_scores + at * k, (size_t)r->nq * k * sizeof(float));
+            memcpy(r->out_i, c.out_indices + at * k, (size_t)r->nq * k * sizeof(int64_t));
         }
         at += r->nq;
     }
-    ix->n_combined_batches++;
-    ix->n_combined_requests += batch.size();
+    if (sv.combined) {
+        std::lock_guard<std::mutex> ql(ix->q_mu);
+        ix->n_combined_batches++;
+        ix->n_combined_requests += sv.batch.size();
+    }
 }
 
 extern "C" {
@@ -1289,32 +1438,49 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
     ls_req me{q, nq, k, flags, out_scores, out_indices};
     std::unique_lock<std::mutex> lk(ix->q_mu);
     ix->req_q.push_back(&me);
-    std::vector<ls_req*> batch;
     while (!me.done) {
-        if (ix->leader_active) {
+        if (ix->leader_active || me.taken) {  // (taken: my request is in a batch someone is serving)
             ix->q_cv.wait(lk);
             continue;
         }
-        ix->leader_active = true;  // serve the queue until this thread's own request is done
-        while (!me.done && !ix->req_q.empty()) {
-            batch.clear();
-            ls_req* head = ix->req_q.front();
-            int64_t total = 0;
-            while (!ix->req_q.empty()) {
-                ls_req* r = ix->req_q.front();
-                if (r->k != head->k || r->flags != head->flags || total + r->nq > LS_SCAN_PATH_MAX_NQ) break;
-                batch.push_back(r);
-                total += r->nq;
-                ix->req_q.pop_front();
-            }
-            lk.unlock();
-            serve_requests(ix, batch);
-            lk.lock();
-            for (ls_req* r : batch) r->done = true;
-            ix->q_cv.notify_all();
+        // lead ONE batch: queue its launch, pass the leadership on, then wait for its results
+        ix->leader_active = true;
+        // A call is still in flight. Two callers taking turns (one request in flight, one waiting): queue
+        // the waiting one's launch NOW, behind the running one - the GPU then goes from scan to scan instead
+        // of idling from one call's last result to the next call's launch (2 callers: 15.5 k -> 18 k
+        // queries/s, p50 130 -> 110 us). More callers than that: every pass costs the same 50-60 us however
+        // many queries ride in it, so the batch is formed when the call in flight has handed its results
+        // back and takes along everything that arrived meanwhile (queued at once behind the running call, a
+        // batch held 1-2 requests and 8 callers fell from 51 k to 35 k queries/s; forming it "as late as
+        // keeps the launches back to back" from a running estimate of the call time: 43 k).
+        while (ix->calls_in_flight > 0 &&
+               !(ix->opt_overlap_calls && ix->requests_in_flight + (int64_t)ix->req_q.size() <= 2))
+            ix->q_cv.wait(lk);
+        ls_served sv;
+        ls_req* head = ix->req_q.front();
+        int64_t total = 0;
+        while (!ix->req_q.empty()) {
+            ls_req* r = ix->req_q.front();
+            if (r->k != head->k || r->flags != head->flags || total + r->nq > LS_SCAN_PATH_MAX_NQ) break;
+            sv.batch.push_back(r);
+            r->taken = true;
+            total += r->nq;
+            ix->req_q.pop_front();
         }
+        lk.unlock();
+        serve_begin(ix, sv);
+        lk.lock();
+        ix->calls_in_flight++;
+        ix->requests_in_flight += (int64_t)sv.batch.size();
         ix->leader_active = false;
-        ix->q_cv.notify_all();  // a waiter whose request is still queued takes over
+        ix->q_cv.notify_all();  // a waiter whose request is still queued leads the next batch
+        lk.unlock();
+        serve_finish(ix, sv);
+        lk.lock();
+        ix->calls_in_flight--;
+        ix->requests_in_flight -= (int64_t)sv.batch.size();
+        for (ls_req* r : sv.batch) r->done = true;
+        ix->q_cv.notify_all();
     }
     if (me.rc != LS_OK && me.err[0]) ls_set_error("%s", me.err);
     return me.rc;
@@ -1325,7 +1491,7 @@ int ls_search_device(ls_index* ix, const void* d_q, int64_t nq, int32_t k, uint3
     int rc = ls_i_check_search_args(ix, d_q, nq, k, flags, d_out_scores, d_out_indices);
     if (rc != LS_OK) return rc;
     if (nq == 0) return LS_OK;
-    std::lock_guard<std::mutex> lk(ix->mu);
+    ls_quiesce lk(ix);  // (no synchronous host call in flight, then the handle's mutex)
     if (ix->group)
         return ls_group_search(ix, (const float*)d_q, false, nq, k, flags, (float*)d_out_scores,
                                (int64_t*)d_out_indices, (hipStream_t)stream);
@@ -1343,7 +1509,7 @@ int ls_check(ls_index* ix, void* stream) {
         ls_set_error("ls_check: index is null");
         return LS_ERR_INVALID_ARG;
     }
-    std::lock_guard<std::mutex> lk(ix->mu);
+    ls_quiesce lk(ix);  // (no synchronous host call in flight, then the handle's mutex)
     if (ix->group) return ls_group_check(ix, (hipStream_t)stream);
     LS_HIP(hipSetDevice(ix->device));
     int rc = ls_i_flush_pending(ix);
@@ -1362,7 +1528,7 @@ int ls_add(ls_index* ix, const float* rows, int64_t n_add) {
         return LS_ERR_INVALID_ARG;
     }
     if (n_add == 0) return LS_OK;
-    std::lock_guard<std::mutex> lk(ix->mu);
+    ls_quiesce lk(ix);  // (no synchronous host call in flight, then the handle's mutex)
     if (ix->group) return ls_group_add(ix, rows, n_add);
     if (ix->n + n_add >= 0xffffffffll) {
         ls_set_error("ls_add: %lld rows exceed the 2^32-1 rows one shard can index",
@@ -1396,7 +1562,7 @@ int ls_reconstruct(ls_index* ix, int64_t row0, int64_t count, float* out) {
         return LS_ERR_INVALID_ARG;
     }
     if (count == 0) return LS_OK;
-    std::lock_guard<std::mutex> lk(ix->mu);
+    ls_quiesce lk(ix);  // (no synchronous host call in flight, then the handle's mutex)
     if (ix->group) return ls_group_reconstruct(ix, row0, count, out);
     LS_HIP(hipSetDevice(ix->device));
     const ls_geom& g = ix->g;
@@ -1482,7 +1648,7 @@ int ls_export_flags(ls_index* ix, void* d_dst, int64_t nq, void* stream) {
         return LS_ERR_INVALID_ARG;
     }
     if (nq == 0) return LS_OK;
-    std::lock_guard<std::mutex> lk(ix->mu);
+    ls_quiesce lk(ix);  // (no synchronous host call in flight, then the handle's mutex)
     if (ix->group) {
         ls_set_error("ls_export_flags: not available on a sharded handle (its shards' flags travel "
                      "with the exchange; ls_check repairs and re-merges)");
@@ -1592,7 +1758,7 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->opt_combine = value != 0;
         return LS_OK;
     }
-    std::lock_guard<std::mutex> lk(ix->mu);
+    ls_quiesce lk(ix);  // (no synchronous host call in flight, then the handle's mutex)
     if (ix->group) return ls_group_debug_option(ix, which, value);
     if (which == 0) {  // force k' (0 = automatic)
         ix->opt_kprime = value;
@@ -1616,6 +1782,10 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
     }
     if (which == 7) {  // force the number of scan workgroups per launch (0 = automatic)
         ix->opt_blocks = value;
+        return LS_OK;
+    }
+    if (which == 17) {  // synchronous host calls overlap two deep (default on)
+        ix->opt_overlap_calls = value != 0;
         return LS_OK;
     }
     if (which == 16) {  // fp32 index: small batches on the f32 matrix cores, 16 queries per pass (ls_mq.hip; default on)
@@ -1652,7 +1822,7 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
 
 int ls_debug_read_scores(ls_index* ix, float* out, int64_t count) {
     if (!ix || !out || count < 0 || count > ix->n || ix->group) return LS_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(ix->mu);
+    ls_quiesce lk(ix);  // (no synchronous host call in flight, then the handle's mutex)
     LS_HIP(hipSetDevice(ix->device));
     LS_HIP(hipDeviceSynchronize());
     LS_HIP(hipMemcpy(out, ix->sets[ix->last_set].d_S, sizeof(float) * (size_t)count,
@@ -1690,7 +1860,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 23) return -1;
+    if (!ix || which < 0 || which > 24) return -1;
     if (which == 16 || which == 17) {
         std::lock_guard<std::mutex> ql(ix->q_mu);
         return (int64_t)(which == 16 ? ix->n_combined_batches : ix->n_combined_requests);
@@ -1705,6 +1875,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
     if (which == 20) return (int64_t)ix->n_same_launch_retries;
     if (which == 22) return (int64_t)ix->n_forced_checks;
     if (which == 23) return (int64_t)ix->n_mq_launches;
+    if (which == 24) return (int64_t)ix->n_overlapped_calls;
     if (which > 9) return 0;  // 13..15, 18, 19 and 21 are group counters
     if (hipSetDevice(ix->device) != hipSuccess) return -1;
     u32 v = 0;

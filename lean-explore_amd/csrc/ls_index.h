@@ -3,6 +3,7 @@
 #pragma once
 #include "ls_common.h"
 
+#include <chrono>
 #include <condition_variable>
 #include <cstddef>
 #include <deque>
@@ -29,6 +30,25 @@ struct ls_req;          // ls_api.hip: one queued synchronous host search
 #define LS_BC_SETS (1 + LS_BC_LANES)  // batched scratch sets: 0 = caller's stream, then the lanes
 #define LS_PROF_MAX 4096
 
+// Buffers of ONE synchronous host search (ls_search) in flight. Two slots: while the call that owns slot
+// A still polls for its results, the next caller may already queue its launch with slot B (round 5:
+// two callers used to ping-pong as two single launches with the GPU idle in between). Slot c also owns
+// scan scratch generation c: a same-launch selection's retry reads its generation's score vector and
+// granules after the host has seen its answer, so nothing else may touch that generation meanwhile.
+// Lock order: slot mutex(es) first, then ls_index::mu.
+struct ls_host_slot {
+    std::mutex mu;  // held from the enqueue until the results have been handed back
+    float* h_q = nullptr;      size_t h_q_cap = 0;      // pinned query copy (the kernels may read it directly)
+    float* d_qraw = nullptr;   size_t qraw_cap = 0;     // device query copy (floats)
+    float* d_out_s = nullptr;  int64_t* d_out_i = nullptr;  size_t out_cap = 0;  // nq*k (large results)
+    float* h_out_s = nullptr;  int64_t* h_out_i = nullptr;  size_t h_out_cap = 0;  // pinned
+    u32* h_done = nullptr;     // pinned [LS_SCAN_PATH_MAX_NQ]: completion words
+    u32 done_seq = 0;
+    ls_out_gran* h_out_g = nullptr;  size_t h_out_g_cap = 0;  // pinned: result granules of a spinning call
+    std::vector<ls_fin_params> retry_jobs;  // the call's same-launch jobs (LS_DONE_RETRY)
+};
+#define LS_HOST_SLOTS 2
+
 struct ls_index {
     int32_t device = 0;
     int32_t n_cu = 256;
@@ -45,8 +65,8 @@ struct ls_index {
     std::condition_variable q_cv;
     std::deque<ls_req*> req_q;
     bool leader_active = false;
-    std::vector<float> comb_q, comb_s;   // the leader's staging of a combined batch
-    std::vector<int64_t> comb_i;
+    int32_t calls_in_flight = 0;       // batches queued whose results have not been handed back yet (under q_mu)
+    int64_t requests_in_flight = 0;    // ... and the requests in them
     int32_t opt_combine = 1;
     uint64_t n_combined_batches = 0, n_combined_requests = 0;
     // non-null: this handle is a row-sharded GROUP (ls_create_sharded): `n`, `dtype`, `g` and
@@ -55,7 +75,6 @@ struct ls_index {
     ls_shard_group* group = nullptr;
 
     // scratch (grown on demand, reused by every search on this handle)
-    float* d_qraw = nullptr;   size_t qraw_cap = 0;   // floats
     // per-query scan scratch, LS_NSETS generations: launch i's piggy-backed finalize of group i-1
     // reads one generation while its scan of group i fills the other
     struct scratch_set {
@@ -158,20 +177,20 @@ struct ls_index {
     int32_t opt_query_copy = 0;        // synchronous host calls: 0 = the kernels read the pinned host copy over PCIe
                                        // themselves, 1 = a copy command brings the query to device memory first
     int32_t opt_same_launch = 1;       // synchronous host calls: the selection rides on its own query's scan launch
-    std::vector<ls_fin_params> retry_jobs;  // the same-launch jobs of the host call in flight (LS_DONE_RETRY)
     uint64_t n_forced_checks = 0;           // checks of pending batched calls the library ran on its own
     uint64_t n_same_launch_retries = 0;     // host calls that had to launch the stand-alone finalize
     u32 gran_tag = 0;                  // tag of the last same-launch selection (ls_fin_params::tag; never 0)
     int32_t max_blocks = 0;
-    float* d_out_s = nullptr;  int64_t* d_out_i = nullptr;  size_t out_cap = 0;  // nq*k
     u32* d_counters = nullptr;                        // [0] finalize slow-path count
-    u32* h_done = nullptr;     // pinned [LS_SCAN_PATH_MAX_NQ]: completion words of the host API
-    u32 done_seq = 0;
+    ls_host_slot hs[LS_HOST_SLOTS];
+    std::atomic<unsigned> hs_rr{0};
+    int32_t opt_overlap_calls = 1;     // synchronous host calls may overlap two deep (debug option 17)
+    uint64_t n_overlapped_calls = 0;   // host calls that were queued while another one was still in flight
+    int32_t force_gen = -1;            // >= 0: the scan scratch generation the call being queued must use
+    std::vector<ls_fin_params>* cur_retry = nullptr;  // where the call being queued keeps its same-launch jobs
+    u32 cur_done_seq = 0;              // ... and the sequence number its completion words / granules carry
     u32* done_base = nullptr;  // set by ls_search around its scan-path call, else null
-    ls_out_gran* h_out_g = nullptr;  size_t h_out_g_cap = 0;  // pinned: result granules of a spinning host call
     ls_out_gran* gran_out_base = nullptr;                      // set together with done_base
-    float* h_q = nullptr;      size_t h_q_cap = 0;    // pinned
-    float* h_out_s = nullptr;  int64_t* h_out_i = nullptr;  size_t h_out_cap = 0;
 
     // options / instrumentation
     int32_t opt_kprime = 0;  // 0 = automatic
@@ -187,6 +206,18 @@ struct ls_index {
     size_t prof_n = 0;
 };
 
+
+// Every synchronous host call in flight has handed its results back (both host slots), then the handle's
+// mutex: what every entry point that touches the scan scratch, the corpus or the base takes.
+struct ls_quiesce {
+    std::unique_lock<std::mutex> a, b, m;
+    explicit ls_quiesce(ls_index* ix) {
+        std::lock(ix->hs[0].mu, ix->hs[1].mu);
+        a = std::unique_lock<std::mutex>(ix->hs[0].mu, std::adopt_lock);
+        b = std::unique_lock<std::mutex>(ix->hs[1].mu, std::adopt_lock);
+        m = std::unique_lock<std::mutex>(ix->mu);
+    }
+};
 
 template <typename T>
 static inline int ls_grow(T** p, size_t* cap, size_t need) {

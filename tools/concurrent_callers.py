@@ -26,10 +26,12 @@ for n in (200_000, 25_000):
     for _ in range(50): ix.search(q[:1], 50, normalize=True)
     for T in (1, 2, 4, 8, 16):
         row = []
-        for comb in (1, 0):
+        for comb, ov in ((1, 1), (1, 0), (0, 1)):
             ix.debug_option(10, comb)
+            ix.debug_option(17, ov)  # synchronous calls may overlap two deep (round 5)
             qps, p50 = run(ix, q, 50, T)
-            row.append(f"{'combined' if comb else 'serialised'} {qps:8.0f} q/s p50 {p50:6.1f} us")
+            row.append(f"{'combined' if comb else 'serialised'}{'' if ov else ' (no overlap)'} {qps:8.0f} q/s p50 {p50:6.1f} us")
+        ix.debug_option(17, 1)
         print(f"N={n} d=384 f32 k=50, {T:2d} callers: " + " | ".join(row), flush=True)
     print("   combined batches", ix.debug_counter(16), "requests in them", ix.debug_counter(17), flush=True)
     ix.close()

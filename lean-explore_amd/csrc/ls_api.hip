@@ -304,6 +304,10 @@ int ls_set_base(ls_index* ix, int64_t base) {
     }
     ls_quiesce lk(ix);  // (no synchronous host call in flight, then the handle's mutex)
     if (ix->group) return ls_group_set_base(ix, base);
+    // held-back pipelined batches launch their select - which adds the base - at the next flush: the
+    // batches already submitted must be numbered with the base they were submitted under
+    LS_HIP(hipSetDevice(ix->device));
+    if (int rc = ls_i_flush_deferred(ix)) return rc;
     ix->base = base;
     return LS_OK;
 }
@@ -876,8 +880,18 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
         return rc;
     const int slot = (int)ix->bc_pending.size();
     float*& qblk = ix->d_qkeep_blk[slot / LS_BC_QKEEP_BLOCK];
-    if (!qblk)
-        LS_HIP(hipMalloc((void**)&qblk, sizeof(float) * (size_t)ix->bc_qkeep_stride * LS_BC_QKEEP_BLOCK));
+    if (!qblk) {
+        // a block of LS_BC_QKEEP_BLOCK slots is 4 GB for nq = 16384, d = 1024: if it does not
+        // fit, the backlog is checked (every slot freed) and the call retried by the caller
+        if (hipMalloc((void**)&qblk, sizeof(float) * (size_t)ix->bc_qkeep_stride * LS_BC_QKEEP_BLOCK) != hipSuccess) {
+            (void)hipGetLastError();
+            qblk = nullptr;
+            ls_set_error("batched call: out of device memory for the repair copies of %d queued batches "
+                         "(%zu bytes per batch): check the pending calls (ls_check) and retry",
+                         LS_BC_QKEEP_BLOCK, sizeof(float) * (size_t)ix->bc_qkeep_stride);
+            return LS_ERR_HIP;
+        }
+    }
     u32* d_flags = ix->d_overflow + (size_t)slot * ix->bc_slot_stride;
     float* d_qkeep = qblk + (size_t)(slot % LS_BC_QKEEP_BLOCK) * ix->bc_qkeep_stride;
     if ((rc = ls_grow(&st.d_sample_top, &st.sample_top_cap, nrec * 16)) != LS_OK) return rc;

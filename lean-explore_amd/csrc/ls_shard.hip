@@ -66,6 +66,8 @@ struct rccl_api {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
 };
@@ -95,6 +97,8 @@ int rccl_bind() {
     LS_SYM(GroupStart, "ncclGroupStart")
     LS_SYM(GroupEnd, "ncclGroupEnd")
     LS_SYM(AllGather, "ncclAllGather")
+    LS_SYM(Send, "ncclSend")
+    LS_SYM(Recv, "ncclRecv")
     LS_SYM(GetErrorString, "ncclGetErrorString")
     LS_SYM(GetVersion, "ncclGetVersion")
 #undef LS_SYM
@@ -194,9 +198,11 @@ struct ls_shard_group {
     std::vector<int> dev;        // device ordinal of shard g
     std::vector<int64_t> lo;     // first global row of shard g (relative to the group's base)
     bool replicated = false;     // every sub-handle holds the WHOLE corpus (ls_create_replicated)
+    std::atomic<bool> failed{false};  // replicated: an add reached some replicas only - the handle refuses further work
     std::atomic<uint32_t> rr{0}; // replicated: the next synchronous host call goes to replica rr % G
     bool distinct = false;       // all device ids differ (an RCCL communicator can be formed)
-    int exchange_mode = 0;       // 0: RCCL all-gather when `distinct`; 1: peer copies to the primary
+    int exchange_mode = 0;       // 0: RCCL all-gather when `distinct`; 1: peer copies to the primary;
+                                 // 2: RCCL gather-to-root (ncclSend / ncclRecv in one group) when `distinct`
     std::vector<ncclComm_t> comms;
     bool comms_ready = false;
     bool debug_fail_rccl = false;  // test hook (debug option 12): pretend the collective failed
@@ -248,7 +254,7 @@ struct ls_shard_group {
 };
 
 static inline bool group_uses_rccl(const ls_shard_group* G) {
-    return G->distinct && G->exchange_mode == 0;
+    return G->distinct && (G->exchange_mode == 0 || G->exchange_mode == 2);
 }
 
 static int group_grow(ls_shard_group::buf* b, size_t need) { return ls_grow(&b->p, &b->cap, need); }
@@ -287,6 +293,35 @@ static int group_exchange_rccl(ls_shard_group* G, int slot, size_t block) {
     return LS_OK;
 }
 
+// The same exchange as a GATHER TO ROOT: only the primary merges (one process, one merge - unlike the
+// one-process-per-GPU model of sharded.py, where every rank needs every block), so only the primary needs
+// the G blocks. ncclSend / ncclRecv in one group: every other shard sends its block once, nothing grows
+// on the non-primary devices (the all-gather keeps G x the buffer and moves G x the bytes: 98 MB per rank
+// and call at nq = 1024, k = 1000, G = 8). north_star names the all-gather, which stays the default;
+// ls_debug_option(8, 2) selects this one, ls_shard_exchange_info names the collective in use.
+static int group_exchange_rccl_gather(ls_shard_group* G, int slot, size_t block) {
+    int rc;
+    if ((rc = group_init_comms(G)) != LS_OK) return rc;
+    LS_HIP(hipSetDevice(G->dev[0]));
+    if ((rc = group_grow(&G->sh[0].gathered[slot], block * G->G)) != LS_OK) return rc;
+    char* dst = G->sh[0].gathered[slot].p;
+    LS_HIP(hipMemcpyAsync(dst, G->sh[0].packed[slot].p, block, hipMemcpyDeviceToDevice, G->sh[0].stream));
+    if (G->G == 1) return LS_OK;
+    LS_NCCL(g_rccl.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (int g = 1; g < G->G && r == ncclSuccess; ++g)
+        r = g_rccl.Recv(dst + (size_t)g * block, block, ncclUint8, g, G->comms[0], G->sh[0].stream);
+    for (int g = 1; g < G->G && r == ncclSuccess; ++g)
+        r = g_rccl.Send(G->sh[g].packed[slot].p, block, ncclUint8, 0, G->comms[g], G->sh[g].stream);
+    if (r != ncclSuccess) {
+        (void)g_rccl.GroupEnd();
+        ls_set_error("ncclSend / ncclRecv failed: %s", g_rccl.GetErrorString(r));
+        return LS_ERR_HIP;
+    }
+    LS_NCCL(g_rccl.GroupEnd());
+    return LS_OK;
+}
+
 static int group_exchange(ls_shard_group* G, int slot, size_t block) {
     int rc;
     G->n_exchanges++;
@@ -295,7 +330,8 @@ static int group_exchange(ls_shard_group* G, int slot, size_t block) {
             ls_set_error("RCCL failure injected by ls_debug_option(12, 1)");
             rc = LS_ERR_HIP;
         } else {
-            rc = group_exchange_rccl(G, slot, block);
+            rc = G->exchange_mode == 2 ? group_exchange_rccl_gather(G, slot, block)
+                                       : group_exchange_rccl(G, slot, block);
         }
         if (rc == LS_OK) return LS_OK;
         // RCCL is not usable here (library missing, ncclCommInitAll or the collective failed): the
@@ -375,12 +411,26 @@ static int group_start_workers(ls_shard_group* G) {
     G->workers.assign(G->G, nullptr);
     for (int g = 1; g < G->G; ++g) {  // shard 0 is queued from the calling thread
         ls_shard_worker* w = new (std::nothrow) ls_shard_worker();
-        if (!w) {
-            ls_set_error("sharded index: out of host memory for the enqueue workers");
+        bool ok = w != nullptr;
+        if (ok) {
+            w->device = G->dev[g];
+            try {  // (std::thread may throw std::system_error: nothing crosses the C ABI)
+                w->th = std::thread([w] { w->run(); });
+            } catch (...) {
+                ok = false;
+            }
+        }
+        if (!ok) {  // no half-built worker set: the next call starts over
+            delete w;
+            for (ls_shard_worker* o : G->workers) {
+                if (!o) continue;
+                o->shutdown();
+                delete o;
+            }
+            G->workers.clear();
+            ls_set_error("sharded index: cannot start the enqueue worker of shard %d", g);
             return LS_ERR_INVALID_ARG;
         }
-        w->device = G->dev[g];
-        w->th = std::thread([w] { w->run(); });
         G->workers[g] = w;
     }
     return LS_OK;
@@ -482,7 +532,9 @@ int ls_group_search(ls_index* ix, const float* q, bool q_on_host, int64_t nq, in
 
     LS_HIP(hipSetDevice(P));
     hipStream_t s0 = G->sh[0].stream;
-    const bool q_direct = q_on_host && nq <= LS_SCAN_PATH_MAX_NQ;  // kernels read the pinned buffer
+    // kernels read the pinned buffer themselves - single queries only: every scan workgroup reads the whole
+    // query block, 256 x 16 x 4 KB over PCIe per shard otherwise (copied with one command instead)
+    const bool q_direct = q_on_host && nq == 1;
     const bool out_direct = q_on_host && on <= (size_t)(1 << 16);
     float* dst_s = out_s;
     int64_t* dst_i = out_i;
@@ -654,9 +706,20 @@ int ls_group_add(ls_index* ix, const float* rows, int64_t n_add) {
                      (long long)(ix->n + n_add));
         return LS_ERR_INVALID_ARG;
     }
-    if (G->replicated) {  // every replica appends the same rows
-        for (ls_index* sub : G->sub)
-            if (int rc = ls_add(sub, rows, n_add)) return rc;
+    if (G->replicated) {
+        // every replica appends the same rows. A failure part-way would leave replicas of different lengths
+        // behind a round-robin dispatcher: the handle is then marked failed and refuses searches
+        // and further adds instead of answering differently from call to call.
+        if (G->failed) {
+            ls_set_error("ls_add: an earlier add left the replicas inconsistent; recreate the index");
+            return LS_ERR_INVALID_ARG;
+        }
+        for (size_t r = 0; r < G->sub.size(); ++r) {
+            if (int rc = ls_add(G->sub[r], rows, n_add)) {
+                if (r > 0) G->failed = true;
+                return rc;
+            }
+        }
         ix->n += n_add;
         return LS_OK;
     }
@@ -688,9 +751,9 @@ int ls_group_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ls_set_error("ls_debug_option(%d): a replicated handle has no exchange step", which);
         return LS_ERR_INVALID_ARG;
     }
-    if (which == 8) {  // 0: RCCL all-gather between distinct devices (default); 1: peer copies
-        if (value != 0 && value != 1) {
-            ls_set_error("ls_debug_option(8): exchange mode must be 0 (RCCL) or 1 (peer copies)");
+    if (which == 8) {  // 0: RCCL all-gather between distinct devices (default); 1: peer copies; 2: RCCL gather to the primary
+        if (value < 0 || value > 2) {
+            ls_set_error("ls_debug_option(8): exchange mode must be 0 (RCCL all-gather), 1 (peer copies) or 2 (RCCL gather-to-root)");
             return LS_ERR_INVALID_ARG;
         }
         int rc = group_check_locked(ix);
@@ -750,6 +813,10 @@ int ls_replica_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint3
                       float* out_s, int64_t* out_i) {
     ls_device_guard guard;
     ls_shard_group* G = ix->group;
+    if (G->failed.load(std::memory_order_acquire)) {
+        ls_set_error("ls_search: an add left the replicas inconsistent; recreate the index");
+        return LS_ERR_INVALID_ARG;
+    }
     const uint32_t r = G->rr.fetch_add(1, std::memory_order_relaxed) % (uint32_t)G->G;
     return ls_search(G->sub[r], q, nq, k, flags, out_s, out_i);
 }
@@ -959,7 +1026,9 @@ int32_t ls_shard_exchange_info(ls_index* ix, char* buf, int32_t cap) {
     std::string o = "{\"exchange\": \"";
     o += G->replicated ? "none (replicas: every device holds the whole corpus)"
          : G->rccl_failed ? "peer-copy (RCCL failed)"
-         : group_uses_rccl(G) ? (G->comms_ready ? "rccl all-gather" : "rccl all-gather (not used yet)")
+         : group_uses_rccl(G) ? (G->exchange_mode == 2
+                                     ? (G->comms_ready ? "rccl gather-to-root (ncclSend/ncclRecv)" : "rccl gather-to-root (not used yet)")
+                                     : (G->comms_ready ? "rccl all-gather" : "rccl all-gather (not used yet)"))
          : (G->distinct ? "peer-copy (selected)" : "device-to-device copies (shards share a device)");
     o += "\", \"rccl_version\": " + std::to_string(G->rccl_version);
     std::string err = G->rccl_error;

@@ -219,6 +219,12 @@ def test_rccl_exchange_with_one_rank():
         D, I = ix.search(q, k)
         assert ix.debug_counter(15) == 2             # RCCL communicators initialised and used
         _check(D, I, corpus, q, k, False, True)
+        assert "rccl all-gather" in ix.exchange_info()["exchange"]
+        ix.debug_option(8, 2)                        # RCCL gather-to-root: ncclSend / ncclRecv, only the primary receives
+        D, I = ix.search(q, k)
+        assert ix.debug_counter(15) == 2
+        assert "gather-to-root" in ix.exchange_info()["exchange"]
+        _check(D, I, corpus, q, k, False, True)
         ix.debug_option(8, 1)                        # the same group over peer copies
         D, I = ix.search(q, k)
         assert ix.debug_counter(15) == 0

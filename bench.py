@@ -629,9 +629,26 @@ def run_host_api(env: Env, workload: str, calls: int = 300) -> dict:
         t0 = time.perf_counter()
         ix.search(q, k, normalize=True)
         lat[i] = time.perf_counter() - t0
+    # the same call through the plain ctypes binding (north_star: "thin ctypes shim"); FlatIPIndex.search above
+    # goes through csrc/lsfast.c when it is built (the same C symbol without ctypes' argument conversion)
+    from lean_explore_amd import native
+
+    lib, h = native.load(), ix._handle
+    D = np.empty((1, k), np.float32)
+    I = np.empty((1, k), np.int64)
+    lat_ct = np.empty(calls)
+    for i in range(30 + calls):
+        t0 = time.perf_counter()
+        rc = lib.ls_search(h, native.addr(q), 1, k, native.LS_FLAG_NORMALIZE, native.addr(D), native.addr(I))
+        if i >= 30:
+            lat_ct[i - 30] = time.perf_counter() - t0
+        if rc:
+            native.check(rc)
     ix.close()
     mean = float(lat.mean())
     return {"workload": f"{workload}: N={n} d={d} {dtype} nq=1 k={k}", "calls": calls,
+            "binding": "csrc/lsfast.c (CPython)" if native.fast_search() is not None else "ctypes",
+            "us_per_call_p50_ctypes_binding": round(float(np.median(lat_ct)) * 1e6, 2),
             "us_per_call_mean": round(mean * 1e6, 2),
             "us_per_call_p50": round(float(np.median(lat)) * 1e6, 2),
             "us_per_call_p90": round(float(np.quantile(lat, 0.9)) * 1e6, 2),
@@ -805,6 +822,8 @@ def main():
             "prewarm_s": PREWARM_S,
             "roofline": head["roofline"],
         }
+        if "parity" in head:
+            out["parity"] = head["parity"]
         if "cpu_baseline" in head:
             out["cpu_baseline"] = head["cpu_baseline"]
         if secondary:

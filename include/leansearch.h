@@ -27,7 +27,9 @@
  *     and on several streams: calls are serialised inside, and device work that shares the
  *     handle's scratch is fenced across streams by events. Concurrent ls_search calls do not
  *     queue one behind the other: whichever thread is serving takes every waiting request of the
- *     same k and flags (up to 16 queries) into ONE corpus pass; waiters sleep, they do not spin.
+ *     same k and flags (up to 16 queries) into ONE corpus pass (fp32 index: on the f32 matrix cores,
+ *     bit-identical to the separate calls); waiters sleep, they do not spin. A synchronous call's
+ *     launch may be queued while the previous call still waits for its answer (two host slots).
  *   - stream lifetime: a hipStream_t handed to ls_search_device must stay alive until the next
  *     ls_check (or synchronous call) on that handle has returned, or until ls_destroy: the handle
  *     remembers the stream of its most recent calls and may synchronise it when a later call
@@ -240,8 +242,12 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * two calls ahead ride on the MFMA pass launch: 0 off, 1 on (default); option 14: select
  * step of the batched path as one wave per query in <= 48 registers where the shape allows (k <= 128,
  * <= 128 corpus slices; runs inside a resident MFMA pass): default on;
+ * option 16: fp32 index, 2..16 queries per corpus pass on the f32 matrix cores (ls_mq.hip): default on
+ * (0: the VALU scan groups of 8 / 4 / 1 - same bits); option 17: synchronous host calls may overlap two
+ * deep (default on);
  * option 8 (sharded handles): exchange step 0 = RCCL all-gather between distinct devices (default),
- * 1 = peer copies into the primary device's gather buffer; option 11 (sharded handles): one host
+ * 1 = peer copies into the primary device's gather buffer, 2 = RCCL gather-to-root (ncclSend / ncclRecv:
+ * only the primary, which merges, receives the blocks); option 11 (sharded handles): one host
  * thread per shard queues that shard's work: -1 automatic (on when the device ids are distinct,
  * default), 0 off, 1 on; option 12 (sharded handles, test hook): make the next RCCL exchange fail
  * (the handle must fall back to peer copies and keep answering).
@@ -254,6 +260,8 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * on this node: fell back to peer copies), 19 calls whose shards were queued by the enqueue workers;
  * counter 20: synchronous host calls that had to launch the stand-alone selection (option 9's retry);
  * counter 22: checks of pending batched calls the library ran on its own (slots exhausted or re-sliced; summed);
+ * counter 23: ls_mq launches (small fp32 batches on the f32 matrix cores); counter 24: synchronous host calls
+ * that were queued while another one was still in flight;
  * counters 0, 1, 8, 11, 12 are summed over the shards, 9 and 10 are the primary shard's;
  * counter 16: combined batches ls_search served, 17: the requests they carried; counter 18 (sharded
  * handles): mean host nanoseconds spent queueing one search (every device's work + exchange + merge).

@@ -1376,6 +1376,7 @@ struct ls_req {
     char err[256] = "";
 };
 
+#define LS_WAITER_SPIN_US 300  // a queued caller polls this long before it sleeps on the condition variable
 struct ls_served {  // one batch between its begin and its finish
     ls_host_call call;
     std::vector<ls_req*> batch;
@@ -1454,7 +1455,21 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
     ix->req_q.push_back(&me);
     while (!me.done) {
         if (ix->leader_active || me.taken) {  // (taken: my request is in a batch someone is serving)
-            ix->q_cv.wait(lk);
+            // The answer is typically 50-150 us away and a futex wake-up costs tens of us (times the callers
+            // woken at once): poll the queue's epoch for a while before sleeping (round 5)
+            const uint64_t seen = ix->q_epoch.load(std::memory_order_acquire);
+            lk.unlock();
+            bool changed = false;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned it = 0; !changed; ++it) {
+                for (int i = 0; i < 32; ++i) _mm_pause();
+                changed = ix->q_epoch.load(std::memory_order_acquire) != seen;
+                if ((it & 15) == 15 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(LS_WAITER_SPIN_US)) break;
+            }
+            lk.lock();
+            if (!changed && !me.done && (ix->leader_active || me.taken) &&
+                ix->q_epoch.load(std::memory_order_acquire) == seen)
+                ix->q_cv.wait(lk);
             continue;
         }
         // lead ONE batch: queue its launch, pass the leadership on, then wait for its results
@@ -1468,8 +1483,20 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         // batch held 1-2 requests and 8 callers fell from 51 k to 35 k queries/s; forming it "as late as
         // keeps the launches back to back" from a running estimate of the call time: 43 k).
         while (ix->calls_in_flight > 0 &&
-               !(ix->opt_overlap_calls && ix->requests_in_flight + (int64_t)ix->req_q.size() <= 2))
-            ix->q_cv.wait(lk);
+               !(ix->opt_overlap_calls && ix->requests_in_flight + (int64_t)ix->req_q.size() <= 2)) {
+            const uint64_t seen = ix->q_epoch.load(std::memory_order_acquire);  // (as above: poll, then sleep)
+            lk.unlock();
+            bool changed = false;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned it = 0; !changed; ++it) {
+                for (int i = 0; i < 32; ++i) _mm_pause();
+                changed = ix->q_epoch.load(std::memory_order_acquire) != seen;
+                if ((it & 15) == 15 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(LS_WAITER_SPIN_US)) break;
+            }
+            lk.lock();
+            if (!changed && ix->calls_in_flight > 0 && ix->q_epoch.load(std::memory_order_acquire) == seen)
+                ix->q_cv.wait(lk);
+        }
         ls_served sv;
         ls_req* head = ix->req_q.front();
         int64_t total = 0;
@@ -1487,6 +1514,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         ix->calls_in_flight++;
         ix->requests_in_flight += (int64_t)sv.batch.size();
         ix->leader_active = false;
+        ix->q_epoch.fetch_add(1, std::memory_order_release);
         ix->q_cv.notify_all();  // a waiter whose request is still queued leads the next batch
         lk.unlock();
         serve_finish(ix, sv);
@@ -1494,6 +1522,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         ix->calls_in_flight--;
         ix->requests_in_flight -= (int64_t)sv.batch.size();
         for (ls_req* r : sv.batch) r->done = true;
+        ix->q_epoch.fetch_add(1, std::memory_order_release);
         ix->q_cv.notify_all();
     }
     if (me.rc != LS_OK && me.err[0]) ls_set_error("%s", me.err);

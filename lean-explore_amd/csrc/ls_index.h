@@ -65,6 +65,7 @@ struct ls_index {
     std::condition_variable q_cv;
     std::deque<ls_req*> req_q;
     bool leader_active = false;
+    std::atomic<uint64_t> q_epoch{0};  // bumped whenever the queue's state changes (leadership free, results handed back)
     int32_t calls_in_flight = 0;       // batches queued whose results have not been handed back yet (under q_mu)
     int64_t requests_in_flight = 0;    // ... and the requests in them
     int32_t opt_combine = 1;

@@ -29,7 +29,7 @@ dst.mkdir(parents=True, exist_ok=True)
 
 DOMINANT = {  # substring(s) that must ALL appear in the kernel name
     "c3": ("ls_gemm_filter_kernel", ", 0>("), "c4": ("ls_gemm_filter_kernel", ", 0>("),
-    "bm25": ("bm25_score_kernel",),
+    "bm25": ("bm25_score_kernel",), "c2x8": ("ls_mq_kernel",), "c2px8": ("ls_mq_kernel",),
 }
 need = DOMINANT.get(wl, ("ls_scan_kernel",))
 

@@ -88,3 +88,56 @@ def test_errors_reach_the_caller_that_made_them():
         assert sorted(out) == sorted([native.LS_ERR_K_TOO_LARGE] * 2 + [5, 5])
     finally:
         ix.close()
+
+
+def test_two_alternating_callers_overlap_and_stay_exact():
+    """Round 5: a synchronous call runs in two phases on one of two host slots; with two callers taking turns
+    the second call's launch is queued while the first still polls for its answer (debug counter 24 counts
+    such calls). Every answer must be bit-identical to the caller's own separate call (zero-excuse oracle
+    included), also while a third thread adds rows / checks / sets the base in between - those entry
+    points wait for the host calls in flight (ls_quiesce) - and with the overlap switched off (option 17)."""
+    n, d = 100_000, 384
+    corpus = H.gauss(91, n, d)
+    pool = H.gauss(92, 32, d)
+    ix = FlatIPIndex.from_array(corpus)
+    try:
+        want = [ix.search(pool[i:i + 1], 50) for i in range(32)]
+        oracle.compare_kernel_order(np.concatenate([w[0] for w in want[:4]]), np.concatenate([w[1] for w in want[:4]]),
+                                    corpus, pool[:4], 50, orders=("scan",))
+        for overlap in (1, 0):
+            ix.debug_option(17, overlap)
+            before = ix.debug_counter(24)
+            errors, stop = [], threading.Event()
+
+            def worker(t):
+                for j in range(300):
+                    i = (7 * j + 13 * t) % 32
+                    D, I = ix.search(pool[i:i + 1], 50)
+                    if not (np.array_equal(D, want[i][0]) and np.array_equal(I, want[i][1])):
+                        errors.append((t, j, i))
+
+            def meddler():
+                from lean_explore_amd import native
+
+                lib = native.load()
+                while not stop.is_set():
+                    ix.check()
+                    native.check(lib.ls_set_base(ix._handle, 0))
+                    stop.wait(0.0005)  # (both take every host slot: leave the callers room to overlap)
+
+            ths = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+            m = threading.Thread(target=meddler)
+            m.start()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            stop.set()
+            m.join()
+            assert not errors, (overlap, errors[:5])
+            if overlap:
+                assert ix.debug_counter(24) > before, "two alternating callers never overlapped"
+            else:
+                assert ix.debug_counter(24) == before
+    finally:
+        ix.close()

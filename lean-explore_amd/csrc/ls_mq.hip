@@ -116,8 +116,8 @@ __global__ __launch_bounds__(LS_MQ_THREADS, 2) void ls_mq_kernel(
     float* Bs = reinterpret_cast<float*>(smem_dyn);                    // [CH][4][16]
     u64* Ks = reinterpret_cast<u64*>(smem_dyn + (size_t)CH * 256);     // [16 queries][4 waves][M], then the bounds
 
-    // Tiles of 16 rows are dealt round-robin to the waves of the launch (the four waves of a workgroup take
-    // four adjacent tiles): a run of adjacent, similar rows spreads over many workgroups.
+    // Tiles of 16 rows are dealt round-robin to the waves of the launch (adjacent tiles go to different
+    // workgroups): a run of adjacent, similar rows spreads over many workgroups.
     // Measured alternatives (tools/multiq_time.py, N = 200 k, 2 / 16 queries per pass, d = 384 | d = 1024):
     //   this form with 448 workgroups of 4 waves (1.75 per CU; 256 are ~10 % faster) 62.0 / 66.1 | 150.9 / 165.6 us
     //   256 workgroups of 8 waves, the tiles of a workgroup dealt to its waves
@@ -129,7 +129,10 @@ __global__ __launch_bounds__(LS_MQ_THREADS, 2) void ls_mq_kernel(
     // workgroups (one workgroup per CU leaves no second slot).
     const long long W = (long long)nblk * LS_MQ_WAVES;
     const long long NT = (n + 15) / 16;
-    long long t = (long long)bid * LS_MQ_WAVES + wave;
+    // wave-major numbering: the launch's last, partial round of tiles (12 500 tiles over 1024 waves: 0.2 of
+    // a round) goes to ONE wave in each of many workgroups instead of all four waves of a few - the tail is a
+    // lone wave's tile (~2 us) in 212 CUs, not four waves' worth (~4 us) in 53
+    long long t = (long long)wave * nblk + bid;
 
     // unit u of a tile -> first chunk: group-major, then the lane's V rounds, then 4-chunk steps
     auto unit_chunk = [](int u) constexpr -> int {

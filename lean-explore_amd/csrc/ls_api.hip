@@ -343,6 +343,23 @@ int ls_i_flush_pending(ls_index* ix) {
     return ls_launch_finalize(jobs, np, ix->pending_stream);  // one launch, one workgroup per job
 }
 
+// Launches (query groups) the scan path will use for a call of nq queries: ONE definition, shared by the
+// scheduling below and by the host API's decision to overlap a call (a call that owns one scratch generation
+// must be a single group).
+static int64_t scan_group_count(const ls_index* ix, int64_t nq, int32_t k) {
+    const int64_t keff = std::min<int64_t>(k, ix->n);
+    const int mq_blocks = ix->opt_blocks > 0 ? std::min(ix->opt_blocks, ix->max_blocks)
+                                             : ls_mq_blocks(ix->n > 0 ? ix->n : 1, ix->n_cu);
+    const bool mq_ok = ix->opt_mq && ix->opt_multi_query && ix->dtype == LS_DTYPE_F32 && ix->n >= LS_MQ_MIN_ROWS &&
+                       ls_mq_lane_keys(mq_blocks, (int)std::max<int64_t>(keff, 1)) > 0;
+    int64_t groups = 0;
+    for (int64_t left = nq; left > 0; ++groups) {
+        if (mq_ok && left >= 2) left -= std::min<int64_t>(left, LS_QUERIES_PER_LAUNCH_MAX);
+        else left -= !ix->opt_multi_query ? 1 : (left >= 5 ? std::min<int64_t>(left, 8) : (left >= 2 ? std::min<int64_t>(left, 4) : 1));
+    }
+    return groups;
+}
+
 // Queue one search on stream `s` through the scan path. d_q: device fp32 [nq, d]; outputs
 // device [nq, k].
 static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
@@ -367,10 +384,10 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
     // scratch generations this call will use: a same-launch job's retry reads its generation's S and
     // granules after the host has seen its answer, so such a call must not wrap around the LS_NSETS
     // generations (one query per launch - debug option 6 - and 3+ queries would: ADVICE r4)
-    int64_t n_groups = 0;
-    for (int64_t left = nq; left > 0; ++n_groups) {
-        if (mq_ok && left >= 2) left -= std::min<int64_t>(left, LS_QUERIES_PER_LAUNCH_MAX);
-        else left -= !ix->opt_multi_query ? 1 : (left >= 5 ? std::min<int64_t>(left, 8) : (left >= 2 ? std::min<int64_t>(left, 4) : 1));
+    const int64_t n_groups = scan_group_count(ix, nq, k);
+    if (ix->force_gen >= 0 && n_groups != 1) {  // (host_call_begin asks the same function)
+        ls_set_error("internal: an overlapped host call must be a single query group (%lld)", (long long)n_groups);
+        return LS_ERR_INVALID_ARG;
     }
     // Everything is queued on the caller's stream. Queries go out in groups of 8, 4 or 1 that
     // share one pass over the corpus:
@@ -1075,20 +1092,6 @@ int ls_i_check_search_args(const ls_index* ix, const void* q, int64_t nq, int32_
 // used to alternate as lone launches with the GPU idle from the end of one call's selection to the next
 // call's launch (~15 us of every 65: profiles/ab/r04_concurrent_callers_replicas.txt); overlapped, the
 // second launch is already queued when the first one's scan ends.
-static int64_t scan_group_count(const ls_index* ix, int64_t nq, int32_t k) {
-    const int64_t keff = std::min<int64_t>(k, ix->n);
-    const int mq_blocks = ix->opt_blocks > 0 ? std::min(ix->opt_blocks, ix->max_blocks)
-                                             : ls_mq_blocks(ix->n > 0 ? ix->n : 1, ix->n_cu);
-    const bool mq_ok = ix->opt_mq && ix->opt_multi_query && ix->dtype == LS_DTYPE_F32 && ix->n >= LS_MQ_MIN_ROWS &&
-                       ls_mq_lane_keys(mq_blocks, (int)std::max<int64_t>(keff, 1)) > 0;
-    int64_t groups = 0;
-    for (int64_t left = nq; left > 0; ++groups) {
-        if (mq_ok && left >= 2) left -= std::min<int64_t>(left, LS_QUERIES_PER_LAUNCH_MAX);
-        else left -= !ix->opt_multi_query ? 1 : (left >= 5 ? std::min<int64_t>(left, 8) : (left >= 2 ? std::min<int64_t>(left, 4) : 1));
-    }
-    return groups;
-}
-
 struct ls_host_call {
     ls_index* ix = nullptr;
     ls_host_slot* S = nullptr;

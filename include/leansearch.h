@@ -244,7 +244,8 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * <= 128 corpus slices; runs inside a resident MFMA pass): default on;
  * option 16: fp32 index, 2..16 queries per corpus pass on the f32 matrix cores (ls_mq.hip): default on
  * (0: the VALU scan groups of 8 / 4 / 1 - same bits); option 17: synchronous host calls may overlap two
- * deep (default on);
+ * deep (default on); option 18: fp16 index with 768-byte stored rows, batched pass in the row-split,
+ * 64-queries-per-wave shape (measured slower, profiles/ab/r05_tile_shape.txt: default off);
  * option 8 (sharded handles): exchange step 0 = RCCL all-gather between distinct devices (default),
  * 1 = peer copies into the primary device's gather buffer, 2 = RCCL gather-to-root (ncclSend / ncclRecv:
  * only the primary, which merges, receives the blocks); option 11 (sharded handles): one host

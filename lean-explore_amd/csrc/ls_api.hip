@@ -606,9 +606,8 @@ struct bc_plan {
 static bc_plan bc_make_plan(const ls_index* ix, int64_t nq, int32_t k) {
     const ls_geom& g = ix->g;
     const bool f32 = ix->dtype == LS_DTYPE_F32;
-    const int QG = ls_gemm_qg(g);
-    const int QT = f32 ? 64 : LS_GEMM_WAVES * 16 * QG;  // queries per workgroup
-    const int TM = f32 ? 64 : ls_gemm_tile_rows(g);
+    const int QT = f32 ? 64 : ls_gemm_qt(g);  // queries per workgroup
+    const int TM = f32 ? 64 : ls_gemm_tile_rows(g);  // rows a slice contributes to one tile
     const int64_t nq_pad = (nq + QT - 1) / QT * QT;
     const int nqt = (int)(nq_pad / QT);
     // corpus slices: one 8-wave workgroup per CU in total, a multiple of the 8 XCDs. The fp32
@@ -616,6 +615,7 @@ static bc_plan bc_make_plan(const ls_index* ix, int64_t nq, int32_t k) {
     int nsplits = (LS_GEMM_WG_PER_CU * ix->n_cu / nqt) / 8 * 8;
     nsplits = std::max(8, std::min(nsplits, 256));
     if (f32) nsplits = 2 * std::max(8, std::min(LS_GEMM_MAX_SPLITS / 2, (2 * ix->n_cu / nqt) / 8 * 8));
+    else nsplits *= ls_gemm_rs(g);  // the row-split shape: every workgroup walks two slices
     int64_t rps = (ix->n + nsplits - 1) / nsplits;
     rps = (rps + TM - 1) / TM * TM;
     const int tiles_per_split = (int)(rps / TM);
@@ -820,8 +820,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     if (rc != LS_OK) return rc;
     const ls_geom& g = ix->g;
     const bool f32 = ix->dtype == LS_DTYPE_F32;
-    const int QG = ls_gemm_qg(g);
-    const int QT = f32 ? 64 : LS_GEMM_WAVES * 16 * QG;  // queries per workgroup
+    const int QT = f32 ? 64 : ls_gemm_qt(g);  // queries per workgroup
     const int64_t nq_pad = (nq + QT - 1) / QT * QT;
     const int64_t qkeep_need = nq * g.d;
     if ((int)ix->bc_pending.size() >= ix->bc_slots() ||
@@ -965,7 +964,7 @@ static int batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, 
     // calls back, which is held until now for that (the register-starved geometries - config 4's
     // 1.5 KiB rows - spend ~1 % of a multi-millisecond batch between passes and keep their own
     // sample launch)
-    const bool fuse_ok = chain && !f32 && ix->opt_fused != 0 && g.chunks <= 48;
+    const bool fuse_ok = chain && !f32 && ix->opt_fused != 0 && g.chunks <= 48 && ls_gemm_rs(g) == 1;
     bool ride = false;
     if (fuse_ok && ix->held.size() == 2) {
         const ls_index::bc_stage& d = ix->held.front();
@@ -1828,6 +1827,11 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
     }
     if (which == 7) {  // force the number of scan workgroups per launch (0 = automatic)
         ix->opt_blocks = value;
+        return LS_OK;
+    }
+    if (which == 18) {  // fp16 index, 48-chunk rows: the batched pass in the row-split, 64-queries-per-wave shape (default off)
+        if (int rc = ls_i_batched_repair(ix)) return rc;  // nothing pending in the other geometry
+        ix->g.qg4 = value != 0;
         return LS_OK;
     }
     if (which == 17) {  // synchronous host calls overlap two deep (default on)

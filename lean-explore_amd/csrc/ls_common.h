@@ -174,6 +174,7 @@ struct ls_geom {
     int32_t L;        // lanes per row (16, 32 or 64)
     int32_t V;        // chunks per lane (1..4)
     int32_t elem;     // bytes per element (4 or 2)
+    int32_t qg4;      // fp16, 48-chunk rows: the batched pass uses the row-split, 64-queries-per-wave shape (ls_gemm.hip RS = 2)
 };
 int ls_pick_geom(int32_t d, int32_t dtype, ls_geom* g);
 
@@ -306,7 +307,9 @@ int ls_launch_tau(const u32* d_sample_top, int nsplits, int64_t nq, int64_t nq_p
 #ifdef LS_GEMM_TIMING
 int ls_gemm_read_sample_stamps(unsigned long long* out, int count);  // variant builds: sample-pass phase stamps
 #endif
-int ls_gemm_qg(const ls_geom& g);         // query groups of 16 per wave (2, or 1 for 2 KiB rows)
+int ls_gemm_qg(const ls_geom& g);         // query groups of 16 per wave (2, 1 for 2 KiB rows, 4 in the row-split shape)
+int ls_gemm_rs(const ls_geom& g);         // wave groups the tile's rows are split over (1, or 2: ls_geom::qg4)
+int ls_gemm_qt(const ls_geom& g);         // queries per workgroup
 int ls_gemm_tile_rows(const ls_geom& g);  // corpus rows per LDS tile (64, or 32 for long rows)
 #define LS_BSEL_MAX_KEYS 8192         // candidate keys per query the select kernel can hold in LDS
 int ls_launch_batch_select(const ls_gemm_bufs& b, int nsplits, int64_t nq, int k, int keys_need,

@@ -76,10 +76,12 @@ __host__ __device__ constexpr int gemm_nbuf(int chunks) {
 // Output layout = the order in which ls_gemm_filter_kernel consumes it: the 16-byte chunk c of
 // query q (tile qt, wave w, group g2, li = q % 16) is fragment (qt, w, g2, kk = c / 4), lane
 // (c % 4) * 16 + li. One wave load of a B fragment is then one contiguous 1 KiB read.
-__device__ __forceinline__ long long qfrag_chunk(int q, int c, int QG, int KS) {
-    const int QPW = 16 * QG, QT = LS_GEMM_WAVES * QPW;
+// (WQ = waves of a workgroup that hold DIFFERENT queries: 8, or 4 in the row-split geometry where two waves
+// share a query block and take a row half each)
+__device__ __forceinline__ long long qfrag_chunk(int q, int c, int QG, int KS, int WQ) {
+    const int QPW = 16 * QG, QT = WQ * QPW;
     const int qt = q / QT, w = (q % QT) / QPW, g2 = (q % QPW) / 16, li = q % 16;
-    return ((((long long)(qt * LS_GEMM_WAVES + w) * QG + g2) * KS + (c >> 2)) << 6) + ((c & 3) << 4) + li;
+    return ((((long long)(qt * WQ + w) * QG + g2) * KS + (c >> 2)) << 6) + ((c & 3) << 4) + li;
 }
 // One wave per query (4 queries per block): the norm is the library's canonical wave reduction
 // (ls_wave_sumsq), every lane converts and stores whole 16-byte chunks. The raw fp32 queries are
@@ -88,7 +90,7 @@ __device__ __forceinline__ long long qfrag_chunk(int q, int c, int QG, int KS) {
 __global__ __launch_bounds__(256) void ls_prep_f16_kernel(const float* __restrict__ qin,
                                                           u32x4* __restrict__ qout,
                                                           float* __restrict__ qkeep, int nq,
-                                                          int nq_pad, int d, int d_pad, int QG,
+                                                          int nq_pad, int d, int d_pad, int QG, int WQ,
                                                           int normalize, u32* __restrict__ overflow) {
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void ls_prep_f16_kernel(const float* __restric
             const float v = (live && j < d) ? (normalize ? src[j] * inv : src[j]) : 0.0f;
             h[e] = (_Float16)v;
         }
-        qout[qfrag_chunk(qi, c, QG, KS)] = __builtin_bit_cast(u32x4, h);
+        qout[qfrag_chunk(qi, c, QG, KS, WQ)] = __builtin_bit_cast(u32x4, h);
     }
 }
 
@@ -121,7 +123,7 @@ int ls_launch_prep_f16(const float* d_q, void* d_qh, float* d_qkeep, int64_t nq,
     // one-wave workgroups: 37 registers and no LDS, i.e. a wave that fits beside a resident MFMA pass
     // (tools/coresidency_probe.hip), whatever SIMD has room for it
     hipLaunchKernelGGL(ls_prep_f16_kernel, dim3((unsigned)nq_pad), dim3(64), 0, s, d_q,
-                       (u32x4*)d_qh, d_qkeep, (int)nq, (int)nq_pad, g.d, g.d_pad, ls_gemm_qg(g),
+                       (u32x4*)d_qh, d_qkeep, (int)nq, (int)nq_pad, g.d, g.d_pad, ls_gemm_qg(g), LS_GEMM_WAVES / ls_gemm_rs(g),
                        normalize ? 1 : 0, d_overflow);
     LS_HIP(hipGetLastError());
     return LS_OK;
@@ -195,6 +197,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 struct phase_sample { static constexpr bool value = true; };
 struct phase_full { static constexpr bool value = false; };
 
+#ifndef LS_GEMM_PF_QG4
+#define LS_GEMM_PF_QG4 1  // A-fragment look-ahead of the sample pass and of the 64-queries-per-wave shape (registers)
+#endif
 #define LS_GEMM_PASS 0    // full pass against a given tau
 #define LS_GEMM_SAMPLE 1  // sample pass: best sample scores per lane
 #define LS_GEMM_FUSED 2   // full pass of this batch, then the sample phase of the NEXT batch
@@ -214,7 +219,14 @@ struct phase_full { static constexpr bool value = false; };
 // workgroups on arrival counters inside the kernel: 28 us of start-up, waits and cross-XCD reads of
 // freshly written-through scores per launch against 23 us for the two kernels it replaced -
 // tools/fused_phases.py, profiles/ab/r04_c3_fused_forms.txt).
-template <int CHUNKS, int QG, int TOPN, bool NT, int MODE>
+// RS (round 5, the "64 queries per wave" shape for stored rows of 768 bytes): RS = 2 splits the tile's ROWS over
+// wave pairs - waves 0-3 take the first half of every tile, waves 4-7 the second, wave w and w + 4 hold the same
+// QG = 4 query groups - so every A fragment read from LDS feeds 4 MFMAs instead of 2 (LDS reads per MFMA 0.5 ->
+// 0.25; profiles/ab/r05_tile_shape.txt prices the reads at 6 % of the pass, by clock). B is then 192 VGPRs: one
+// accumulator set, row blocks in sequence (the config-4 loop). The two halves of a tile come from TWO adjacent
+// corpus slices (as in ls_gemm32.hip), so a (query, slice, quarter) queue still has exactly one producer lane
+// and the tau / select kernels are shared unchanged; a launch then covers 2 x workgroups / query-tiles slices.
+template <int CHUNKS, int QG, int RS, int TOPN, bool NT, int MODE>
 __device__ __forceinline__ void gemm_filter_body(
     const u32x4* __restrict__ corpus, long long n, const u32x4* __restrict__ qh, int nq, int nqt,
     const float* __restrict__ tau, long long rows_per_split, int tile_stride_arg, const ls_gemm_out& out) {
@@ -222,7 +234,9 @@ __device__ __forceinline__ void gemm_filter_body(
     constexpr bool SAMPLE = MODE == LS_GEMM_SAMPLE;
     constexpr bool FUSED = MODE == LS_GEMM_FUSED;
     constexpr int TM = gemm_tm(CHUNKS);    // corpus rows per LDS tile
-    constexpr int NRB = TM / 16;           // 16-row MFMA blocks per tile
+    constexpr int TMH = TM / RS;           // ... of which one slice contributes this many (a wave's rows)
+    constexpr int NRB = TMH / 16;          // 16-row MFMA blocks per wave and tile
+    constexpr int WQ = LS_GEMM_WAVES / RS; // waves holding different queries
     constexpr int KS = CHUNKS / 4;         // k-steps: 32 fp16 = 4 chunks each
     constexpr int QPW = 16 * QG;           // queries per wave
     constexpr int NV = NRB * QG * 4;       // filter values per lane per tile
@@ -247,13 +261,27 @@ __device__ __forceinline__ void gemm_filter_body(
     LS_SSTAMP_F(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar DMA addressing
     const int qd = lane >> 4, li = lane & 15;  // quarter (k-chunk / row group), index in group
-    int split, qt;
-    wg_coords((int)blockIdx.x, nqt, &split, &qt);
-    const int nsplits = (int)gridDim.x / nqt;
+    int wsplit, qt;  // the workgroup's slice (RS = 2: slice PAIR) and query tile
+    wg_coords((int)blockIdx.x, nqt, &wsplit, &qt);
+    const int nsplits = RS * ((int)gridDim.x / nqt);
+    const int rs = RS > 1 ? wave / WQ : 0;   // row half this wave computes (= its slice of the pair)
+    const int wq = RS > 1 ? wave % WQ : wave;  // query block of the wave
+    const int split = wsplit * RS + rs;
     const long long r_begin = (long long)split * rows_per_split;
     long long r_end = r_begin + rows_per_split;
     if (r_end > n) r_end = n;
-    const int ntiles_all = r_begin < r_end ? (int)((r_end - r_begin + TM - 1) / TM) : 0;
+    int ntiles_all = 0;  // of the longest slice of the workgroup (the tile loop is common: barriers)
+#pragma unroll
+    for (int h = 0; h < RS; ++h) {
+        const long long b0 = (long long)(wsplit * RS + h) * rows_per_split;
+        long long e0 = b0 + rows_per_split;
+        if (e0 > n) e0 = n;
+        const int th = b0 < e0 ? (int)((e0 - b0 + TMH - 1) / TMH) : 0;
+        ntiles_all = th > ntiles_all ? th : ntiles_all;
+    }
+    // the slice whose rows this wave's DMA pieces fetch: piece rows 0 .. TMH-1 are the first slice's
+    const long long dma_begin = RS > 1 ? (long long)(wsplit * RS + (wave * (TM * CHUNKS / LS_GEMM_THREADS) * 64) / (TMH * CHUNKS)) * rows_per_split
+                                       : r_begin;
     // the phase being run: every tile_stride-th tile of the slice, nt of them (a fused launch runs
     // the sample phase first and resets both for the full pass)
     int tile_stride = tile_stride_arg;
@@ -281,15 +309,22 @@ __device__ __forceinline__ void gemm_filter_body(
         for (int j = 0; j < LOADS; ++j) {
             const int Lc = (wave * LOADS + j) * 64 + lane;
             const int r = Lc / CHUNKS, sl = Lc % CHUNKS;
-            goff[j] = r * CHUNKS + (sl ^ (r & 15));
+            goff[j] = (r % TMH) * CHUNKS + (sl ^ (r & 15));
         }
     }
+    static_assert(RS == 1 || ((TMH * CHUNKS) % (64 * (TM * CHUNKS / LS_GEMM_THREADS)) == 0 && !(CHUNKS == 96)),
+                  "row split: a wave's DMA pieces must lie in one half of the tile");
     // piece j (0 .. LOADS-1) of tile ti -> the tile buffer at LDS byte offset bufoff
     auto stage_piece = [&](int ti, int bufoff, int j) {
 #if LS_ABL_NODMA
         if (!SAMPLE && ti > 0) return;
 #endif
-        const u32x4* base = corpus + (r_begin + (long long)ti * TM) * CHUNKS;
+        long long row0 = dma_begin + (long long)ti * TMH;
+        if (RS > 1) {  // a short (last) slice of the pair runs out of rows before the other: stay inside the pad rows
+            const long long lim = n + LS_CORPUS_PAD_ROWS - TMH;
+            row0 = row0 < lim ? row0 : lim;
+        }
+        const u32x4* base = corpus + row0 * CHUNKS;
         int lane_v = lane;
         if constexpr (LEAN || PAIRED) asm volatile("" : "+v"(lane_v));
         if constexpr (PAIRED) {
@@ -307,7 +342,7 @@ __device__ __forceinline__ void gemm_filter_body(
             if constexpr (LEAN) {
                 const int Lc = (wave * LOADS + j) * 64 + lane_v;
                 const int r = Lc / CHUNKS, sl = Lc % CHUNKS;
-                off = r * CHUNKS + (sl ^ (r & 15));
+                off = (r % TMH) * CHUNKS + (sl ^ (r & 15));
             } else {
                 off = goff[j];
             }
@@ -370,9 +405,9 @@ __device__ __forceinline__ void gemm_filter_body(
     const u32x4* qfrag[QG];
 #pragma unroll
     for (int g2 = 0; g2 < QG; ++g2) {
-        qj[g2] = (qt * LS_GEMM_WAVES + wave) * QPW + g2 * 16 + li;
+        qj[g2] = (qt * WQ + wq) * QPW + g2 * 16 + li;
         // fragment-ordered by ls_prep_f16_kernel: each load below is one contiguous KiB per wave
-        qfrag[g2] = qh + ((((long long)(qt * LS_GEMM_WAVES + wave) * QG + g2) * KS) << 6) + lane;
+        qfrag[g2] = qh + ((((long long)(qt * WQ + wq) * QG + g2) * KS) << 6) + lane;
         tauv[g2] = SAMPLE ? 0.0f : (LS_ABL_NOPASS ? FLT_MAX : tau[qj[g2]]);
     }
 #pragma unroll
@@ -407,7 +442,7 @@ __device__ __forceinline__ void gemm_filter_body(
     for (int m = 0; m < 4; ++m)
         lo4[m] = li * (PAIRED ? 2 : 1) * ROW_BYTES + (((4 * m + qd) ^ li) * 16);
     auto a_frag = [&](int bufoff, int rb, int kk) -> half8 {  // bufoff: byte offset of the tile
-        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + lo4[kk & 3] + bufoff +
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + lo4[kk & 3] + bufoff + rs * (TMH * ROW_BYTES) +
                                                         rb * (PAIRED ? 1 : 16) * ROW_BYTES + (kk >> 2) * 256);
         return __builtin_bit_cast(half8, v);
     };
@@ -452,7 +487,7 @@ __device__ __forceinline__ void gemm_filter_body(
     // the MFMA stream again without a second accumulator set.
     // One set, one query group (2 KiB rows): a single chain per row block would stall on its own
     // MFMA latency, so all blocks advance together and the filter runs before the k-loop.
-    constexpr bool SEQ_RB = ONE_ACC && QG == 2;
+    constexpr bool SEQ_RB = ONE_ACC && QG >= 2;
     // SEQ_RB also spreads the DMA pieces of the tile that is fetched next over the first row
     // block's k-steps (one piece every other k-step) instead of issuing all of them right behind
     // the barrier, where both waves of a SIMD would do so at once with the matrix pipe idle.
@@ -499,7 +534,7 @@ __device__ __forceinline__ void gemm_filter_body(
                 const int pb = rb == 0 ? NRB - 1 : rb - 1;  // block whose scores are filtered now
                 const bool have = rb == 0 ? have_prev : true;
                 const int prow0 = (rb == 0 ? prev_row0 : cur_row0) + pb * 16;
-                constexpr int PF = SMP ? 1 : LS_GEMM_PF, NA = PF + 1;  // A fragments are read PF k-steps ahead (the sample pass has 8 registers fewer)
+                constexpr int PF = (SMP || QG >= 4) ? LS_GEMM_PF_QG4 : LS_GEMM_PF, NA = PF + 1;  // A fragments are read PF k-steps ahead (the sample pass has 8 registers fewer)
                 half8 a[NA];
 #pragma unroll
                 for (int p0 = 0; p0 < PF; ++p0) a[p0] = a_frag(bufoff, rb, p0);
@@ -591,7 +626,7 @@ __device__ __forceinline__ void gemm_filter_body(
 #endif
     };
     reset_acc();
-    auto tile_row0 = [&](int i) { return (i * tile_stride) * TM + 4 * qd; };  // slice-relative
+    auto tile_row0 = [&](int i) { return (i * tile_stride) * TMH + 4 * qd; };  // slice-relative
     auto flush_last = [&](auto ph, const f32x4v (&acc)[NRB][QG]) {  // the last tile still has to be filtered
         const int row0 = tile_row0(nt - 1);
 #pragma unroll
@@ -641,7 +676,7 @@ __device__ __forceinline__ void gemm_filter_body(
         if constexpr (SMP) LS_SSTAMP_F(1);
         auto advance = [&](int& b) { b = b + TILE_BYTES == NBUF * TILE_BYTES ? 0 : b + TILE_BYTES; };
         auto one_tile = [&](f32x4v (&cur)[NRB][QG], const f32x4v (&prev)[NRB][QG], int i) {
-            constexpr bool always = LS_GEMM_STRAIGHT && !SMP && (AHEAD + 1) * TM <= LS_CORPUS_PAD_ROWS;
+            constexpr bool always = LS_GEMM_STRAIGHT && !SMP && (AHEAD + 1) * TMH <= LS_CORPUS_PAD_ROWS;
             const bool more = always ? true : i + AHEAD < nt;
             // the next tile's DMA pieces are issued between this tile's k-steps (run_tile), not in
             // one burst behind the barrier
@@ -690,7 +725,7 @@ __device__ __forceinline__ void gemm_filter_body(
         tile_stride = out.sample_stride;
         nt = (ntiles_all + tile_stride - 1) / tile_stride;
         // the straight-line full pass (two buffers) has already fetched and handed over sample tile 0
-        constexpr bool PREFETCHED = LS_GEMM_STRAIGHT && NBUF == 2 && 2 * TM <= LS_CORPUS_PAD_ROWS;
+        constexpr bool PREFETCHED = LS_GEMM_STRAIGHT && NBUF == 2 && 2 * TMH <= LS_CORPUS_PAD_ROWS;
         if constexpr (!PREFETCHED) {
             __builtin_amdgcn_s_barrier();  // every wave has left the tile ring
             phase_prologue();
@@ -700,7 +735,7 @@ __device__ __forceinline__ void gemm_filter_body(
             asm volatile("" : "+s"(qn));  // a different buffer: nothing of the first load may be reused
 #pragma unroll
             for (int g2 = 0; g2 < QG; ++g2)
-                qfrag[g2] = qn + ((((long long)(qt * LS_GEMM_WAVES + wave) * QG + g2) * KS) << 6) + lane;
+                qfrag[g2] = qn + ((((long long)(qt * WQ + wq) * QG + g2) * KS) << 6) + lane;
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
@@ -742,11 +777,21 @@ template <int CHUNKS, int QG, int TOPN, bool NT, int MODE>
 __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_gemm_filter_kernel(
     const u32x4* __restrict__ corpus, long long n, const u32x4* __restrict__ qh, int nq, int nqt,
     const float* __restrict__ tau, long long rows_per_split, int tile_stride, ls_gemm_out out) {
-    gemm_filter_body<CHUNKS, QG, TOPN, NT, MODE>(corpus, n, qh, nq, nqt, tau, rows_per_split, tile_stride, out);
+    gemm_filter_body<CHUNKS, QG, 1, TOPN, NT, MODE>(corpus, n, qh, nq, nqt, tau, rows_per_split, tile_stride, out);
+}
+// the row-split, 64-queries-per-wave shape (its own kernel name: the profile tooling tells the shapes apart)
+template <int CHUNKS, int TOPN, bool NT, int MODE>
+__global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_gemm_filter_rs2_kernel(
+    const u32x4* __restrict__ corpus, long long n, const u32x4* __restrict__ qh, int nq, int nqt,
+    const float* __restrict__ tau, long long rows_per_split, int tile_stride, ls_gemm_out out) {
+    gemm_filter_body<CHUNKS, 4, 2, TOPN, NT, MODE>(corpus, n, qh, nq, nqt, tau, rows_per_split, tile_stride, out);
 }
 
-int ls_gemm_qg(const ls_geom& g) { return gemm_qg(g.chunks); }
-int ls_gemm_tile_rows(const ls_geom& g) { return gemm_tm(g.chunks); }
+static inline bool gemm_is_qg4(const ls_geom& g) { return g.qg4 != 0 && g.chunks == 48 && g.elem == 2; }
+int ls_gemm_rs(const ls_geom& g) { return gemm_is_qg4(g) ? 2 : 1; }
+int ls_gemm_qg(const ls_geom& g) { return gemm_is_qg4(g) ? 4 : gemm_qg(g.chunks); }
+int ls_gemm_qt(const ls_geom& g) { return (LS_GEMM_WAVES / ls_gemm_rs(g)) * 16 * ls_gemm_qg(g); }
+int ls_gemm_tile_rows(const ls_geom& g) { return gemm_tm(g.chunks) / ls_gemm_rs(g); }
 
 // One launcher for the three kinds of launch. `fz` non-null (with d_tau) = a fused launch (this
 // batch's full pass + the next batch's sample phase); else d_tau null = sample pass, non-null = full pass. ev_start /
@@ -757,9 +802,8 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
                           int64_t rows_per_split, int tile_stride, const ls_gemm_bufs& b,
                           bool sample_top2, hipStream_t s, const ls_gemm_fuse* fz, hipEvent_t ev_start,
                           hipEvent_t ev_stop) {
-    const int QG = ls_gemm_qg(g);
-    const int nqt = (int)(nq_pad / (LS_GEMM_WAVES * 16 * QG));
-    const dim3 grid((unsigned)(nsplits * nqt));
+    const int nqt = (int)(nq_pad / ls_gemm_qt(g));
+    const dim3 grid((unsigned)(nsplits / ls_gemm_rs(g) * nqt));
     ls_gemm_out o{};
     o.queues = (uint2*)b.d_queues;
     o.counts = b.d_counts;
@@ -786,6 +830,28 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
         LS_HIP(hipGetLastError());                                                                \
         return LS_OK;                                                                             \
     }
+#define LS_GEMM_LAUNCH_RS2(C, MODE, TOPN, NT)                                                     \
+    {                                                                                             \
+        auto kern = ls_gemm_filter_rs2_kernel<C, TOPN, NT, MODE>;                                 \
+        static ls_attr_once once;                                                                 \
+        if (int rc = ls_set_max_dynamic_lds(once, (const void*)kern, LS_GEMM_LDS_BYTES)) return rc; \
+        hipExtLaunchKernelGGL(kern, grid, dim3(LS_GEMM_THREADS), smem, s, ev_start, ev_stop, 0,   \
+                              (const u32x4*)d_corpus, (long long)n, (const u32x4*)d_qh, (int)nq,  \
+                              nqt, d_tau, (long long)rows_per_split, tile_stride, o);             \
+        LS_HIP(hipGetLastError());                                                                \
+        return LS_OK;                                                                             \
+    }
+    if (gemm_is_qg4(g)) {  // 48-chunk rows, 64 queries per wave, rows split over wave pairs
+        if (fz) {
+            ls_set_error("batched path: the row-split shape has no fused launch");
+            return LS_ERR_INVALID_ARG;
+        }
+        if (d_tau && nqt == 1) LS_GEMM_LAUNCH_RS2(48, LS_GEMM_PASS, 4, true)
+        else if (d_tau) LS_GEMM_LAUNCH_RS2(48, LS_GEMM_PASS, 4, false)
+        else if (sample_top2) LS_GEMM_LAUNCH_RS2(48, LS_GEMM_SAMPLE, 2, false)
+        else LS_GEMM_LAUNCH_RS2(48, LS_GEMM_SAMPLE, 4, false)
+    }
+#undef LS_GEMM_LAUNCH_RS2
 #define LS_GEMM_TOP2(C) (C / 4 * gemm_qg(C) * 4 >= 128 && sample_top2)
 // (the fused launch exists for the two-accumulator geometries only: rows of up to 768 bytes. The
 // register-starved ones spend ~1 % of a multi-millisecond batch outside the pass; a forced fused run of

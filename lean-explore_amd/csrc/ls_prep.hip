@@ -134,6 +134,7 @@ int ls_pick_geom(int32_t d, int32_t dtype, ls_geom* g) {
             g->L = sizes[i][1];
             g->V = sizes[i][2];
             g->elem = elem;
+            g->qg4 = 0;
             g->d_pad = g->chunks * per;
             return LS_OK;
         }

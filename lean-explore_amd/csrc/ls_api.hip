@@ -215,15 +215,19 @@ void ls_destroy(ls_index* ix) {
         if (h.h_out_g) (void)hipHostFree(h.h_out_g);
         if (h.h_out_s) (void)hipHostFree(h.h_out_s);
         if (h.h_out_i) (void)hipHostFree(h.h_out_i);
+        if (h.stream) {
+            (void)hipStreamSynchronize(h.stream);
+            (void)hipStreamDestroy(h.stream);
+        }
     }
     for (auto& st : ix->sets) {
         (void)hipFree(st.d_S);
         (void)hipFree(st.d_cand);
         (void)hipFree(st.d_bound);
         (void)hipFree(st.d_gran);
+        (void)hipFree(st.d_qpad);
     }
     (void)hipFree(ix->d_counters);
-    (void)hipFree(ix->d_qpad);
     for (hipStream_t cs : {ix->chain_main[0], ix->chain_main[1], ix->chain_sel})
         if (cs) (void)hipStreamSynchronize(cs);
     for (auto& st : ix->bc_sets) {
@@ -397,12 +401,8 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
     // while group i's scan fills B). The last group's finalizes are "pending": they ride on the
     // next call's first scan (LS_FLAG_PIPELINE) or are launched on their own right away.
     const bool pipeline = (flags & LS_FLAG_PIPELINE) != 0;
-    // The two scratch generations are ordered by stream order only: a call on another stream
-    // first waits (on the host) for whatever the previous stream still runs on them.
-    if (ix->scan_used && ix->last_scan_stream != s && !(ix->n_pending && ix->pending_stream != s))
-        LS_HIP(hipStreamSynchronize(ix->last_scan_stream));
-    ix->scan_used = true;
-    ix->last_scan_stream = s;
+    // A scratch generation is ordered by stream order only: a launch that uses it on another stream than
+    // its previous user first waits (on the host) for that stream (per generation, below).
     if (ix->n_pending && (ix->pending_stream != s || !ix->opt_overlap)) {
         hipStream_t old = ix->pending_stream;
         rc = ls_i_flush_pending(ix);
@@ -431,6 +431,8 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         }
         const int gen = ix->force_gen >= 0 ? ix->force_gen : (int)(ix->set_rr++ % LS_NSETS);
         ls_index::scratch_set& st = ix->sets[gen];
+        if (st.last_stream && st.last_stream != s) LS_HIP(hipStreamSynchronize(st.last_stream));
+        st.last_stream = s;
         if (ix->n_pending && ix->n <= 0) {  // an empty index launches no scan to ride on
             rc = ls_i_flush_pending(ix);
             if (rc != LS_OK) return rc;
@@ -450,7 +452,8 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         const bool same_launch =
             !pipeline && ix->n > 0 && ix->opt_same_launch != 0 && ix->done_base != nullptr &&
             n_groups <= LS_NSETS &&
-            s == ix->own_stream && keff <= 256 &&  // (k > 256 orders its result on 1024 threads: own launch)
+            (s == ix->own_stream || s == ix->hs[0].stream || s == ix->hs[1].stream) &&  // (the library's own streams)
+            keff <= 256 &&  // (k > 256 orders its result on 1024 threads: own launch)
             (int64_t)blocks * (kprime + 1) <= LS_GRAN_MAX &&
             ls_fin_lds_bytes_host(own_keys_cap, (int)std::max<int64_t>(keff, 1)) <= LS_PIGGY_LDS_MAX;
         if (ix->n_pending && same_launch) {  // left by an earlier pipelined call: its own launch
@@ -470,13 +473,13 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         // padded query slots re-read the last real query (their results are never finalised)
         const float* qsrc = d_q + q0 * g.d;
         if (real < NQ) {  // (never for an ls_mq launch: it takes the real count)
-            rc = ls_grow(&ix->d_qpad, &ix->qpad_cap, (size_t)LS_QUERIES_PER_LAUNCH_MAX * g.d);
+            rc = ls_grow(&st.d_qpad, &st.qpad_cap, (size_t)LS_QUERIES_PER_LAUNCH_MAX * g.d);
             if (rc != LS_OK) return rc;
             for (int i = 0; i < NQ; ++i)
-                LS_HIP(hipMemcpyAsync(ix->d_qpad + (size_t)i * g.d,
+                LS_HIP(hipMemcpyAsync(st.d_qpad + (size_t)i * g.d,
                                       d_q + (q0 + std::min(i, real - 1)) * g.d,
                                       sizeof(float) * g.d, hipMemcpyDefault, s));
-            qsrc = ix->d_qpad;
+            qsrc = st.d_qpad;
         }
         a.d_q = qsrc;
         a.nq = NQ;
@@ -1102,6 +1105,7 @@ struct ls_host_call {
     float* out_scores = nullptr;
     int64_t* out_indices = nullptr;
     bool group = false, spin = false, out_direct = false, queued = false;
+    hipStream_t stream = nullptr;
     int rc = LS_OK;
 };
 
@@ -1148,7 +1152,11 @@ static int host_call_begin_impl(ls_host_call& c) {
     ls_host_slot& S = ix->hs[si];
     c.S = &S;
     LS_HIP(hipSetDevice(ix->device));
-    hipStream_t s = ix->own_stream;
+    if (overlapped && !S.stream) LS_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    // an overlapped call runs on its slot's stream: the next call's scan workgroups move onto the CUs as this
+    // call's retire, under its selection workgroup and its tail (one stream would order kernel behind kernel)
+    hipStream_t s = overlapped ? S.stream : ix->own_stream;
+    c.stream = s;
     if ((rc = ls_grow(&S.d_qraw, &S.qraw_cap, qn)) != LS_OK) return c.rc = rc;
     if ((rc = ls_grow_pinned(&S.h_q, &S.h_q_cap, qn)) != LS_OK) return c.rc = rc;
     if (on > S.out_cap) {
@@ -1238,7 +1246,7 @@ static int host_call_finish(ls_host_call& c) {
     const int64_t nq = c.nq;
     const int32_t k = c.k;
     const size_t on = (size_t)nq * k;
-    hipStream_t s = ix->own_stream;
+    hipStream_t s = c.stream;
     float* out_scores = c.out_scores;
     int64_t* out_indices = c.out_indices;
     const int64_t base = ix->base;  // (ls_set_base waits for the calls in flight)

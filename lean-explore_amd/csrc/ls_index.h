@@ -38,6 +38,8 @@ struct ls_req;          // ls_api.hip: one queued synchronous host search
 // Lock order: slot mutex(es) first, then ls_index::mu.
 struct ls_host_slot {
     std::mutex mu;  // held from the enqueue until the results have been handed back
+    hipStream_t stream = nullptr;  // overlapped calls run on their slot's own stream: the next call's scan starts
+                                   // while this call's selection workgroup and tail are still running
     float* h_q = nullptr;      size_t h_q_cap = 0;      // pinned query copy (the kernels may read it directly)
     float* d_qraw = nullptr;   size_t qraw_cap = 0;     // device query copy (floats)
     float* d_out_s = nullptr;  int64_t* d_out_i = nullptr;  size_t out_cap = 0;  // nq*k (large results)
@@ -84,9 +86,11 @@ struct ls_index {
         u64* d_bound = nullptr;      // max_blocks
         void* d_gran = nullptr;      // same-launch selection: LS_QUERIES_PER_LAUNCH_MAX * LS_GRAN_MAX tagged
                                      // 16-byte granules (ls_fin_params::gran), allocated at first use
+        float* d_qpad = nullptr;     // padded query group of a ragged VALU group (8 x d floats)
+        size_t qpad_cap = 0;
+        hipStream_t last_stream = nullptr;  // stream of the last launch that used this generation: a launch
+                                            // on another stream first waits (on the host) for that one
     } sets[LS_NSETS];
-    hipStream_t last_scan_stream = nullptr;
-    bool scan_used = false;
     uint64_t set_rr = 0;
     int32_t last_set = 0;
     // batched (MFMA) path scratch, allocated on first use. Set 0 serves plain calls on the
@@ -170,7 +174,6 @@ struct ls_index {
     int n_pending = 0;                 // queries whose finalize has not been launched yet
     ls_fin_batch pending{};
     hipStream_t pending_stream = nullptr;
-    float* d_qpad = nullptr; size_t qpad_cap = 0;  // padded query group (ragged last group)
     long long s_stride = 0;            // floats between the score vectors of one generation
     int32_t opt_multi_query = 1;       // several queries per corpus pass (groups of 8 / 4)
     int32_t opt_mq = 1;                // fp32 index: 2..16 queries per pass on the f32 matrix cores (ls_mq.hip)

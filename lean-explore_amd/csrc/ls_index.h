@@ -70,6 +70,8 @@ struct ls_index {
     std::atomic<uint64_t> q_epoch{0};  // bumped whenever the queue's state changes (leadership free, results handed back)
     int32_t calls_in_flight = 0;       // batches queued whose results have not been handed back yet (under q_mu)
     int64_t requests_in_flight = 0;    // ... and the requests in them
+    int64_t peak_callers = 0;          // decaying maximum of (requests in flight + queued): the callers around lately
+    uint32_t peak_decay = 0;
     int32_t opt_combine = 1;
     uint64_t n_combined_batches = 0, n_combined_requests = 0;
     // non-null: this handle is a row-sharded GROUP (ls_create_sharded): `n`, `dtype`, `g` and

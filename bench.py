@@ -659,6 +659,52 @@ def run_host_api(env: Env, workload: str, calls: int = 300) -> dict:
                     "and stream sync inside the timed call"}
 
 
+def run_callers(env: Env, workload: str = "c2", secs: float = 0.6) -> dict:
+    """T threads of synchronous single-query ls_search on ONE handle (an MCP server with several clients,
+    reference mcp/server.py:147-151 -> search/engine.py:250): queries/s and p50 latency for T = 1, 2, 4, 8, 16.
+    Concurrent requests are combined into shared corpus passes (fp32: csrc/ls_mq.hip, bit-identical rows) and
+    overlap two deep on the handle's two host slots; tools/concurrent_callers.py A/Bs the mechanisms."""
+    import threading
+
+    from lean_explore_amd.index import FlatIPIndex
+
+    n, d, dtype, _, k = WORKLOADS[workload]
+    corpus = gauss(1234, n, d)
+    q = gauss(5678, 16, d)
+    ix = FlatIPIndex.from_array(corpus, dtype=dtype, device=env.device_index)
+    del corpus
+    for _ in range(50):
+        ix.search(q[:1], k, normalize=True)
+    out = {"workload": f"{workload}: N={n} d={d} {dtype} k={k}, one query per call", "seconds_per_point": secs}
+    for T in (1, 2, 4, 8, 16):
+        counts, lats = [0] * T, [[] for _ in range(T)]
+        stop = [0.0]
+
+        def w(t):
+            qq = q[t:t + 1]
+            while time.perf_counter() < stop[0]:
+                t0 = time.perf_counter()
+                ix.search(qq, k, normalize=True)
+                lats[t].append(time.perf_counter() - t0)
+                counts[t] += 1
+
+        th = [threading.Thread(target=w, args=(t,)) for t in range(T)]
+        t0 = time.perf_counter()
+        stop[0] = t0 + secs
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt = time.perf_counter() - t0
+        allat = np.concatenate([np.asarray(l) for l in lats])
+        out[f"callers_{T}"] = {"queries_per_s": round(sum(counts) / dt, 1), "p50_us": round(float(np.median(allat)) * 1e6, 1)}
+    out["combined_batches"] = ix.debug_counter(16)
+    out["requests_in_combined_batches"] = ix.debug_counter(17)
+    out["overlapped_calls"] = ix.debug_counter(24)
+    ix.close()
+    return out
+
+
 def run_bm25(n_docs: int = 200_000, k: int = 1000, calls: int = 300) -> dict:
     """BM25+ name retrieval (reference search/engine.py:192-223; bm25s's eager-sparse
     scoring) on the HIP kernels: one 3-token query over `n_docs` synthetic declaration names, synchronous
@@ -795,6 +841,10 @@ def main():
     host_api = None
     if not args.no_host_api and env.n_gpus == 1 and args.workload == "c2" and env.rank == 0:
         host_api = {w: run_host_api(env, w) for w in ("c2", "c2p")}
+        try:
+            host_api["concurrent_callers"] = run_callers(env, "c2")
+        except Exception as e:
+            host_api["concurrent_callers"] = {"error": repr(e)}
 
     if env.rank == 0:
         out = {

@@ -115,3 +115,11 @@ def test_default_line_carries_both_metric_halves_and_host_api():
     assert 0.0 < c3["roofline"]["frac_whole_batch"] <= c3["roofline"]["frac"] <= 1.0
     for w in ("c2", "c2p"):
         assert out["host_api"][w]["us_per_call_mean"] > 0
+    # round 5: the zero-excuse parity block on the timed arrays, the 8-queries-per-pass shapes, concurrent callers
+    assert out["parity"]["kernel_order_mismatches"] == 0 and out["parity"]["bit_identical_queries"] == 1
+    for w in ("c2x8", "c2px8"):
+        x = out["secondary"][w]
+        assert x["recall_at_k"] == 1.0 and x["roofline"]["kernel"] == "ls_mq_kernel"
+        assert x["parity"]["kernel_order_mismatches"] == 0 and x["parity"]["bit_identical_queries"] == 8
+    cc = out["host_api"]["concurrent_callers"]
+    assert cc["callers_2"]["queries_per_s"] > cc["callers_1"]["queries_per_s"] and cc["overlapped_calls"] > 0

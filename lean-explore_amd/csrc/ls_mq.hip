@@ -389,7 +389,23 @@ int ls_mq_blocks(int64_t n, int32_t n_cu) {
     //  256 workgroups 60.3 / 128.6 / 167.0 us, 448: 67.2 / 140.9 / 179.7, 512: 65.0 / 137.0 / 176.9,
     //  768: 65.9 / 140.3 / 181.0 - four waves per CU with 12-16 KB in flight each already carry the HBM
     //  stream; more streams only add DRAM page conflicts and a longer tail)
-    return (int)std::max<int64_t>(std::min<int64_t>(b, n_cu), 1);
+    if (b <= n_cu) return (int)std::max<int64_t>(b, 1);
+    // ... and among the counts in [0.92, 1] x CUs the one whose last round of tiles is the fullest (12 500 tiles
+    // over 256 x 4 waves are 12.2 rounds: a fifth of the waves then runs a 13th tile alone; 241 workgroups make
+    // it 12.97). Same box, 16 queries: 256 -> 241-250 workgroups 61.6 -> 59.4 us (d = 384), 142.3 -> 133.9 (d = 768),
+    // 166.8 -> 167.7-170.5 (d = 1024: within the noise).
+    int64_t best = n_cu;
+    double best_fill = -1.0;
+    for (int64_t c = n_cu; c >= (int64_t)n_cu * 92 / 100; --c) {
+        const double rounds = (double)NT / (double)(c * LS_MQ_WAVES);
+        double fill = rounds - (double)(int64_t)rounds;
+        if (fill == 0.0) fill = 1.0;
+        if (fill > best_fill + 0.02) {  // near-ties go to the larger count
+            best_fill = fill;
+            best = c;
+        }
+    }
+    return (int)best;
 }
 
 // keys a lane keeps: the smallest of {3, 5, 8} for which "some lane of the launch holds that many of one

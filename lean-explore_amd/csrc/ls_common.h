@@ -156,11 +156,32 @@ static inline int ls_set_max_dynamic_lds(ls_attr_once& st, const void* fn, int b
 // butterfly 32, 16, 8, 4, 2, 1 (every lane ends with the same value). Every kernel that
 // normalises a query calls this, so a normalised query is bit-identical on every path.
 #ifdef __HIPCC__
+// v[lane] + v[lane ^ 32], then ^ 16, 8, 4, 2, 1 - the same pairs as a __shfl_xor butterfly (so the same
+// bits: an IEEE add is commutative), without its six ds_bpermute round trips through the LDS crossbar
+// (~120 cycles each for a wave that waits for nothing else): v_permlane32_swap / v_permlane16_swap
+// across the 16-lane rows, DPP inside them (lane ^ 8 = row_ror:8; lane ^ 4 = row_shl:4 into lanes 0-3 and
+// 8-11 + row_shr:4 into lanes 4-7 and 12-15; quad_perm for ^ 2 and ^ 1). Whole wave active.
+__device__ __forceinline__ float ls_wave_xor_sum(float f) {
+    unsigned v = __builtin_bit_cast(unsigned, f);
+    auto add = [](unsigned a, unsigned b) -> unsigned {
+        return __builtin_bit_cast(unsigned, __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b));
+    };
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    v = add((unsigned)r[0], (unsigned)r[1]);
+    r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = add((unsigned)r[0], (unsigned)r[1]);
+    v = add(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true));  // row_ror:8
+    int x4 = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0x5, false);             // row_shl:4 -> banks 0, 2
+    x4 = __builtin_amdgcn_update_dpp(x4, (int)v, 0x114, 0xf, 0xa, false);                // row_shr:4 -> banks 1, 3
+    v = add(v, (unsigned)x4);
+    v = add(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));   // lane ^ 2
+    v = add(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));   // lane ^ 1
+    return __builtin_bit_cast(float, v);
+}
 __device__ __forceinline__ float ls_wave_sumsq(const float* __restrict__ x, int d, int lane) {
     float ss = 0.0f;
     for (int j = lane; j < d; j += 64) ss = fmaf(x[j], x[j], ss);
-    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    return ss;
+    return ls_wave_xor_sum(ss);
 }
 #endif
 

@@ -144,50 +144,63 @@ __global__ __launch_bounds__(LS_MQ_THREADS, 2) void ls_mq_kernel(
         const long long tc = tile < NT ? tile : NT - 1;  // a prefetch past the wave's last tile re-reads it
         return corpus + (tc * 16 + li) * CH + kq;
     };
-    // the first P units fly while the queries are prepared
+
+    // ---- queries -> LDS in MFMA B layout, faiss.normalize_L2 fused (reference engine.py:242) exactly as
+    // in ls_scan_kernel: canonical wave sum of squares (ls_wave_sumsq's order: lane l sums x[l], x[l+64], ..
+    // by fused multiply-adds, then the xor tree 32..1), one correctly rounded 1/sqrt, one multiply per
+    // element. Unused query columns (>= nq) and the row padding are zero. A wave stages queries
+    // 4 wave .. 4 wave + 3: all their loads are issued before the first is used (one memory round trip
+    // instead of one per query: 10.7 -> ~3 us at nq = 16, tools/mq_phases.py), and in FRONT of the corpus
+    // ring's first loads - vector memory returns in order, and the queries (L2 hits for all but the first
+    // workgroup) would otherwise arrive behind a cold HBM round trip. The ring's first P units then fly
+    // while the queries are normalised and written.
+    constexpr int EPL = CH * 4 / 64;             // elements per lane and query
+    constexpr int QPW = LS_MQ_NQ / LS_MQ_WAVES;  // queries per wave
+    static_assert(QPW == 4, "one 16-byte LDS write per element");
+    float xq[QPW][EPL];
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) {
+        const int qi = QPW * wave + j;
+        const float* src = qraw + (long long)(qi < nq ? qi : 0) * d;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+            const int e = lane + 64 * i;
+            xq[j][i] = src[e < d ? e : d - 1];  // (unconditional loads; masked below)
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     mq_f32x4 ring[P];
     {
         const mq_f32x4* p0 = tile_ptr(t);
 #pragma unroll
         for (int u = 0; u < P; ++u) ring[u] = __builtin_nontemporal_load(p0 + unit_chunk(u));
     }
-
-    // ---- queries -> LDS in MFMA B layout, faiss.normalize_L2 fused (reference engine.py:242) exactly as
-    // in ls_scan_kernel: canonical wave sum of squares (ls_wave_sumsq's order: lane l sums x[l], x[l+64], ..
-    // by fused multiply-adds, then the xor tree 32..1), one correctly rounded 1/sqrt, one multiply per
-    // element. Unused query columns (>= nq) and the row padding are zero. A wave stages queries
-    // wave, wave+4, ..: all their loads are issued before the first is used (one memory round trip
-    // instead of one per query: 10.7 -> ~3 us at nq = 16, tools/mq_phases.py).
+    __builtin_amdgcn_sched_barrier(0);
     {
-        constexpr int EPL = CH * 4 / 64;             // elements per lane and query
-        constexpr int QPW = LS_MQ_NQ / LS_MQ_WAVES;  // queries per wave
-        float xq[QPW][EPL];
+        float inv[QPW];
 #pragma unroll
         for (int j = 0; j < QPW; ++j) {
-            const int qi = wave + LS_MQ_WAVES * j;
-            const float* src = qraw + (long long)(qi < nq ? qi : 0) * d;
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) {
-                const int e = lane + 64 * i;
-                xq[j][i] = (qi < nq && e < d) ? src[e] : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < QPW; ++j) {
-            const int qi = wave + LS_MQ_WAVES * j;
-            float inv = 1.0f;
+            for (int i = 0; i < EPL; ++i)
+                if (QPW * wave + j >= nq || lane + 64 * i >= d) xq[j][i] = 0.0f;
+            inv[j] = 1.0f;
             if (normalize) {
                 float ss = 0.0f;
 #pragma unroll
                 for (int i = 0; i < EPL; ++i) ss = fmaf(xq[j][i], xq[j][i], ss);  // (zeros past d add nothing)
-                for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-                if (ss > 0.0f) inv = 1.0f / sqrtf(ss);
+                ss = ls_wave_xor_sum(ss);
+                if (ss > 0.0f) inv[j] = 1.0f / sqrtf(ss);
             }
+        }
+        // element e of the wave's four consecutive queries: ONE 16-byte LDS write (the four-byte form put the
+        // 64 lanes of a write on 4 banks)
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) {
-                const int e = lane + 64 * i;
-                Bs[(e >> 2) * 64 + (e & 3) * 16 + qi] = xq[j][i] * inv;
-            }
+        for (int i = 0; i < EPL; ++i) {
+            const int e = lane + 64 * i;
+            mq_f32x4 w4;
+#pragma unroll
+            for (int j = 0; j < QPW; ++j) w4[j] = xq[j][i] * inv[j];
+            *reinterpret_cast<mq_f32x4*>(&Bs[(e >> 2) * 64 + (e & 3) * 16 + QPW * wave]) = w4;
         }
     }
     __syncthreads();
@@ -257,7 +270,15 @@ __global__ __launch_bounds__(LS_MQ_THREADS, 2) void ls_mq_kernel(
 #endif
 
         const long long row0 = t * 16 + 4 * kq;
-        if (live_q) {
+        // the score vector (what the selection's rescue sweeps). S == nullptr: the caller repairs a query whose
+        // workgroup keys cannot be proven complete by serving it again on the single-query path (ls_api.hip).
+        // What these stores cost is paid in the memory system, per write request, once the corpus no longer
+        // fits the Infinity Cache: N = 200 k, d = 1024: 136 us without them for any query count, 140 / 144 /
+        // 155 / 167 us with 2 / 4 / 8 / 16 queries (200 k half-line writes at 16: TCC_EA0_WRREQ_64B,
+        // tools/mq_pmc.sh); d = 384 (307 MB): 54 -> 57.5 us. Tried, same times: a fifth wave that only stores
+        // (fed through LDS: the scanning waves' in-order vmcnt never sees a store), quad-coalesced stores,
+        // adjacent tiles paired into whole 128-byte lines per query (docs/EXPERIMENTS.md, round 5).
+        if (live_q && S) {
             float* sp = S + (long long)li * s_stride + row0;
             if (row0 + 3 < n) {
                 *reinterpret_cast<mq_f32x4*>(sp) = sc;  // s_stride is a multiple of 64 floats
@@ -292,9 +313,17 @@ __global__ __launch_bounds__(LS_MQ_THREADS, 2) void ls_mq_kernel(
     // sequence, re-sorted by a small network), min(A[i], B[M-1-i]) are the keys that leave - and carry a
     // bound: the best key dropped anywhere below (a lane's own drops lie under its last key).
     u64 bnd = lst[M - 1];
+    // (lane ^ 16 / lane ^ 32 by v_permlane16_swap / v_permlane32_swap: no LDS crossbar round trips)
+    auto xor_lanes32 = [&](u32 v, int mask) -> u32 {
+        if (mask == 32) {
+            const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+            return lane < 32 ? (u32)r[1] : (u32)r[0];
+        }
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? (u32)r[0] : (u32)r[1];
+    };
     auto xor_lanes64 = [&](u64 v, int mask) -> u64 {
-        const u32 lo = (u32)__shfl_xor((int)(u32)v, mask, 64), hi = (u32)__shfl_xor((int)(u32)(v >> 32), mask, 64);
-        return ((u64)hi << 32) | lo;
+        return ((u64)xor_lanes32((u32)(v >> 32), mask) << 32) | xor_lanes32((u32)v, mask);
     };
 #pragma unroll
     for (int mask = 16; mask <= 32; mask <<= 1) {

@@ -450,7 +450,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         // caller's stream may be CU-masked, and device-output calls have no way to ask for a retry.
         const int own_keys_cap = std::max(256, blocks * kprime);
         const bool same_launch =
-            !pipeline && ix->n > 0 && ix->opt_same_launch != 0 && ix->done_base != nullptr &&
+            !pipeline && ix->n > 0 && ix->opt_same_launch != 0 && !ix->reserving && ix->done_base != nullptr &&
             n_groups <= LS_NSETS &&
             (s == ix->own_stream || s == ix->hs[0].stream || s == ix->hs[1].stream) &&  // (the library's own streams)
             keff <= 256 &&  // (k > 256 orders its result on 1024 threads: own launch)
@@ -485,7 +485,14 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         a.nq = NQ;
         a.normalize = normalize;
         a.reverse = ix->opt_alternate && (ix->sweep_count++ & 1);
-        a.d_S = st.d_S;
+        // An ls_mq launch whose selection jobs ride along (synchronous host calls) writes NO score vectors: such
+        // a job never reads S inside the launch anyway (it answers LS_DONE_RETRY), and its retry serves the
+        // query again, alone, on the scan kernel - the same bits (host_call_finish). The 16 x n x 4 bytes of
+        // stores cost 3 us of 57 (d = 384) and 4..29 us of 140..167 (d = 1024, 2..16 queries) at N = 200 k.
+        // (k > 256: the selection has its own launch behind the pass; without S it answers the same way)
+        const bool host_words = !pipeline && ix->done_base != nullptr && ix->cur_retry != nullptr && !ix->reserving;
+        const bool skip_scores = use_mq && (same_launch || host_words) && ix->opt_mq_skip_scores;
+        a.d_S = skip_scores ? nullptr : st.d_S;
         a.s_stride = ix->s_stride;
         a.d_cand = st.d_cand;
         a.c_stride = (long long)ix->max_blocks * LS_KP_MAX;
@@ -509,7 +516,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         }
         for (int i = 0; i < real; ++i) {
             ls_fin_params& p = jobs.p[i];
-            p.S = st.d_S + (size_t)i * a.s_stride;
+            p.S = skip_scores ? nullptr : st.d_S + (size_t)i * a.s_stride;
             p.n = ix->n;
             p.cand = st.d_cand + (size_t)i * a.c_stride;
             p.bound = st.d_bound + (size_t)i * a.b_stride;
@@ -528,7 +535,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             p.gran = same_launch ? (const char*)st.d_gran + (size_t)i * LS_GRAN_MAX * 16 : nullptr;
             p.tag = same_launch ? ix->gran_tag : 0u;
             p.wait = same_launch ? 1u : 0u;
-            if (same_launch && ix->cur_retry) ix->cur_retry->push_back(p);  // kept until the host has seen the answers
+            if ((same_launch || skip_scores) && ix->cur_retry) ix->cur_retry->push_back(p);  // kept until the host has seen the answers
         }
         if (prof) LS_HIP(hipEventRecord(pe[0], s));
         rc = use_mq ? ls_launch_mq(ix->d_corpus, ix->n, g, a, s) : ls_launch_scan(ix->d_corpus, ix->n, g, a, s);
@@ -1107,6 +1114,7 @@ struct ls_host_call {
     bool group = false, spin = false, out_direct = false, queued = false;
     hipStream_t stream = nullptr;
     int rc = LS_OK;
+    int gen = -1;  // the scratch generation an overlapped call was given (ls_index::force_gen)
 };
 
 static int host_call_begin_impl(ls_host_call& c) {
@@ -1204,7 +1212,7 @@ static int host_call_begin_impl(ls_host_call& c) {
     }
     ix->cur_retry = &S.retry_jobs;
     ix->cur_done_seq = S.done_seq;
-    ix->force_gen = overlapped ? (int)si : -1;
+    ix->force_gen = c.gen = overlapped ? (int)si : -1;
     rc = ls_i_search_on_stream(ix, in_direct ? S.h_q : S.d_qraw, nq, k, c.flags & LS_FLAG_NORMALIZE,
                                c.out_direct ? S.h_out_s : S.d_out_s, c.out_direct ? S.h_out_i : S.d_out_i, s, true);
     ix->done_base = nullptr;
@@ -1325,6 +1333,28 @@ static int host_call_finish(ls_host_call& c) {
             for (const ls_fin_params& p : S.retry_jobs) {
                 const int64_t qi = p.done - S.h_done;
                 if (qi < 0 || qi >= nq || S.h_done[qi] != (S.done_seq | LS_DONE_RETRY)) continue;
+                if (!p.S) {
+                    // the job rode on an ls_mq launch that wrote no score vectors: serve the query again, alone
+                    // (scan kernel: the same bits; its selection gets its own launch and answers through the
+                    // same completion word / granules). The call still owns its slot: the query copy is intact.
+                    if ((rc = flush()) != LS_OK) return rc;
+                    ix->done_base = S.h_done + qi;
+                    ix->gran_out_base = k <= LS_OUT_GRAN_MAX_K ? S.h_out_g + (size_t)qi * k : nullptr;
+                    ix->cur_retry = nullptr;
+                    ix->cur_done_seq = S.done_seq;
+                    ix->force_gen = c.gen;
+                    ix->reserving = true;
+                    rc = ls_i_search_on_stream(ix, S.d_qraw + (size_t)qi * ix->g.d, 1, k, c.flags & LS_FLAG_NORMALIZE,
+                                               (c.out_direct ? S.h_out_s : S.d_out_s) + (size_t)qi * k,
+                                               (c.out_direct ? S.h_out_i : S.d_out_i) + (size_t)qi * k, s, true);
+                    ix->reserving = false;
+                    ix->done_base = nullptr;
+                    ix->gran_out_base = nullptr;
+                    ix->force_gen = -1;
+                    if (rc != LS_OK) return rc;
+                    ix->n_mq_reserved++;
+                    continue;
+                }
                 jobs.p[nj] = p;
                 jobs.p[nj].wait = 0;  // behind the kernel boundary every granule is there
                 jobs.p[nj].keys_cap = LS_FINAL_CAP;
@@ -1857,6 +1887,10 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->g.qg4 = value != 0;
         return LS_OK;
     }
+    if (which == 19) {  // ls_mq launches of synchronous host calls write no score vectors (default on)
+        ix->opt_mq_skip_scores = value != 0;
+        return LS_OK;
+    }
     if (which == 17) {  // synchronous host calls overlap two deep (default on)
         ix->opt_overlap_calls = value != 0;
         return LS_OK;
@@ -1933,7 +1967,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 24) return -1;
+    if (!ix || which < 0 || which > 25) return -1;
     if (which == 16 || which == 17) {
         std::lock_guard<std::mutex> ql(ix->q_mu);
         return (int64_t)(which == 16 ? ix->n_combined_batches : ix->n_combined_requests);
@@ -1949,6 +1983,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
     if (which == 22) return (int64_t)ix->n_forced_checks;
     if (which == 23) return (int64_t)ix->n_mq_launches;
     if (which == 24) return (int64_t)ix->n_overlapped_calls;
+    if (which == 25) return (int64_t)ix->n_mq_reserved;
     if (which > 9) return 0;  // 13..15, 18, 19 and 21 are group counters
     if (hipSetDevice(ix->device) != hipSuccess) return -1;
     u32 v = 0;

@@ -98,7 +98,9 @@ def test_mq_integer_corpus_ties_and_clusters():
     ix = FlatIPIndex.from_array(c)
     D, I = ix.search(q, 200)
     oracle.compare_kernel_order(D, I, c, q, 200, orders=("scan",))
-    assert ix.debug_counter(0) >= 1, "the sorted corpus should have forced the exact slow path"
+    # (host call: the launch wrote no score vectors, the unproven queries were served again on the scan kernel -
+    # counter 25 - whose own selection may or may not need its slow path - counter 0)
+    assert ix.debug_counter(0) + ix.debug_counter(25) >= 1, "the sorted corpus should have forced a repair"
     ix.close()
     c2 = H.gauss(8, 10_000, 64)
     c2[10, 0] = np.nan
@@ -148,4 +150,28 @@ def test_one_query_per_launch_with_many_groups_keeps_its_retries_straight():
     ix.debug_option(0, 1)
     D, I = ix.search(q, 100)
     oracle.compare_kernel_order(D, I, c, q, 100, orders=("scan",))
+    ix.close()
+
+
+def test_host_calls_without_score_vectors_are_served_again_when_unproven():
+    """Synchronous host calls (the reference's call, engine.py:250, several callers combined): the ls_mq launch
+    writes no score vectors (debug option 19); a query whose workgroup keys cannot be proven complete - a
+    clustered corpus, k' forced to 1 - is served again, alone, on the scan kernel. Same bits either way."""
+    c = H.gauss(3, 60_000, 384)
+    q = H.gauss(4, 9, 384)
+    c = np.ascontiguousarray(c[np.argsort(c @ q[0])])
+    ix = FlatIPIndex.from_array(c)
+    D, I = ix.search(q, 100)
+    assert ix.debug_counter(25) >= 1, "the clustered query was not served again"
+    oracle.compare_kernel_order(D, I, c, q, 100, orders=("scan",))
+    ix.debug_option(0, 1)  # k' = 1: every query needs the repair
+    before = ix.debug_counter(25)
+    D1, I1 = ix.search(q, 100)
+    assert ix.debug_counter(25) >= before + 5
+    assert np.array_equal(D1, D) and np.array_equal(I1, I)
+    ix.debug_option(19, 0)  # with score vectors: the stand-alone selection repairs from S
+    before = ix.debug_counter(25)
+    D2, I2 = ix.search(q, 100)
+    assert ix.debug_counter(25) == before
+    assert np.array_equal(D2, D) and np.array_equal(I2, I)
     ix.close()

@@ -6,19 +6,7 @@ import numpy as np
 from lean_explore_amd.index import FlatIPIndex
 from tests import helpers as H
 
-def run(ix, q, k, T, secs=1.0):
-    counts = [0] * T; lats = [[] for _ in range(T)]; stop = time.perf_counter() + secs
-    def w(t):
-        qq = q[t:t + 1]
-        while time.perf_counter() < stop:
-            t0 = time.perf_counter(); ix.search(qq, k, normalize=True); lats[t].append(time.perf_counter() - t0); counts[t] += 1
-    th = [threading.Thread(target=w, args=(t,)) for t in range(T)]
-    t0 = time.perf_counter()
-    for x in th: x.start()
-    for x in th: x.join()
-    dt = time.perf_counter() - t0
-    allat = np.concatenate([np.asarray(l) for l in lats])
-    return sum(counts) / dt, np.median(allat) * 1e6
+from tools.concurrent_callers_lib import run
 
 for n in (200_000, 25_000):
     c = H.gauss(1234, n, 384); q = H.gauss(5678, 16, 384)

@@ -242,6 +242,9 @@ void ls_destroy(ls_index* ix) {
         (void)hipFree(st.d_sample_top);
     }
     for (float* b : ix->d_qkeep_blk) (void)hipFree(b);
+    (void)hipFree(ix->d_mq_keep);
+    (void)hipFree(ix->d_mq_flags);
+    if (ix->h_mq_flags) (void)hipHostFree(ix->h_mq_flags);
     (void)hipFree(ix->d_overflow);
     if (ix->h_overflow) (void)hipHostFree(ix->h_overflow);
     for (hipEvent_t e : ix->prof_ev) (void)hipEventDestroy(e);
@@ -364,6 +367,9 @@ static int64_t scan_group_count(const ls_index* ix, int64_t nq, int32_t k) {
     return groups;
 }
 
+#define LS_MQ_KEEP_SLOTS 256  // ls_mq launches without score vectors between two repairs (device-output calls)
+static int mq_repair(ls_index* ix);
+
 // Queue one search on stream `s` through the scan path. d_q: device fp32 [nq, d]; outputs
 // device [nq, k].
 static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
@@ -417,6 +423,11 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         const int NQ = use_mq ? (int)std::min<int64_t>(left, LS_QUERIES_PER_LAUNCH_MAX)
                               : (!ix->opt_multi_query ? 1 : (left >= 5 ? 8 : (left >= 2 ? 4 : 1)));
         const int real = (int)std::min<int64_t>(NQ, left);
+        if (use_mq && ix->dev_call_repairable && !ix->reserving &&
+            ((int)ix->mq_pend.size() >= LS_MQ_KEEP_SLOTS || (ix->d_mq_keep && ix->mq_keep_d != g.d))) {
+            rc = mq_repair(ix);  // the ring of kept queries is full: make what is pending final first
+            if (rc != LS_OK) return rc;
+        }
         const int blocks = use_mq ? mq_blocks : scan_blocks;
         const int kprime = use_mq ? mq_kprime : scan_kprime;
         const bool prof = ix->profiling && ix->prof_n < LS_PROF_MAX;
@@ -491,7 +502,27 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         // stores cost 3 us of 57 (d = 384) and 4..29 us of 140..167 (d = 1024, 2..16 queries) at N = 200 k.
         // (k > 256: the selection has its own launch behind the pass; without S it answers the same way)
         const bool host_words = !pipeline && ix->done_base != nullptr && ix->cur_retry != nullptr && !ix->reserving;
-        const bool skip_scores = use_mq && (same_launch || host_words) && ix->opt_mq_skip_scores;
+        // (device-output calls whose results ls_check may still repair: mq_repair; never a repair's own launch)
+        const bool dev_keep = use_mq && ix->dev_call_repairable && !ix->reserving && ix->done_base == nullptr &&
+                              ix->opt_mq_skip_scores && ix->n > 0;
+        const bool skip_scores = (use_mq && (same_launch || host_words) && ix->opt_mq_skip_scores) || dev_keep;
+        int keep_slot = -1;
+        if (dev_keep) {
+            if (!ix->d_mq_keep || ix->mq_keep_d != g.d) {
+                if (ix->d_mq_keep) (void)hipFree(ix->d_mq_keep);
+                ix->d_mq_keep = nullptr;
+                LS_HIP(hipMalloc((void**)&ix->d_mq_keep, sizeof(float) * (size_t)LS_MQ_KEEP_SLOTS * LS_QUERIES_PER_LAUNCH_MAX * g.d));
+                ix->mq_keep_d = g.d;
+            }
+            if (!ix->d_mq_flags) {
+                const size_t fb = sizeof(u32) * (size_t)LS_MQ_KEEP_SLOTS * LS_QUERIES_PER_LAUNCH_MAX;
+                LS_HIP(hipMalloc((void**)&ix->d_mq_flags, fb));
+                LS_HIP(hipMemset(ix->d_mq_flags, 0, fb));
+                LS_HIP(hipHostMalloc((void**)&ix->h_mq_flags, fb, hipHostMallocDefault));
+            }
+            keep_slot = (int)ix->mq_pend.size();
+            ix->mq_pend.push_back({keep_slot, real, k, flags, d_out_s + q0 * k, d_out_i + q0 * k, s});
+        }
         a.d_S = skip_scores ? nullptr : st.d_S;
         a.s_stride = ix->s_stride;
         a.d_cand = st.d_cand;
@@ -501,6 +532,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         a.blocks = blocks;
         a.kprime = kprime;
         a.mq_keys = mq_keys;
+        a.d_qkeep = keep_slot >= 0 ? ix->d_mq_keep + (size_t)keep_slot * LS_QUERIES_PER_LAUNCH_MAX * g.d : nullptr;
         ls_fin_batch& jobs = same_launch ? a.fin : ix->pending;
         if (same_launch) {
             if (!st.d_gran) {  // zeroed once: no granule of a later launch carries tag 0
@@ -535,6 +567,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             p.gran = same_launch ? (const char*)st.d_gran + (size_t)i * LS_GRAN_MAX * 16 : nullptr;
             p.tag = same_launch ? ix->gran_tag : 0u;
             p.wait = same_launch ? 1u : 0u;
+            p.repair = keep_slot >= 0 ? ix->d_mq_flags + (size_t)keep_slot * LS_QUERIES_PER_LAUNCH_MAX + i : nullptr;
             if ((same_launch || skip_scores) && ix->cur_retry) ix->cur_retry->push_back(p);  // kept until the host has seen the answers
         }
         if (prof) LS_HIP(hipEventRecord(pe[0], s));
@@ -567,9 +600,53 @@ bool ls_i_batched_eligible(const ls_index* ix, int64_t nq, int32_t k) {
     return nq >= LS_GEMM32_MIN_NQ && big;  // fp32: exact f32 MFMA (ls_gemm32.hip), any row length
 }
 
+// ls_mq launches of device-output calls that wrote no score vectors: every selection job that could not
+// prove its keys complete raised its word in d_mq_flags; those queries are served again here, alone, on the
+// scan kernel (the same bits), from the launch's own copy of the raw queries, into the call's output rows.
+// Synchronises the streams involved. No-op when nothing is pending.
+static int mq_repair(ls_index* ix) {
+    if (ix->mq_pend.empty()) return LS_OK;
+    if (int rc = ls_i_flush_pending(ix)) return rc;  // the youngest launch's selection jobs
+    std::vector<ls_index::mq_pending_call> pend;
+    pend.swap(ix->mq_pend);
+    hipStream_t last = pend.back().stream;
+    for (const auto& pc : pend)
+        if (pc.stream != last) LS_HIP(hipStreamSynchronize(pc.stream));
+    if (ix->pending_stream && ix->pending_stream != last) LS_HIP(hipStreamSynchronize(ix->pending_stream));
+    const size_t used = pend.size() * LS_QUERIES_PER_LAUNCH_MAX;
+    LS_HIP(hipMemcpyAsync(ix->h_mq_flags, ix->d_mq_flags, sizeof(u32) * used, hipMemcpyDeviceToHost, last));
+    LS_HIP(hipStreamSynchronize(last));
+    bool any = false;
+    const bool was = ix->reserving, rep = ix->dev_call_repairable;
+    ix->reserving = true;  // (its launches keep their score vectors and are final when they return)
+    ix->dev_call_repairable = false;
+    int rc = LS_OK;
+    for (const auto& pc : pend) {
+        const u32* fl = ix->h_mq_flags + (size_t)pc.slot * LS_QUERIES_PER_LAUNCH_MAX;
+        const float* qk = ix->d_mq_keep + (size_t)pc.slot * LS_QUERIES_PER_LAUNCH_MAX * ix->mq_keep_d;
+        for (int q = 0; q < pc.nq && rc == LS_OK; ++q) {
+            if (!fl[q]) continue;
+            any = true;
+            ix->n_mq_reserved++;
+            rc = scan_search_on_stream(ix, qk + (size_t)q * ix->mq_keep_d, 1, pc.k, pc.flags & LS_FLAG_NORMALIZE,
+                                       pc.d_out_s + (size_t)q * pc.k, pc.d_out_i + (size_t)q * pc.k, last);
+        }
+        if (rc != LS_OK) break;
+    }
+    ix->reserving = was;
+    ix->dev_call_repairable = rep;
+    if (rc != LS_OK) return rc;
+    if (any) {
+        LS_HIP(hipMemsetAsync(ix->d_mq_flags, 0, sizeof(u32) * used, last));
+        LS_HIP(hipStreamSynchronize(last));
+    }
+    return LS_OK;
+}
+
 // Re-run the queries of the pending batched calls whose candidate queues overflowed (or were
 // short) through the exact per-query scan path, from the calls' OWN query copies. Synchronises.
 int ls_i_batched_repair(ls_index* ix) {
+    if (int rc = mq_repair(ix)) return rc;
     if (int rc = ls_i_flush_deferred(ix)) return rc;
     if (ix->bc_pending.empty()) return LS_OK;
     std::vector<ls_index::batched_call> pend;
@@ -1595,10 +1672,17 @@ int ls_search_device(ls_index* ix, const void* d_q, int64_t nq, int32_t k, uint3
                                (int64_t*)d_out_indices, (hipStream_t)stream);
     LS_HIP(hipSetDevice(ix->device));
     hipStream_t s = (hipStream_t)stream;
+    // pipelined results are final after ls_check, synchronous ones when this returns: both leave room for the
+    // repair of an ls_mq launch without score vectors (mq_repair); LS_FLAG_ASYNC alone promises stream order
+    ix->dev_call_repairable = (flags & LS_FLAG_PIPELINE) || !(flags & LS_FLAG_ASYNC);
     rc = ls_i_search_on_stream(ix, (const float*)d_q, nq, k, flags, (float*)d_out_scores,
                           (int64_t*)d_out_indices, s, false);
+    ix->dev_call_repairable = false;
     if (rc != LS_OK) return rc;
-    if (!(flags & (LS_FLAG_ASYNC | LS_FLAG_PIPELINE))) LS_HIP(hipStreamSynchronize(s));
+    if (!(flags & (LS_FLAG_ASYNC | LS_FLAG_PIPELINE))) {
+        LS_HIP(hipStreamSynchronize(s));
+        if ((rc = mq_repair(ix)) != LS_OK) return rc;
+    }
     return LS_OK;
 }
 

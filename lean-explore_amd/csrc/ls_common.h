@@ -238,6 +238,10 @@ struct ls_fin_params {
     const void* gran;      // non-null: the candidates are granules (cand / bound unused)
     u32 tag;               // this launch's tag (never 0)
     u32 wait;              // 1: the granules are being written by this very launch: sweep for the tag
+    // An ls_mq launch that wrote no score vectors (S == nullptr) for a device-output call: a job whose keys
+    // cannot be proven complete raises this device word and leaves its output rows alone; ls_check (or the
+    // end of a synchronous call) serves the query again on the scan kernel (ls_api.hip mq_repair).
+    u32* repair;
 };
 struct ls_out_gran {   // host view of one result granule
     float score;
@@ -286,6 +290,7 @@ struct ls_scan_args {
     long long g_stride;    //           tagged granules (ls_fin_params::gran), g_stride granules per query
     u32 tag;
     int mq_keys;           // ls_launch_mq only: keys every lane keeps (ls_mq_lane_keys)
+    float* d_qkeep;        // ls_launch_mq only, optional: the launch copies its nq raw queries there (d floats apart)
 };
 int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const ls_scan_args& a,
                    hipStream_t s);

@@ -183,6 +183,24 @@ struct ls_index {
     int32_t opt_mq_skip_scores = 1;    // ... whose selection jobs ride along write no score vectors (debug option 19)
     uint64_t n_mq_reserved = 0;        // queries of such launches served again on the scan kernel (counter 25)
     bool reserving = false;            // (that second serve is being queued: its selection takes its own launch)
+    // ... and so do pipelined / synchronous DEVICE-output calls: the launch keeps its raw queries (slot of
+    // d_mq_keep), an unproven query raises its word in d_mq_flags, mq_repair (ls_check, the end of a
+    // synchronous call, ring full) serves it again in place. LS_FLAG_ASYNC alone keeps the score vectors:
+    // its results are promised in stream order.
+    struct mq_pending_call {
+        int slot, nq;
+        int32_t k;
+        uint32_t flags;
+        float* d_out_s;
+        int64_t* d_out_i;
+        hipStream_t stream;
+    };
+    std::vector<mq_pending_call> mq_pend;
+    float* d_mq_keep = nullptr;        // [LS_MQ_KEEP_SLOTS][16][mq_keep_d]
+    int32_t mq_keep_d = 0;
+    u32* d_mq_flags = nullptr;         // [LS_MQ_KEEP_SLOTS][16]
+    u32* h_mq_flags = nullptr;         // pinned mirror
+    bool dev_call_repairable = false;  // set by ls_search_device around a call whose results may be repaired later
     int32_t opt_query_copy = 0;        // synchronous host calls: 0 = the kernels read the pinned host copy over PCIe
                                        // themselves, 1 = a copy command brings the query to device memory first
     int32_t opt_same_launch = 1;       // synchronous host calls: the selection rides on its own query's scan launch

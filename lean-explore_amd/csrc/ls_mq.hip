@@ -81,7 +81,7 @@ __global__ __launch_bounds__(LS_MQ_THREADS, 2) void ls_mq_kernel(
     const mq_f32x4* __restrict__ corpus, long long n, const float* __restrict__ qraw, int d, int nq,
     int normalize, float* __restrict__ S, long long s_stride, u64* __restrict__ cand, long long c_stride,
     u64* __restrict__ bound, long long b_stride, int kprime, int nfin, ls_fin_batch fin,
-    void* __restrict__ gran, long long g_stride, u32 tag) {
+    void* __restrict__ gran, long long g_stride, u32 tag, float* __restrict__ qkeep) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
     // the first `nfin` workgroups run selection jobs (of the previous launch, or - same-launch hand-off -
     // of this launch's own queries), exactly as in ls_scan_kernel
@@ -168,6 +168,10 @@ __global__ __launch_bounds__(LS_MQ_THREADS, 2) void ls_mq_kernel(
             xq[j][i] = src[e < d ? e : d - 1];  // (unconditional loads; masked below)
         }
     }
+    // (a launch without score vectors keeps its raw queries for the repair: workgroup b copies query b)
+    if (qkeep)
+        for (int qq = bid; qq < nq; qq += nblk)
+            for (int e = threadIdx.x; e < d; e += LS_MQ_THREADS) qkeep[(long long)qq * d + e] = qraw[(long long)qq * d + e];
     __builtin_amdgcn_sched_barrier(0);
     mq_f32x4 ring[P];
     {
@@ -470,7 +474,7 @@ static int mq_launch(const void* corpus, int64_t n, const ls_geom& g, const ls_s
     hipLaunchKernelGGL(kern, dim3(a.blocks + a.nfin), dim3(LS_MQ_THREADS), smem, s, (const mq_f32x4*)corpus,
                        (long long)n, a.d_q, g.d, a.nq, a.normalize ? 1 : 0, a.d_S, (long long)a.s_stride,
                        a.d_cand, (long long)a.c_stride, a.d_bound, (long long)a.b_stride, a.kprime, a.nfin,
-                       a.fin, a.d_gran, (long long)a.g_stride, a.tag);
+                       a.fin, a.d_gran, (long long)a.g_stride, a.tag, a.d_qkeep);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }

@@ -175,3 +175,43 @@ def test_host_calls_without_score_vectors_are_served_again_when_unproven():
     assert ix.debug_counter(25) == before
     assert np.array_equal(D2, D) and np.array_equal(I2, I)
     ix.close()
+
+
+def test_device_calls_without_score_vectors_are_repaired_at_check():
+    """Device-output calls: pipelined results are final after ls_check, synchronous ones when the call returns -
+    their ls_mq launches write no score vectors either, keep their raw queries, and an unproven query (clustered
+    corpus) is served again in place by the scan kernel. LS_FLAG_ASYNC alone promises stream order: it keeps S."""
+    import torch
+
+    c = H.gauss(3, 60_000, 384)
+    q = H.gauss(4, 12, 384)
+    c = np.ascontiguousarray(c[np.argsort(c @ q[0])])
+    ix = FlatIPIndex.from_array(c)
+    tq = torch.from_numpy(q).cuda()
+    outs = [ix.search_device(tq[:m], 100, pipeline=True) for m in (12, 2, 7)]
+    tq2 = tq.clone()
+    torch.cuda.synchronize()
+    tq.zero_()  # (the passes have consumed the queries: the repair works from the launches' own copies)
+    torch.cuda.synchronize()
+    ix.check()
+    assert ix.debug_counter(25) >= 3, "the clustered query was not served again"
+    for m, (Dt, It) in zip((12, 2, 7), outs):
+        oracle.compare_kernel_order(Dt.cpu().numpy(), It.cpu().numpy(), c, q[:m], 100, orders=("scan",))
+    before = ix.debug_counter(25)
+    Dt, It = ix.search_device(tq2[:9], 100)  # synchronous: repaired before it returns
+    assert ix.debug_counter(25) > before
+    oracle.compare_kernel_order(Dt.cpu().numpy(), It.cpu().numpy(), c, q[:9], 100, orders=("scan",))
+    before = ix.debug_counter(25)
+    Dt, It = ix.search_device(tq2[:9], 100, asynchronous=True)
+    torch.cuda.synchronize()
+    assert ix.debug_counter(25) == before and ix.debug_counter(0) >= 1
+    oracle.compare_kernel_order(Dt.cpu().numpy(), It.cpu().numpy(), c, q[:9], 100, orders=("scan",))
+    # more pipelined launches than kept-query slots between two checks: the ring forces a repair
+    ix.debug_option(0, 1)
+    outs = [ix.search_device(tq2[:3], 50, pipeline=True) for _ in range(300)]
+    ix.check()
+    D0, I0 = outs[0][0].cpu().numpy(), outs[0][1].cpu().numpy()
+    oracle.compare_kernel_order(D0, I0, c, q[:3], 50, orders=("scan",))
+    for Dt, It in outs[1:]:
+        assert np.array_equal(Dt.cpu().numpy(), D0) and np.array_equal(It.cpu().numpy(), I0)
+    ix.close()

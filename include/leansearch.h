@@ -173,7 +173,11 @@ int ls_search(ls_index* index, const float* q, int64_t nq, int32_t k, uint32_t f
  * repaired query is re-written in place. Call ls_check before trusting the results of ANY batched
  * call (the speculative MFMA paths: nq > 16 on an fp16 index, nq >= 24 on an fp32 index, on shards
  * of at least 8192 rows) or of any pipelined search; per-query scan-path calls (everything else)
- * are exact in stream order. ls_debug_counter(index, 10) names the path the last call took. */
+ * are exact in stream order. (Small fp32 batches - 2..16 queries per corpus pass, ls_mq.hip - write no score
+ * vectors when the call is pipelined or synchronous: a query whose selection could not prove its keys
+ * complete is served again, in place, at ls_check / before the synchronous call returns; with LS_FLAG_ASYNC
+ * alone they keep the score vectors and stay exact in stream order.)
+ * ls_debug_counter(index, 10) names the path the last call took. */
 int ls_search_device(ls_index* index, const void* d_q, int64_t nq, int32_t k, uint32_t flags,
                      void* d_out_scores, void* d_out_indices, void* stream);
 
@@ -181,7 +185,8 @@ int ls_search_device(ls_index* index, const void* d_q, int64_t nq, int32_t k, ui
  * pipelined search queued since the last ls_check final: queries of batched calls whose
  * speculative threshold let fewer than k rows through, or whose candidate queues overflowed, are
  * re-run here by the exact per-query scan path (from the library's own copy of the queries) and
- * their output rows re-written. Returns LS_OK once everything is exact. Up to 1024 batched calls
+ * their output rows re-written; so are the queries of pipelined small-batch launches (ls_mq.hip, up to 256
+ * between two checks) that raised their repair word. Returns LS_OK once everything is exact. Up to 1024 batched calls
  * (fewer for batches of more than 4096 queries) may be outstanding; one more triggers the same repair step on its own. */
 int ls_check(ls_index* index, void* stream);
 
@@ -246,6 +251,9 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * (0: the VALU scan groups of 8 / 4 / 1 - same bits); option 17: synchronous host calls may overlap two
  * deep (default on); option 18: fp16 index with 768-byte stored rows, batched pass in the row-split,
  * 64-queries-per-wave shape (measured slower, profiles/ab/r05_tile_shape.txt: default off);
+ * option 19: ls_mq launches of synchronous host calls and of pipelined / synchronous device calls write no
+ * score vectors; an unproven query is served again on the scan kernel - same bits (default on; 0: every
+ * launch writes them and the selection repairs from them);
  * option 8 (sharded handles): exchange step 0 = RCCL all-gather between distinct devices (default),
  * 1 = peer copies into the primary device's gather buffer, 2 = RCCL gather-to-root (ncclSend / ncclRecv:
  * only the primary, which merges, receives the blocks); option 11 (sharded handles): one host
@@ -262,7 +270,8 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * counter 20: synchronous host calls that had to launch the stand-alone selection (option 9's retry);
  * counter 22: checks of pending batched calls the library ran on its own (slots exhausted or re-sliced; summed);
  * counter 23: ls_mq launches (small fp32 batches on the f32 matrix cores); counter 24: synchronous host calls
- * that were queued while another one was still in flight;
+ * that were queued while another one was still in flight; counter 25: queries of ls_mq launches without
+ * score vectors that were served again on the scan kernel;
  * counters 0, 1, 8, 11, 12 are summed over the shards, 9 and 10 are the primary shard's;
  * counter 16: combined batches ls_search served, 17: the requests they carried; counter 18 (sharded
  * handles): mean host nanoseconds spent queueing one search (every device's work + exchange + merge).

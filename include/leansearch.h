@@ -251,8 +251,8 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * (0: the VALU scan groups of 8 / 4 / 1 - same bits); option 17: synchronous host calls may overlap two
  * deep (default on); option 18: fp16 index with 768-byte stored rows, batched pass in the row-split,
  * 64-queries-per-wave shape (measured slower, profiles/ab/r05_tile_shape.txt: default off);
- * option 19: ls_mq launches of synchronous host calls and of pipelined / synchronous device calls write no
- * score vectors; an unproven query is served again on the scan kernel - same bits (default on; 0: every
+ * option 19: launches of synchronous host calls (ls_scan and ls_mq) and ls_mq launches of pipelined /
+ * synchronous device calls write no score vectors; an unproven query is served again on the scan kernel - same bits (default on; 0: every
  * launch writes them and the selection repairs from them);
  * option 8 (sharded handles): exchange step 0 = RCCL all-gather between distinct devices (default),
  * 1 = peer copies into the primary device's gather buffer, 2 = RCCL gather-to-root (ncclSend / ncclRecv:

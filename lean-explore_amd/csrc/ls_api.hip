@@ -505,7 +505,8 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         // (device-output calls whose results ls_check may still repair: mq_repair; never a repair's own launch)
         const bool dev_keep = use_mq && ix->dev_call_repairable && !ix->reserving && ix->done_base == nullptr &&
                               ix->opt_mq_skip_scores && ix->n > 0;
-        const bool skip_scores = (use_mq && (same_launch || host_words) && ix->opt_mq_skip_scores) || dev_keep;
+        // (single queries of synchronous host calls too - the reference's call: 0.5-1 us of 47 / 122)
+        const bool skip_scores = ((same_launch || host_words) && ix->opt_mq_skip_scores) || dev_keep;
         int keep_slot = -1;
         if (dev_keep) {
             if (!ix->d_mq_keep || ix->mq_keep_d != g.d) {
@@ -1188,7 +1189,7 @@ struct ls_host_call {
     uint32_t flags = 0;
     float* out_scores = nullptr;
     int64_t* out_indices = nullptr;
-    bool group = false, spin = false, out_direct = false, queued = false;
+    bool group = false, spin = false, out_direct = false, queued = false, in_direct = false;
     hipStream_t stream = nullptr;
     int rc = LS_OK;
     int gen = -1;  // the scratch generation an overlapped call was given (ls_index::force_gen)
@@ -1264,7 +1265,7 @@ static int host_call_begin_impl(ls_host_call& c) {
     // in flight before the query is touched, so the read hides, and the copy command measured 1.6-2 us
     // SLOWER per call (profiles/ab/r04_hostapi_selection.txt). Debug option 15 = 1 selects the copy.
     // (only single queries: every workgroup reads the whole query block - 256 x 16 x 4 KB over PCIe otherwise)
-    const bool in_direct = small_call && nq == 1 && !ix->opt_query_copy;
+    const bool in_direct = c.in_direct = small_call && nq == 1 && !ix->opt_query_copy;
     if (c.spin && !S.h_done) {
         LS_HIP(hipHostMalloc((void**)&S.h_done, sizeof(u32) * LS_SCAN_PATH_MAX_NQ, hipHostMallocDefault));
         memset(S.h_done, 0, sizeof(u32) * LS_SCAN_PATH_MAX_NQ);
@@ -1421,7 +1422,7 @@ static int host_call_finish(ls_host_call& c) {
                     ix->cur_done_seq = S.done_seq;
                     ix->force_gen = c.gen;
                     ix->reserving = true;
-                    rc = ls_i_search_on_stream(ix, S.d_qraw + (size_t)qi * ix->g.d, 1, k, c.flags & LS_FLAG_NORMALIZE,
+                    rc = ls_i_search_on_stream(ix, (c.in_direct ? S.h_q : S.d_qraw) + (size_t)qi * ix->g.d, 1, k, c.flags & LS_FLAG_NORMALIZE,
                                                (c.out_direct ? S.h_out_s : S.d_out_s) + (size_t)qi * k,
                                                (c.out_direct ? S.h_out_i : S.d_out_i) + (size_t)qi * k, s, true);
                     ix->reserving = false;

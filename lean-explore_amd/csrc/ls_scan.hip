@@ -22,6 +22,11 @@
 //     kernel (ls_select.hip) proves the global top-k is contained in the emitted keys, or falls
 //     back to an exact selection over the score vector S, which this kernel also writes.
 #include "ls_select_dev.h"
+#ifdef LS_SCAN_ABL_NOS  // timing ablation: no score vectors (results of unproven queries are wrong)
+#define LS_SCAN_S(x) ((float*)nullptr)
+#else
+#define LS_SCAN_S(x) (x)
+#endif
 
 #include <hip/hip_fp16.h>
 
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void l
                 const int qi = j % NQ, u = j / NQ;
                 const long long row = tt * TR + u * R + grp;
                 const bool valid = holder && row < n;
-                if (valid) S[qi * s_stride + row] = p[c];
+                if (valid && S) S[qi * s_stride + row] = p[c];
                 key[c] = valid ? ls_make_key(p[c], (u32)row) : 0ull;
                 myq[c] = qi;
             }
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void l
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
                 if (valid) {
-                    S[qi * s_stride + row] = sc[qi];
+                    if (S) S[qi * s_stride + row] = sc[qi];
                     lst[qi] = ls_make_key(sc[qi], (u32)row);  // this lane's one key of the launch
                 }
             }
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void l
         }
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
-            if (valid) S[qi * s_stride + row] = sc[qi];  // TR contiguous floats
+            if (valid && S) S[qi * s_stride + row] = sc[qi];  // TR contiguous floats (S == nullptr: ls_api.hip mq_repair)
             const u64 key = valid ? ls_make_key(sc[qi], (u32)row) : 0ull;
             u64 mask = __ballot(key > thr[qi]);
             while (mask) {  // rare once the threshold has warmed up
@@ -552,7 +557,7 @@ static int launch_lvq(const void* corpus, int64_t n, const ls_geom& g, const ls_
         if (int rc = ls_set_max_dynamic_lds(once, (const void*)kern, LS_PIGGY_LDS_MAX)) return rc; \
         hipLaunchKernelGGL(kern, dim3(a.blocks + a.nfin), dim3(LS_SCAN_THREADS), smem, s,          \
                            (const f32x4*)corpus, (long long)n, g.chunks, a.d_q, g.d,               \
-                           a.normalize ? 1 : 0, a.reverse ? 1 : 0, a.d_S, (long long)a.s_stride,   \
+                           a.normalize ? 1 : 0, a.reverse ? 1 : 0, LS_SCAN_S(a.d_S), (long long)a.s_stride,   \
                            a.d_cand, (long long)a.c_stride, a.d_bound, (long long)a.b_stride,      \
                            a.kprime, a.nfin, a.fin, a.d_gran, (long long)a.g_stride, a.tag);                                     \
     }

@@ -72,6 +72,10 @@ extern "C" {
                              /* that call's sample scores, or at ls_check()); results are NOT */
                              /* ordered on `stream` - they are valid after ls_check()         */
 
+#define LS_FLAG_INORDER 8u   /* ls_search_device with LS_FLAG_PIPELINE: the caller consumes scan-path    */
+                             /* results on the GPU before ls_check (in the lanes' order, e.g. a sharded */
+                             /* exchange): every launch keeps its score vectors and repairs in-kernel   */
+
 #define LS_MAX_K 2048 /* same ceiling as FAISS's GPU k-selection; reference uses k = 1000     */
 
 typedef struct ls_index ls_index; /* opaque */
@@ -173,10 +177,10 @@ int ls_search(ls_index* index, const float* q, int64_t nq, int32_t k, uint32_t f
  * repaired query is re-written in place. Call ls_check before trusting the results of ANY batched
  * call (the speculative MFMA paths: nq > 16 on an fp16 index, nq >= 24 on an fp32 index, on shards
  * of at least 8192 rows) or of any pipelined search; per-query scan-path calls (everything else)
- * are exact in stream order. (Small fp32 batches - 2..16 queries per corpus pass, ls_mq.hip - write no score
+ * are exact in stream order. (Single queries and small fp32 batches - ls_scan.hip, ls_mq.hip - write no score
  * vectors when the call is pipelined or synchronous: a query whose selection could not prove its keys
- * complete is served again, in place, at ls_check / before the synchronous call returns; with LS_FLAG_ASYNC
- * alone they keep the score vectors and stay exact in stream order.)
+ * complete is served again, in place, at ls_check / before the synchronous call returns. With LS_FLAG_ASYNC
+ * alone, or with LS_FLAG_INORDER, they keep the score vectors and are exact in stream / lane order.)
  * ls_debug_counter(index, 10) names the path the last call took. */
 int ls_search_device(ls_index* index, const void* d_q, int64_t nq, int32_t k, uint32_t flags,
                      void* d_out_scores, void* d_out_indices, void* stream);

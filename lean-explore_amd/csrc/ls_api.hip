@@ -423,7 +423,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         const int NQ = use_mq ? (int)std::min<int64_t>(left, LS_QUERIES_PER_LAUNCH_MAX)
                               : (!ix->opt_multi_query ? 1 : (left >= 5 ? 8 : (left >= 2 ? 4 : 1)));
         const int real = (int)std::min<int64_t>(NQ, left);
-        if (use_mq && ix->dev_call_repairable && !ix->reserving &&
+        if ((use_mq || NQ == 1) && ix->dev_call_repairable && !ix->reserving &&
             ((int)ix->mq_pend.size() >= LS_MQ_KEEP_SLOTS || (ix->d_mq_keep && ix->mq_keep_d != g.d))) {
             rc = mq_repair(ix);  // the ring of kept queries is full: make what is pending final first
             if (rc != LS_OK) return rc;
@@ -503,8 +503,8 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         // (k > 256: the selection has its own launch behind the pass; without S it answers the same way)
         const bool host_words = !pipeline && ix->done_base != nullptr && ix->cur_retry != nullptr && !ix->reserving;
         // (device-output calls whose results ls_check may still repair: mq_repair; never a repair's own launch)
-        const bool dev_keep = use_mq && ix->dev_call_repairable && !ix->reserving && ix->done_base == nullptr &&
-                              ix->opt_mq_skip_scores && ix->n > 0;
+        const bool dev_keep = (use_mq || (NQ == 1 && ix->opt_scan_skip_scores)) && ix->dev_call_repairable &&
+                              !ix->reserving && ix->done_base == nullptr && ix->opt_mq_skip_scores && ix->n > 0;
         // (single queries of synchronous host calls too - the reference's call: 0.5-1 us of 47 / 122)
         const bool skip_scores = ((same_launch || host_words) && ix->opt_mq_skip_scores) || dev_keep;
         int keep_slot = -1;
@@ -1154,7 +1154,7 @@ int ls_i_check_search_args(const ls_index* ix, const void* q, int64_t nq, int32_
         ls_set_error("search: bad argument (nq=%lld k=%d)", (long long)nq, k);
         return LS_ERR_INVALID_ARG;
     }
-    if (flags & ~(LS_FLAG_NORMALIZE | LS_FLAG_ASYNC | LS_FLAG_PIPELINE)) {
+    if (flags & ~(LS_FLAG_NORMALIZE | LS_FLAG_ASYNC | LS_FLAG_PIPELINE | LS_FLAG_INORDER)) {
         ls_set_error("search: unknown flags 0x%x", flags);
         return LS_ERR_INVALID_ARG;
     }
@@ -1675,7 +1675,7 @@ int ls_search_device(ls_index* ix, const void* d_q, int64_t nq, int32_t k, uint3
     hipStream_t s = (hipStream_t)stream;
     // pipelined results are final after ls_check, synchronous ones when this returns: both leave room for the
     // repair of an ls_mq launch without score vectors (mq_repair); LS_FLAG_ASYNC alone promises stream order
-    ix->dev_call_repairable = (flags & LS_FLAG_PIPELINE) || !(flags & LS_FLAG_ASYNC);
+    ix->dev_call_repairable = !(flags & LS_FLAG_INORDER) && ((flags & LS_FLAG_PIPELINE) || !(flags & LS_FLAG_ASYNC));
     rc = ls_i_search_on_stream(ix, (const float*)d_q, nq, k, flags, (float*)d_out_scores,
                           (int64_t*)d_out_indices, s, false);
     ix->dev_call_repairable = false;
@@ -1972,8 +1972,9 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->g.qg4 = value != 0;
         return LS_OK;
     }
-    if (which == 19) {  // ls_mq launches of synchronous host calls write no score vectors (default on)
+    if (which == 19) {  // launches whose unproven queries can be served again write no score vectors (default on; 2: not the single-query device launches)
         ix->opt_mq_skip_scores = value != 0;
+        ix->opt_scan_skip_scores = value == 1;
         return LS_OK;
     }
     if (which == 17) {  // synchronous host calls overlap two deep (default on)

@@ -180,6 +180,7 @@ struct ls_index {
     int32_t opt_multi_query = 1;       // several queries per corpus pass (groups of 8 / 4)
     int32_t opt_mq = 1;                // fp32 index: 2..16 queries per pass on the f32 matrix cores (ls_mq.hip)
     uint64_t n_mq_launches = 0;
+    int32_t opt_scan_skip_scores = 1;  // ... single-query launches of pipelined / synchronous device calls too
     int32_t opt_mq_skip_scores = 1;    // ... whose selection jobs ride along write no score vectors (debug option 19)
     uint64_t n_mq_reserved = 0;        // queries of such launches served again on the scan kernel (counter 25)
     bool reserving = false;            // (that second serve is being queued: its selection takes its own launch)

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void l
     const f32x4* __restrict__ corpus, long long n, int chunks, const float* __restrict__ qraw,
     int d, int normalize, int reverse, float* __restrict__ S, long long s_stride,
     u64* __restrict__ cand, long long c_stride, u64* __restrict__ bound, long long b_stride,
-    int kprime, int nfin, ls_fin_batch fin, void* __restrict__ gran, long long g_stride, u32 tag) {
+    int kprime, int nfin, ls_fin_batch fin, void* __restrict__ gran, long long g_stride, u32 tag,
+    float* __restrict__ qkeep) {
     // The first `nfin` workgroups of a launch run the PREVIOUS launch's selection jobs
     // (finalize_body, ls_select_dev.h) while every other workgroup scans for the current queries:
     // selection costs neither a launch nor a kernel boundary and hides under the scan.
@@ -235,11 +236,17 @@ __global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void l
         // scan workgroups below are writing; they never wait for anything. Should they not get to
         // run while this workgroup holds its slot (a CU-masked stream, a partitioned device) the
         // sweep gives up after 200 ms and asks the host for a retry.)
+        // (a single-query launch without a score vector keeps its raw query for the repair, ls_api.hip
+        // mq_repair: the riding selection workgroup has the time, the scan workgroups do not)
+        if (NQ == 1 && qkeep && blockIdx.x == 0)
+            for (int e = threadIdx.x; e < d; e += LS_SCAN_THREADS) qkeep[e] = qraw[e];
         finalize_body<LS_SCAN_THREADS>(fin.p[blockIdx.x], smem_dyn, threadIdx.x);
         return;
     }
     const int bid = (int)blockIdx.x - nfin;
     const int nblk = (int)gridDim.x - nfin;
+    if (NQ == 1 && qkeep && nfin == 0 && bid == 0)  // (nothing rides on this launch: scan workgroup 0 copies)
+        for (int e = threadIdx.x; e < d; e += LS_SCAN_THREADS) qkeep[e] = qraw[e];
 #ifdef LS_HANDOFF_TIMING
     if (threadIdx.x == 0) atomicMax(&g_ho[0], ~wall_clock64());
 #endif
@@ -559,7 +566,7 @@ static int launch_lvq(const void* corpus, int64_t n, const ls_geom& g, const ls_
                            (const f32x4*)corpus, (long long)n, g.chunks, a.d_q, g.d,               \
                            a.normalize ? 1 : 0, a.reverse ? 1 : 0, LS_SCAN_S(a.d_S), (long long)a.s_stride,   \
                            a.d_cand, (long long)a.c_stride, a.d_bound, (long long)a.b_stride,      \
-                           a.kprime, a.nfin, a.fin, a.d_gran, (long long)a.g_stride, a.tag);                                     \
+                           a.kprime, a.nfin, a.fin, a.d_gran, (long long)a.g_stride, a.tag, a.d_qkeep);                          \
     }
     if constexpr (NQ == 1) {
         if (small) LS_SCAN_LAUNCH(true) else LS_SCAN_LAUNCH(false)

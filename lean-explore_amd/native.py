@@ -25,6 +25,7 @@ LS_DTYPE_F16 = 1
 LS_FLAG_NORMALIZE = 1
 LS_FLAG_ASYNC = 2
 LS_FLAG_PIPELINE = 4
+LS_FLAG_INORDER = 8
 LS_MAX_K = 2048
 
 _PKG_DIR = Path(__file__).resolve().parent

@@ -241,7 +241,8 @@ class ShardedFlatIPIndex:
                 # are bound by the host's launch rate, not by the GPU
                 "call": native.load().ls_search_device, "check": native.check,
                 "handle": self.local._ensure_built(), "stream": stream,
-                "flags": native.LS_FLAG_PIPELINE | (native.LS_FLAG_NORMALIZE if normalize else 0),
+                # (INORDER: the exchange consumes the local results before any ls_check could repair them)
+                "flags": native.LS_FLAG_PIPELINE | native.LS_FLAG_INORDER | (native.LS_FLAG_NORMALIZE if normalize else 0),
             }
             slots = []
             for g in range(depth):

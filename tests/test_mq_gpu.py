@@ -215,3 +215,37 @@ def test_device_calls_without_score_vectors_are_repaired_at_check():
     for Dt, It in outs[1:]:
         assert np.array_equal(Dt.cpu().numpy(), D0) and np.array_equal(It.cpu().numpy(), I0)
     ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_single_query_device_calls_without_score_vector_are_repaired(dtype):
+    """The headline's loop - pipelined single-query device calls - writes no score vector either (the riding
+    selection workgroup keeps the raw query); with k' forced to 1 every query needs the repair at ls_check.
+    Option 19 = 2 keeps the vector: same results."""
+    import torch
+
+    c = H.gauss(31, 50_000, 384)
+    q = H.gauss(32, 6, 384)
+    ix = FlatIPIndex.from_array(c, dtype=dtype)
+    tq = torch.from_numpy(q).cuda()
+    ref = [ix.search_device(tq[j:j + 1], 64, asynchronous=True) for j in range(6)]  # (keeps S: exact in stream order)
+    torch.cuda.synchronize()
+    ix.debug_option(0, 1)
+    before = ix.debug_counter(25)
+    outs = [ix.search_device(tq[j:j + 1], 64, pipeline=True) for j in range(6)]
+    ix.check()
+    assert ix.debug_counter(25) >= before + 4
+    for (Dr, Ir), (Dt, It) in zip(ref, outs):
+        assert torch.equal(Dr, Dt) and torch.equal(Ir, It)
+    Ds, Is = ix.search_device(tq[2:3], 64)  # synchronous
+    assert torch.equal(Ds, ref[2][0]) and torch.equal(Is, ref[2][1])
+    ix.debug_option(19, 2)
+    before = ix.debug_counter(25)
+    outs = [ix.search_device(tq[j:j + 1], 64, pipeline=True) for j in range(6)]
+    ix.check()
+    assert ix.debug_counter(25) == before
+    for (Dr, Ir), (Dt, It) in zip(ref, outs):
+        assert torch.equal(Dr, Dt) and torch.equal(Ir, It)
+    if dtype == "f32":
+        oracle.compare_kernel_order(ref[0][0].cpu().numpy(), ref[0][1].cpu().numpy(), c, q[:1], 64, orders=("scan",))
+    ix.close()

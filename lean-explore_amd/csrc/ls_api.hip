@@ -519,7 +519,8 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
                 const size_t fb = sizeof(u32) * (size_t)LS_MQ_KEEP_SLOTS * LS_QUERIES_PER_LAUNCH_MAX;
                 LS_HIP(hipMalloc((void**)&ix->d_mq_flags, fb));
                 LS_HIP(hipMemset(ix->d_mq_flags, 0, fb));
-                LS_HIP(hipHostMalloc((void**)&ix->h_mq_flags, fb, hipHostMallocDefault));
+                LS_HIP(hipHostMalloc((void**)&ix->h_mq_flags, fb + sizeof(u32), hipHostMallocDefault));
+                ix->h_mq_flags[LS_MQ_KEEP_SLOTS * LS_QUERIES_PER_LAUNCH_MAX] = 0u;
             }
             keep_slot = (int)ix->mq_pend.size();
             ix->mq_pend.push_back({keep_slot, real, k, flags, d_out_s + q0 * k, d_out_i + q0 * k, s});
@@ -569,6 +570,7 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             p.tag = same_launch ? ix->gran_tag : 0u;
             p.wait = same_launch ? 1u : 0u;
             p.repair = keep_slot >= 0 ? ix->d_mq_flags + (size_t)keep_slot * LS_QUERIES_PER_LAUNCH_MAX + i : nullptr;
+            p.repair_any = keep_slot >= 0 ? ix->h_mq_flags + LS_MQ_KEEP_SLOTS * LS_QUERIES_PER_LAUNCH_MAX : nullptr;
             if ((same_launch || skip_scores) && ix->cur_retry) ix->cur_retry->push_back(p);  // kept until the host has seen the answers
         }
         if (prof) LS_HIP(hipEventRecord(pe[0], s));
@@ -615,6 +617,10 @@ static int mq_repair(ls_index* ix) {
         if (pc.stream != last) LS_HIP(hipStreamSynchronize(pc.stream));
     if (ix->pending_stream && ix->pending_stream != last) LS_HIP(hipStreamSynchronize(ix->pending_stream));
     const size_t used = pend.size() * LS_QUERIES_PER_LAUNCH_MAX;
+    LS_HIP(hipStreamSynchronize(last));
+    u32* any_word = ix->h_mq_flags + LS_MQ_KEEP_SLOTS * LS_QUERIES_PER_LAUNCH_MAX;
+    if (__atomic_load_n(any_word, __ATOMIC_ACQUIRE) == 0u) return LS_OK;  // the common case: no copy, nothing to read
+    __atomic_store_n(any_word, 0u, __ATOMIC_RELEASE);
     LS_HIP(hipMemcpyAsync(ix->h_mq_flags, ix->d_mq_flags, sizeof(u32) * used, hipMemcpyDeviceToHost, last));
     LS_HIP(hipStreamSynchronize(last));
     bool any = false;

@@ -242,6 +242,7 @@ struct ls_fin_params {
     // cannot be proven complete raises this device word and leaves its output rows alone; ls_check (or the
     // end of a synchronous call) serves the query again on the scan kernel (ls_api.hip mq_repair).
     u32* repair;
+    u32* repair_any;       // pinned host word raised with it: ls_check reads no device memory when nothing was flagged
 };
 struct ls_out_gran {   // host view of one result granule
     float score;

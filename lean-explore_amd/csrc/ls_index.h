@@ -200,7 +200,7 @@ struct ls_index {
     float* d_mq_keep = nullptr;        // [LS_MQ_KEEP_SLOTS][16][mq_keep_d]
     int32_t mq_keep_d = 0;
     u32* d_mq_flags = nullptr;         // [LS_MQ_KEEP_SLOTS][16]
-    u32* h_mq_flags = nullptr;         // pinned mirror
+    u32* h_mq_flags = nullptr;         // pinned mirror; its LAST word is raised by any flagged job (ls_fin_params::repair_any)
     bool dev_call_repairable = false;  // set by ls_search_device around a call whose results may be repaired later
     int32_t opt_query_copy = 0;        // synchronous host calls: 0 = the kernels read the pinned host copy over PCIe
                                        // themselves, 1 = a copy command brings the query to device memory first

@@ -1097,7 +1097,10 @@ static __device__ __forceinline__ void finalize_body(const ls_fin_params& p, uns
         return;
     }
     if (!done && !p.S) {  // no score vector and nobody to ask for a retry inside the stream: flag the query
-        if (tid == 0 && p.repair) __hip_atomic_store(p.repair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && p.repair) {
+            __hip_atomic_store(p.repair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.repair_any) __hip_atomic_store(p.repair_any, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
     if (!done) {

@@ -189,15 +189,17 @@ int ls_search_device(ls_index* index, const void* d_q, int64_t nq, int32_t k, ui
  * pipelined search queued since the last ls_check final: queries of batched calls whose
  * speculative threshold let fewer than k rows through, or whose candidate queues overflowed, are
  * re-run here by the exact per-query scan path (from the library's own copy of the queries) and
- * their output rows re-written; so are the queries of pipelined small-batch launches (ls_mq.hip, up to 256
- * between two checks) that raised their repair word. Returns LS_OK once everything is exact. Up to 1024 batched calls
+ * their output rows re-written; so are the queries of pipelined scan-path launches (single queries and small
+ * fp32 batches, up to 256 launches between two checks) that raised their repair word. Returns LS_OK once everything is exact. Up to 1024 batched calls
  * (fewer for batches of more than 4096 queries) may be outstanding; one more triggers the same repair step on its own. */
 int ls_check(ls_index* index, void* stream);
 
 /* Copy the per-query verification flags of the most recent search queued on this handle into
  * d_dst (device memory on the index's device, uint32 [nq]) in `stream` order: non-zero = that
- * query's output rows are provisional until ls_check. Scan-path searches export zeros. Lets a
- * sharded caller ship the flags with the results instead of synchronising before the exchange. */
+ * query's output rows are provisional until ls_check. Scan-path searches export zeros: a caller that
+ * ships scan-path results before ls_check passes LS_FLAG_INORDER (or LS_FLAG_ASYNC alone), which makes them
+ * exact in order. Lets a sharded caller ship the flags with the results instead of synchronising before
+ * the exchange. */
 int ls_export_flags(ls_index* index, void* d_dst, int64_t nq, void* stream);
 
 /* faiss.normalize_L2(x): in-place row normalisation of host float32 [nq, d];

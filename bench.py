@@ -663,7 +663,8 @@ def run_callers(env: Env, workload: str = "c2", secs: float = 0.6) -> dict:
     """T threads of synchronous single-query ls_search on ONE handle (an MCP server with several clients,
     reference mcp/server.py:147-151 -> search/engine.py:250): queries/s and p50 latency for T = 1, 2, 4, 8, 16.
     Concurrent requests are combined into shared corpus passes (fp32: csrc/ls_mq.hip, bit-identical rows) and
-    overlap two deep on the handle's two host slots; tools/concurrent_callers.py A/Bs the mechanisms."""
+    overlap two deep on the handle's two host slots (short passes) or are gathered into one pass (long passes:
+    d = 1024); tools/concurrent_callers.py and tools/callers_c.c A/B the mechanisms."""
     import threading
 
     from lean_explore_amd.index import FlatIPIndex
@@ -843,6 +844,7 @@ def main():
         host_api = {w: run_host_api(env, w) for w in ("c2", "c2p")}
         try:
             host_api["concurrent_callers"] = run_callers(env, "c2")
+            host_api["concurrent_callers_c2p"] = run_callers(env, "c2p", secs=0.5)  # (the reference's call shape)
         except Exception as e:
             host_api["concurrent_callers"] = {"error": repr(e)}
 

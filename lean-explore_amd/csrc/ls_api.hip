@@ -367,6 +367,8 @@ static int64_t scan_group_count(const ls_index* ix, int64_t nq, int32_t k) {
     return groups;
 }
 
+#define LS_GATHER_SLOW_US 110.0  // a combined call longer than this is a "long pass" (ls_search)
+#define LS_GATHER_MAX_US 60.0
 #define LS_MQ_KEEP_SLOTS 256  // ls_mq launches without score vectors between two repairs (device-output calls)
 static int mq_repair(ls_index* ix);
 
@@ -1614,6 +1616,9 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             const int64_t total = ix->requests_in_flight + (int64_t)ix->req_q.size();
             // (up to 8 callers: with more, the two halves are big passes that only slow each other down -
             // 16 callers 76.5 k early vs 81.2 k waiting, 8 callers 51.4 k vs 45.9 k, 4 callers 32.9 k vs 25.6 k)
+            // (long passes - d = 1024: 140 us - gain nothing from running two at once, they share one HBM; their
+            // callers are gathered into ONE pass instead, below)
+            if (ix->opt_gather && ix->call_us_est > LS_GATHER_SLOW_US) return false;
             return ix->opt_overlap_calls && ix->calls_in_flight < LS_HOST_SLOTS &&
                    (total <= 2 || (total >= ix->peak_callers && total <= 8));
         };
@@ -1631,6 +1636,29 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             if (!changed && ix->calls_in_flight > 0 && ix->q_epoch.load(std::memory_order_acquire) == seen)
                 ix->q_cv.wait(lk);
         }
+        // Gather (round 5, long passes): nothing is in flight and fewer requests are queued than callers were
+        // seen lately - the others are on their way back from the pass that just ended (their results were
+        // handed out microseconds ago). Launching now would split the callers into two groups that wait for each
+        // other's pass forever (4 callers, d = 1024: 2 + 2, every call 2 x 158 us); a short wait puts them all
+        // into ONE pass. Bounded by a third of the running estimate of a call, at most LS_GATHER_MAX_US.
+        if (ix->opt_gather && ix->calls_in_flight == 0 && (int64_t)ix->req_q.size() < ix->peak_callers &&
+            (ix->opt_gather == 2 || ix->call_us_est > LS_GATHER_SLOW_US)) {
+            const double budget_us = std::min<double>(LS_GATHER_MAX_US, ix->call_us_est / 3.0);
+            const auto t0 = std::chrono::steady_clock::now();
+            while ((int64_t)ix->req_q.size() < ix->peak_callers) {
+                const uint64_t seen = ix->q_epoch.load(std::memory_order_acquire);
+                lk.unlock();
+                bool changed = false, late = false;
+                for (unsigned it = 0; !changed && !late; ++it) {
+                    for (int i = 0; i < 16; ++i) _mm_pause();
+                    changed = ix->q_epoch.load(std::memory_order_acquire) != seen;
+                    if ((it & 7) == 7)
+                        late = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > budget_us;
+                }
+                lk.lock();
+                if (late) break;
+            }
+        }
         ls_served sv;
         ls_req* head = ix->req_q.front();
         int64_t total = 0;
@@ -1643,6 +1671,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             ix->req_q.pop_front();
         }
         lk.unlock();
+        const auto t_call = std::chrono::steady_clock::now();
         serve_begin(ix, sv);
         lk.lock();
         ix->calls_in_flight++;
@@ -1658,6 +1687,10 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         lk.unlock();
         serve_finish(ix, sv);
         lk.lock();
+        {
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
+            ix->call_us_est = ix->call_us_est <= 0.0 ? us : ix->call_us_est + (us - ix->call_us_est) / 8.0;
+        }
         ix->calls_in_flight--;
         ix->requests_in_flight -= (int64_t)sv.batch.size();
         for (ls_req* r : sv.batch) r->done = true;
@@ -1976,6 +2009,10 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
     if (which == 18) {  // fp16 index, 48-chunk rows: the batched pass in the row-split, 64-queries-per-wave shape (default off)
         if (int rc = ls_i_batched_repair(ix)) return rc;  // nothing pending in the other geometry
         ix->g.qg4 = value != 0;
+        return LS_OK;
+    }
+    if (which == 20) {  // concurrent callers of long passes are gathered into one pass (0 off, 1 long passes only: default, 2 always)
+        ix->opt_gather = value;
         return LS_OK;
     }
     if (which == 19) {  // launches whose unproven queries can be served again write no score vectors (default on; 2: not the single-query device launches)

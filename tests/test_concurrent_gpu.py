@@ -141,3 +141,32 @@ def test_two_alternating_callers_overlap_and_stay_exact():
                 assert ix.debug_counter(24) == before
     finally:
         ix.close()
+
+
+def test_callers_of_long_passes_are_gathered_and_stay_exact():
+    """d = 1024 (the reference's shape): a combined call takes > 110 us, so concurrent callers are gathered into
+    one pass (debug option 20) instead of running two passes at once. Rows are those of lone calls, bit for bit."""
+    import threading
+
+    c = H.gauss(71, 200_000, 1024)
+    q = H.gauss(72, 8, 1024)
+    ix = FlatIPIndex.from_array(c)
+    want = [ix.search(q[j:j + 1], 100, normalize=True) for j in range(8)]
+    bad = []
+
+    def w(t):
+        for _ in range(60):
+            D, I = ix.search(q[t:t + 1], 100, normalize=True)
+            if not (np.array_equal(D, want[t][0]) and np.array_equal(I, want[t][1])):
+                bad.append(t)
+
+    b0, r0 = ix.debug_counter(16), ix.debug_counter(17)
+    th = [threading.Thread(target=w, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not bad
+    batches, reqs = ix.debug_counter(16) - b0, ix.debug_counter(17) - r0
+    assert reqs >= 180 and reqs / batches > 2.5, (batches, reqs)  # (combined batches only) mostly passes of 3-4 callers
+    ix.close()

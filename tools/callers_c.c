@@ -1,7 +1,7 @@
 /* callers_c.c - T threads making synchronous single-query ls_search calls on ONE handle (the reference's call,
  * search/engine.py:250, issued by several MCP clients, mcp/server.py:147-151), timed from C: what the library's
  * caller combining delivers without the Python threads' GIL hand-offs that tools/concurrent_callers.py includes.
- *   gcc -O2 tools/callers_c.c -o scratch/callers_c -ldl -lm -lpthread && ./scratch/callers_c lean-explore_amd/libleansearch.so */
+ *   gcc -O2 tools/callers_c.c -o scratch/callers_c -ldl -lm -lpthread && ./scratch/callers_c lean-explore_amd/libleansearch.so [overlap [gather [reps]]] */
 #include <dlfcn.h>
 #include <math.h>
 #include <pthread.h>
@@ -45,7 +45,10 @@ int main(int argc, char** argv) {
     int (*create)(ls_index**, const float*, int64_t, int32_t, int32_t, int32_t) = dlsym(lib, "ls_create");
     search = dlsym(lib, "ls_search");
     void (*destroy)(ls_index*) = dlsym(lib, "ls_destroy");
+    int (*option)(ls_index*, int32_t, int32_t) = dlsym(lib, "ls_debug_option");
     const char* (*lasterr)(void) = dlsym(lib, "ls_last_error");
+    const int overlap = argc > 2 ? atoi(argv[2]) : 1;  /* debug option 17: synchronous calls overlap two deep */
+    const int gather = argc > 3 ? atoi(argv[3]) : -1;  /* debug option 20: 0 off, 1 long passes (default), 2 always */
     const int shapes[2][3] = {{200000, 384, 50}, {200000, 1024, 1000}};
     for (int c = 0; c < 2; ++c) {
         const int64_t n = shapes[c][0];
@@ -57,6 +60,8 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 16 * d; ++i) q[i] = gauss(&s);
         ls_index* ix = NULL;
         if (create(&ix, corpus, n, d, 0, 0)) { printf("ls_create: %s\n", lasterr()); return 1; }
+        option(ix, 17, overlap);
+        if (gather >= 0) option(ix, 20, gather);
         {
             float* D = malloc(sizeof(float) * k); int64_t* I = malloc(sizeof(int64_t) * k);
             for (int i = 0; i < 50; ++i) search(ix, q, 1, k, 1u, D, I);
@@ -65,7 +70,7 @@ int main(int argc, char** argv) {
         const int Ts[5] = {1, 2, 4, 8, 16};
         for (int ti = 0; ti < 5; ++ti) {
             const int T = Ts[ti];
-            for (int rep = 0; rep < 2; ++rep) {
+            for (int rep = 0; rep < (argc > 4 ? atoi(argv[4]) : 2); ++rep) {
                 pthread_t th[16];
                 struct job jobs[16];
                 const double t0 = now_us(), stop = t0 + 0.8e6;
@@ -80,7 +85,7 @@ int main(int argc, char** argv) {
                 long m = 0;
                 for (int t = 0; t < T; ++t) { for (long i = 0; i < jobs[t].calls && i < jobs[t].cap; ++i) all[m++] = jobs[t].lat[i]; free(jobs[t].lat); }
                 qsort(all, m, sizeof(double), cmp);
-                printf("C threads N=%lld d=%d k=%d, %2d callers: %8.0f q/s, p50 %.1f us\n", (long long)n, d, k, T, total / (dt * 1e-6), m ? all[m / 2] : 0.0);
+                printf("C threads%s N=%lld d=%d k=%d, %2d callers: %8.0f q/s, p50 %.1f us\n", overlap ? "" : " (no overlap)", (long long)n, d, k, T, total / (dt * 1e-6), m ? all[m / 2] : 0.0);
                 fflush(stdout);
                 free(all);
             }

@@ -663,8 +663,8 @@ def run_callers(env: Env, workload: str = "c2", secs: float = 0.6) -> dict:
     """T threads of synchronous single-query ls_search on ONE handle (an MCP server with several clients,
     reference mcp/server.py:147-151 -> search/engine.py:250): queries/s and p50 latency for T = 1, 2, 4, 8, 16.
     Concurrent requests are combined into shared corpus passes (fp32: csrc/ls_mq.hip, bit-identical rows) and
-    overlap two deep on the handle's two host slots (short passes) or are gathered into one pass (long passes:
-    d = 1024); tools/concurrent_callers.py and tools/callers_c.c A/B the mechanisms."""
+    a leader with nothing in flight waits briefly for the callers seen lately, so that they share ONE pass
+    (gather, debug option 20); tools/concurrent_callers.py and tools/callers_c.c A/B the mechanisms."""
     import threading
 
     from lean_explore_amd.index import FlatIPIndex

@@ -257,9 +257,10 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * (0: the VALU scan groups of 8 / 4 / 1 - same bits); option 17: synchronous host calls may overlap two
  * deep (default on); option 18: fp16 index with 768-byte stored rows, batched pass in the row-split,
  * 64-queries-per-wave shape (measured slower, profiles/ab/r05_tile_shape.txt: default off);
- * option 20: concurrent ls_search callers whose combined call takes > 110 us (d = 1024) are gathered into ONE
- * pass - a leader with nothing in flight waits up to a third of a call, at most 60 us, for the callers seen
- * lately - instead of two passes at once (0 off, 1 default, 2 short passes too);
+ * option 20: concurrent ls_search callers are gathered into ONE pass - a leader with nothing in flight waits up
+ * to a third of a call, at most 60 us, for the callers seen lately - instead of two passes at once on the two
+ * host slots (2 default; 1: only calls longer than 110 us, e.g. d = 1024; 0 off: option 17's two-deep overlap
+ * decides); option 21: callers up to which a second batch may go early when option 20 allows it (default 8);
  * option 19: launches of synchronous host calls (ls_scan and ls_mq) and ls_mq launches of pipelined /
  * synchronous device calls write no score vectors; an unproven query is served again on the scan kernel - same bits (default on; 0: every
  * launch writes them and the selection repairs from them);

@@ -1618,9 +1618,9 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             // 16 callers 76.5 k early vs 81.2 k waiting, 8 callers 51.4 k vs 45.9 k, 4 callers 32.9 k vs 25.6 k)
             // (long passes - d = 1024: 140 us - gain nothing from running two at once, they share one HBM; their
             // callers are gathered into ONE pass instead, below)
-            if (ix->opt_gather && ix->call_us_est > LS_GATHER_SLOW_US) return false;
+            if (ix->opt_gather == 2 || (ix->opt_gather && ix->call_us_est > LS_GATHER_SLOW_US)) return false;
             return ix->opt_overlap_calls && ix->calls_in_flight < LS_HOST_SLOTS &&
-                   (total <= 2 || (total >= ix->peak_callers && total <= 8));
+                   (total <= 2 || (total >= ix->peak_callers && total <= ix->opt_early_cap));
         };
         while (ix->calls_in_flight > 0 && !go_early()) {
             const uint64_t seen = ix->q_epoch.load(std::memory_order_acquire);  // (as above: poll, then sleep)
@@ -1636,13 +1636,15 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             if (!changed && ix->calls_in_flight > 0 && ix->q_epoch.load(std::memory_order_acquire) == seen)
                 ix->q_cv.wait(lk);
         }
-        // Gather (round 5, long passes): nothing is in flight and fewer requests are queued than callers were
+        // Gather (round 5; first for long passes only, then for all - 2 / 4 / 8 callers at d = 384: 23.7 / 40.0 /
+        // 64-75 k -> 26 / 46.5 / 70 k q/s, d = 1024: 8.7 / 15.0 / 30.0 -> 12.1 / 22.5 / 36.5 k; with it no batch goes
+        // early any more): nothing is in flight and fewer requests are queued than callers were
         // seen lately - the others are on their way back from the pass that just ended (their results were
         // handed out microseconds ago). Launching now would split the callers into two groups that wait for each
         // other's pass forever (4 callers, d = 1024: 2 + 2, every call 2 x 158 us); a short wait puts them all
         // into ONE pass. Bounded by a third of the running estimate of a call, at most LS_GATHER_MAX_US.
         if (ix->opt_gather && ix->calls_in_flight == 0 && (int64_t)ix->req_q.size() < ix->peak_callers &&
-            (ix->opt_gather == 2 || ix->call_us_est > LS_GATHER_SLOW_US)) {
+            (ix->opt_gather == 2 || ix->call_us_est > LS_GATHER_SLOW_US || ix->peak_callers > ix->opt_early_cap)) {
             const double budget_us = std::min<double>(LS_GATHER_MAX_US, ix->call_us_est / 3.0);
             const auto t0 = std::chrono::steady_clock::now();
             while ((int64_t)ix->req_q.size() < ix->peak_callers) {
@@ -2011,7 +2013,11 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->g.qg4 = value != 0;
         return LS_OK;
     }
-    if (which == 20) {  // concurrent callers of long passes are gathered into one pass (0 off, 1 long passes only: default, 2 always)
+    if (which == 21) {  // most callers for which a second batch may go early on the other host slot (default 8)
+        ix->opt_early_cap = value;
+        return LS_OK;
+    }
+    if (which == 20) {  // concurrent callers are gathered into one pass (0 off, 1 long passes only, 2 always: default)
         ix->opt_gather = value;
         return LS_OK;
     }

@@ -183,7 +183,8 @@ struct ls_index {
     int32_t opt_scan_skip_scores = 1;  // ... single-query launches of pipelined / synchronous device calls too
     int32_t opt_mq_skip_scores = 1;    // ... whose selection jobs ride along write no score vectors (debug option 19)
     uint64_t n_mq_reserved = 0;        // queries of such launches served again on the scan kernel (counter 25)
-    int32_t opt_gather = 1;            // ls_search: callers of long passes are gathered into one pass (debug option 20)
+    int32_t opt_early_cap = 8;         // ls_search: callers up to which a second batch goes early (debug option 21)
+    int32_t opt_gather = 2;            // ls_search: callers of long passes are gathered into one pass (debug option 20)
     double call_us_est = 0.0;          // running estimate of one combined call, begin to finish (under q_mu)
     bool reserving = false;            // (that second serve is being queued: its selection takes its own launch)
     // ... and so do pipelined / synchronous DEVICE-output calls: the launch keeps its raw queries (slot of

@@ -122,6 +122,6 @@ def test_default_line_carries_both_metric_halves_and_host_api():
         assert x["recall_at_k"] == 1.0 and x["roofline"]["kernel"] == "ls_mq_kernel"
         assert x["parity"]["kernel_order_mismatches"] == 0 and x["parity"]["bit_identical_queries"] == 8
     cc = out["host_api"]["concurrent_callers"]
-    assert cc["callers_2"]["queries_per_s"] > cc["callers_1"]["queries_per_s"] and cc["overlapped_calls"] > 0
+    assert cc["callers_2"]["queries_per_s"] > cc["callers_1"]["queries_per_s"] and cc["combined_batches"] > 0
     cp = out["host_api"]["concurrent_callers_c2p"]  # long passes: the callers are gathered into one pass
     assert cp["callers_4"]["queries_per_s"] > 1.5 * cp["callers_1"]["queries_per_s"]

@@ -104,8 +104,11 @@ def test_two_alternating_callers_overlap_and_stay_exact():
         want = [ix.search(pool[i:i + 1], 50) for i in range(32)]
         oracle.compare_kernel_order(np.concatenate([w[0] for w in want[:4]]), np.concatenate([w[1] for w in want[:4]]),
                                     corpus, pool[:4], 50, orders=("scan",))
-        for overlap in (1, 0):
+        # (gather: 0 = the two-deep overlap decides, round 5's first form; 2 = the shipped default, callers are
+        # gathered into shared passes and nothing goes early)
+        for overlap, gather in ((1, 0), (0, 0), (1, 2)):
             ix.debug_option(17, overlap)
+            ix.debug_option(20, gather)
             before = ix.debug_counter(24)
             errors, stop = [], threading.Event()
 
@@ -134,10 +137,10 @@ def test_two_alternating_callers_overlap_and_stay_exact():
                 th.join()
             stop.set()
             m.join()
-            assert not errors, (overlap, errors[:5])
-            if overlap:
+            assert not errors, (overlap, gather, errors[:5])
+            if overlap and not gather:
                 assert ix.debug_counter(24) > before, "two alternating callers never overlapped"
-            else:
+            elif not overlap:
                 assert ix.debug_counter(24) == before
     finally:
         ix.close()

@@ -62,6 +62,7 @@ int main(int argc, char** argv) {
         if (create(&ix, corpus, n, d, 0, 0)) { printf("ls_create: %s\n", lasterr()); return 1; }
         option(ix, 17, overlap);
         if (gather >= 0) option(ix, 20, gather);
+        if (argc > 5) option(ix, 21, atoi(argv[5]));  /* debug option 21: callers up to which a second batch goes early */
         {
             float* D = malloc(sizeof(float) * k); int64_t* I = malloc(sizeof(int64_t) * k);
             for (int i = 0; i < 50; ++i) search(ix, q, 1, k, 1u, D, I);

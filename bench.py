@@ -706,6 +706,30 @@ def run_callers(env: Env, workload: str = "c2", secs: float = 0.6) -> dict:
     return out
 
 
+def run_callers_c() -> dict:
+    """The same measurement from C threads (tools/callers_c.c, built with gcc on the spot): what the library's
+    caller gathering delivers without the Python threads' GIL hand-offs. One 0.8 s run per point."""
+    import re
+    import subprocess
+    import tempfile
+
+    root = os.path.dirname(os.path.abspath(__file__))
+    from lean_explore_amd import native
+
+    lib = os.environ.get("LEANSEARCH_LIB") or os.path.join(root, "lean-explore_amd", "libleansearch.so")
+    native.load()  # (fails loudly if the library is missing)
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "callers_c")
+        subprocess.run(["gcc", "-O2", os.path.join(root, "tools", "callers_c.c"), "-o", exe, "-ldl", "-lm", "-lpthread"],
+                       check=True, capture_output=True, timeout=120)
+        txt = subprocess.run([exe, lib, "1", "-1", "1"], check=True, capture_output=True, timeout=300, text=True).stdout
+    out = {"harness": "tools/callers_c.c: T pthreads, one synchronous single-query ls_search per call, 0.8 s per point"}
+    for m in re.finditer(r"N=(\d+) d=(\d+) k=(\d+),\s+(\d+) callers:\s+(\d+) q/s, p50 ([\d.]+) us", txt):
+        n, d, k, T, qps, p50 = m.groups()
+        out.setdefault(f"N={n} d={d} k={k}", {})[f"callers_{T}"] = {"queries_per_s": float(qps), "p50_us": float(p50)}
+    return out
+
+
 def run_bm25(n_docs: int = 200_000, k: int = 1000, calls: int = 300) -> dict:
     """BM25+ name retrieval (reference search/engine.py:192-223; bm25s's eager-sparse
     scoring) on the HIP kernels: one 3-token query over `n_docs` synthetic declaration names, synchronous
@@ -847,6 +871,10 @@ def main():
             host_api["concurrent_callers_c2p"] = run_callers(env, "c2p", secs=0.5)  # (the reference's call shape)
         except Exception as e:
             host_api["concurrent_callers"] = {"error": repr(e)}
+        try:
+            host_api["concurrent_callers_c_threads"] = run_callers_c()
+        except Exception as e:
+            host_api["concurrent_callers_c_threads"] = {"error": repr(e)}
 
     if env.rank == 0:
         out = {

@@ -368,7 +368,12 @@ static int64_t scan_group_count(const ls_index* ix, int64_t nq, int32_t k) {
 }
 
 #define LS_GATHER_SLOW_US 110.0  // a combined call longer than this is a "long pass" (ls_search)
-#define LS_GATHER_MAX_US 60.0
+#ifndef LS_GATHER_MAX_US
+#define LS_GATHER_MAX_US 60.0    // the longest a leader waits for the callers seen lately ...
+#endif
+#ifndef LS_GATHER_DIV
+#define LS_GATHER_DIV 3.0        // ... and the fraction of a call's running estimate it may spend on that
+#endif
 #define LS_MQ_KEEP_SLOTS 256  // ls_mq launches without score vectors between two repairs (device-output calls)
 static int mq_repair(ls_index* ix);
 
@@ -1618,7 +1623,13 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             // 16 callers 76.5 k early vs 81.2 k waiting, 8 callers 51.4 k vs 45.9 k, 4 callers 32.9 k vs 25.6 k)
             // (long passes - d = 1024: 140 us - gain nothing from running two at once, they share one HBM; their
             // callers are gathered into ONE pass instead, below)
-            if (ix->opt_gather == 2 || (ix->opt_gather && ix->call_us_est > LS_GATHER_SLOW_US)) return false;
+            if (ix->opt_gather && ix->call_us_est > LS_GATHER_SLOW_US) return false;
+            // (with the gather on, only STRAGGLERS of a short pass go early: every caller seen lately is in flight
+            // or queued, so waiting could add nobody - Python threads hand the GIL around and arrive spread over
+            // more than the gather window: 8 Python callers 46.6 k -> 51-67 k q/s, C threads unchanged at 75-80 k)
+            if (ix->opt_gather == 2)
+                return ix->opt_overlap_calls && ix->calls_in_flight < LS_HOST_SLOTS && total > 2 &&
+                       total >= ix->peak_callers && total <= ix->opt_early_cap;
             return ix->opt_overlap_calls && ix->calls_in_flight < LS_HOST_SLOTS &&
                    (total <= 2 || (total >= ix->peak_callers && total <= ix->opt_early_cap));
         };
@@ -1637,15 +1648,15 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
                 ix->q_cv.wait(lk);
         }
         // Gather (round 5; first for long passes only, then for all - 2 / 4 / 8 callers at d = 384: 23.7 / 40.0 /
-        // 64-75 k -> 26 / 46.5 / 70 k q/s, d = 1024: 8.7 / 15.0 / 30.0 -> 12.1 / 22.5 / 36.5 k; with it no batch goes
-        // early any more): nothing is in flight and fewer requests are queued than callers were
+        // 64-75 k -> 26 / 46.5 / 70 k q/s, d = 1024: 8.7 / 15.0 / 30.0 -> 12.1 / 22.5 / 36.5 k; with it only stragglers
+        // go early, above): nothing is in flight and fewer requests are queued than callers were
         // seen lately - the others are on their way back from the pass that just ended (their results were
         // handed out microseconds ago). Launching now would split the callers into two groups that wait for each
         // other's pass forever (4 callers, d = 1024: 2 + 2, every call 2 x 158 us); a short wait puts them all
         // into ONE pass. Bounded by a third of the running estimate of a call, at most LS_GATHER_MAX_US.
         if (ix->opt_gather && ix->calls_in_flight == 0 && (int64_t)ix->req_q.size() < ix->peak_callers &&
             (ix->opt_gather == 2 || ix->call_us_est > LS_GATHER_SLOW_US || ix->peak_callers > ix->opt_early_cap)) {
-            const double budget_us = std::min<double>(LS_GATHER_MAX_US, ix->call_us_est / 3.0);
+            const double budget_us = std::min<double>(LS_GATHER_MAX_US, ix->call_us_est / LS_GATHER_DIV);
             const auto t0 = std::chrono::steady_clock::now();
             while ((int64_t)ix->req_q.size() < ix->peak_callers) {
                 const uint64_t seen = ix->q_epoch.load(std::memory_order_acquire);

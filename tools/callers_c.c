@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
     int (*option)(ls_index*, int32_t, int32_t) = dlsym(lib, "ls_debug_option");
     const char* (*lasterr)(void) = dlsym(lib, "ls_last_error");
     const int overlap = argc > 2 ? atoi(argv[2]) : 1;  /* debug option 17: synchronous calls overlap two deep */
-    const int gather = argc > 3 ? atoi(argv[3]) : -1;  /* debug option 20: 0 off, 1 long passes (default), 2 always */
+    const int gather = argc > 3 ? atoi(argv[3]) : -1;  /* debug option 20: 0 off, 1 long passes only, 2 always (default) */
     const int shapes[2][3] = {{200000, 384, 50}, {200000, 1024, 1000}};
     for (int c = 0; c < 2; ++c) {
         const int64_t n = shapes[c][0];

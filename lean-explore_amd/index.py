@@ -286,7 +286,7 @@ class FlatIPIndex:
 
     def search_device(self, q, k: int, out_scores=None, out_indices=None, *,
                       normalize: bool = False, asynchronous: bool = False,
-                      pipeline: bool = False, stream=None):
+                      pipeline: bool = False, inorder: bool = False, stream=None):
         """Search with torch CUDA tensors (queries and results stay in HBM).
 
         q: float32 CUDA tensor [nq, d]. Work is queued on ``stream`` (default: torch's current
@@ -298,7 +298,10 @@ class FlatIPIndex:
         ``q`` may be reused at once in stream order). On a sharded index (``devices=[...]``) ``q``
         and the outputs live on ``devices[0]``.
         ``pipeline``: queue on the index's internal lanes so consecutive calls overlap; results
-        are valid only after :meth:`check`.
+        are valid only after :meth:`check` (scan-path launches write no score vectors: a query whose
+        selection could not prove its result complete is served again in place there). ``inorder``
+        (LS_FLAG_INORDER): the caller consumes pipelined scan-path results on the GPU before
+        :meth:`check`; launches then keep their score vectors and are exact in the lanes' order.
         """
         import torch
 
@@ -314,7 +317,8 @@ class FlatIPIndex:
         s = stream if stream is not None else torch.cuda.current_stream(q.device)
         flags = (native.LS_FLAG_NORMALIZE if normalize else 0) | \
                 (native.LS_FLAG_ASYNC if asynchronous else 0) | \
-                (native.LS_FLAG_PIPELINE if pipeline else 0)
+                (native.LS_FLAG_PIPELINE if pipeline else 0) | \
+                (native.LS_FLAG_INORDER if inorder else 0)
         native.check(native.load().ls_search_device(h, q.data_ptr(), nq, int(k), flags,
                                                     out_scores.data_ptr(), out_indices.data_ptr(),
                                                     s.cuda_stream))

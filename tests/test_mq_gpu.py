@@ -249,3 +249,22 @@ def test_single_query_device_calls_without_score_vector_are_repaired(dtype):
     if dtype == "f32":
         oracle.compare_kernel_order(ref[0][0].cpu().numpy(), ref[0][1].cpu().numpy(), c, q[:1], 64, orders=("scan",))
     ix.close()
+
+
+def test_inorder_flag_keeps_pipelined_results_exact_before_check():
+    """LS_FLAG_INORDER (what the torchrun exchange passes): pipelined scan-path launches keep their score vectors,
+    so an unproven query is rescued inside the stream - nothing is left for ls_check to repair."""
+    import torch
+
+    c = H.gauss(3, 60_000, 384)
+    q = H.gauss(4, 6, 384)
+    c = np.ascontiguousarray(c[np.argsort(c @ q[0])])
+    ix = FlatIPIndex.from_array(c)
+    tq = torch.from_numpy(q).cuda()
+    before = ix.debug_counter(25)
+    outs = [ix.search_device(tq[:m], 100, pipeline=True, inorder=True) for m in (6, 1, 3, 1)]
+    ix.check()
+    assert ix.debug_counter(25) == before and ix.debug_counter(0) >= 1
+    for m, (Dt, It) in zip((6, 1, 3, 1), outs):
+        oracle.compare_kernel_order(Dt.cpu().numpy(), It.cpu().numpy(), c, q[:m], 100, orders=("scan",))
+    ix.close()

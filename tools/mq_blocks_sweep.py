@@ -6,7 +6,7 @@ for (n, d) in ((200_000, 384), (200_000, 768), (200_000, 1024)):
     c = H.gauss(1234, n, d)
     ix = FlatIPIndex.from_array(c)
     q = torch.from_numpy(H.gauss(5678, 16, d)).cuda()
-    for blocks in (0, 256, 0, 256, 241):
+    for blocks in (0, 256, 0, 482, 512):
         ix.debug_option(7, blocks)
         for _ in range(30): ix.search_device(q, 50, pipeline=True)
         ix.check(); ix.set_profiling(True)

@@ -315,6 +315,10 @@ int ls_set_base(ls_index* ix, int64_t base) {
     // batches already submitted must be numbered with the base they were submitted under
     LS_HIP(hipSetDevice(ix->device));
     if (int rc = ls_i_flush_deferred(ix)) return rc;
+    // ... and so must the queries a pending repair will serve again (ls_mq / scan launches without score vectors,
+    // unchecked batched calls): repair them now, under the old base
+    if (int rc = ls_i_flush_pending(ix)) return rc;
+    if (int rc = ls_i_batched_repair(ix)) return rc;
     ix->base = base;
     return LS_OK;
 }

@@ -268,3 +268,25 @@ def test_inorder_flag_keeps_pipelined_results_exact_before_check():
     for m, (Dt, It) in zip((6, 1, 3, 1), outs):
         oracle.compare_kernel_order(Dt.cpu().numpy(), It.cpu().numpy(), c, q[:m], 100, orders=("scan",))
     ix.close()
+
+
+def test_set_base_repairs_pending_queries_under_the_old_base():
+    """A pipelined launch without score vectors that raised repair words, then ls_set_base before ls_check: the
+    queries are served again under the base they were submitted with (ls_set_base repairs first)."""
+    import torch
+
+    from lean_explore_amd import native
+
+    c = H.gauss(31, 50_000, 384)
+    q = H.gauss(32, 5, 384)
+    ix = FlatIPIndex.from_array(c)
+    tq = torch.from_numpy(q).cuda()
+    D0, I0 = ix.search(q, 64)
+    ix.debug_option(0, 1)  # k' = 1: every query needs the repair
+    Dt, It = ix.search_device(tq, 64, pipeline=True)
+    native.check(native.load().ls_set_base(ix._handle, 1_000_000))
+    ix.check()
+    assert np.array_equal(Dt.cpu().numpy(), D0) and np.array_equal(It.cpu().numpy(), I0)
+    D1, I1 = ix.search(q, 64)
+    assert np.array_equal(D1, D0) and np.array_equal(I1, I0 + 1_000_000)
+    ix.close()

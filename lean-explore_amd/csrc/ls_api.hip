@@ -638,6 +638,15 @@ static int mq_repair(ls_index* ix) {
     const bool was = ix->reserving, rep = ix->dev_call_repairable;
     ix->reserving = true;  // (its launches keep their score vectors and are final when they return)
     ix->dev_call_repairable = false;
+    // (a repair never answers through a host call's completion words, whatever context it runs in)
+    u32* const sv_done = ix->done_base;
+    auto* const sv_gran = ix->gran_out_base;
+    auto* const sv_retry = ix->cur_retry;
+    const int sv_gen = ix->force_gen;
+    ix->done_base = nullptr;
+    ix->gran_out_base = nullptr;
+    ix->cur_retry = nullptr;
+    ix->force_gen = -1;
     int rc = LS_OK;
     for (const auto& pc : pend) {
         const u32* fl = ix->h_mq_flags + (size_t)pc.slot * LS_QUERIES_PER_LAUNCH_MAX;
@@ -653,6 +662,10 @@ static int mq_repair(ls_index* ix) {
     }
     ix->reserving = was;
     ix->dev_call_repairable = rep;
+    ix->done_base = sv_done;
+    ix->gran_out_base = sv_gran;
+    ix->cur_retry = sv_retry;
+    ix->force_gen = sv_gen;
     if (rc != LS_OK) return rc;
     if (any) {
         LS_HIP(hipMemsetAsync(ix->d_mq_flags, 0, sizeof(u32) * used, last));

@@ -1686,7 +1686,13 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
                         late = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > budget_us;
                 }
                 lk.lock();
-                if (late) break;
+                if (late) {
+                    // the callers that did not come are gone (or slower than the window): stop waiting for them
+                    // quickly - a lone caller after a burst of 16 would otherwise pay the window for ~500 calls
+                    const int64_t here = ix->requests_in_flight + (int64_t)ix->req_q.size();
+                    ix->peak_callers = std::max<int64_t>(here, ix->peak_callers - std::max<int64_t>(1, ix->peak_callers / 4));
+                    break;
+                }
             }
         }
         ls_served sv;

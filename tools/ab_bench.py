@@ -41,7 +41,7 @@ for r in range(args.rounds):
             print(l, "FAILED", p.stderr[-500:])
             continue
         o = json.loads(line[-1])
-        res[l].append((o["roofline"]["kernel_ms"], o["ms_per_step"], o["recall_at_k"], o["repaired_queries"]))
+        res[l].append((o["roofline"]["kernel_ms"], o["ms_per_step"], o["recall_at_k"], o.get("repaired_queries")))
         print(f"round {r} {l:12s} kernel_ms {o['roofline']['kernel_ms']:.4f}  ms_per_step {o['ms_per_step']:.4f} "
               f"recall {o['recall_at_k']} repaired {o['repaired_queries']}", flush=True)
 print(json.dumps({l: {"kernel_ms_median": statistics.median(x[0] for x in v),

@@ -110,9 +110,9 @@ static int alloc_rows(ls_index* ix, int64_t new_n, bool amortise) {
             stride = (want + 63) / 64 * 64;
             bool ok = new_n == 0 ||
                       hipMalloc(&d_new, (size_t)(want + LS_CORPUS_PAD_ROWS) * row_bytes) == hipSuccess;
+            if (ix->s_vecs <= 0) ix->s_vecs = 8;  // (one VALU scan group; grow_score_vectors when a launch needs more)
             for (int i = 0; ok && i < LS_NSETS; ++i)
-                ok = hipMalloc((void**)&S_new[i], sizeof(float) * (size_t)stride * LS_QUERIES_PER_LAUNCH_MAX) ==
-                     hipSuccess;
+                ok = hipMalloc((void**)&S_new[i], sizeof(float) * (size_t)stride * ix->s_vecs) == hipSuccess;
             if (ok) break;
             (void)hipGetLastError();
             (void)hipFree(d_new);
@@ -349,25 +349,77 @@ int ls_i_flush_pending(ls_index* ix) {
     if (np == 0) return LS_OK;
     ix->n_pending = 0;
     ls_fin_batch jobs = ix->pending;
-    for (int i = 0; i < np; ++i) jobs.p[i].keys_cap = LS_FINAL_CAP;
+    jobs.njobs = np;
+    jobs.p0.keys_cap = LS_FINAL_CAP;
     ix->n_launches_total++;
-    return ls_launch_finalize(jobs, np, ix->pending_stream);  // one launch, one workgroup per job
+    return ls_launch_finalize(jobs, ix->pending_stream);  // one launch, one workgroup per job
+}
+
+// The score vectors S (what a selection's rescue sweeps) are kept for 8 queries per generation - one VALU scan
+// group - until a launch that writes them serves more: ls_mq launches of LS_FLAG_ASYNC-only / LS_FLAG_INORDER
+// calls (every other ls_mq launch writes none: skip_scores below). 2 generations x 32 vectors x n floats would be
+// 3.2 GB on a 12.5 M-row shard that never uses them. Drains the device: nothing queued may still
+// use the old vectors.
+static int grow_score_vectors(ls_index* ix, int need) {
+    if (need <= ix->s_vecs) return LS_OK;
+    const int want = need <= 8 ? 8 : (need <= 16 ? 16 : LS_QUERIES_PER_LAUNCH_MAX);
+    if (int rc = ls_i_flush_pending(ix)) return rc;  // (its jobs name the old vectors)
+    LS_HIP(hipDeviceSynchronize());
+    float* S_new[LS_NSETS] = {};
+    for (int i = 0; i < LS_NSETS; ++i) {
+        if (hipMalloc((void**)&S_new[i], sizeof(float) * (size_t)ix->s_stride * want) != hipSuccess) {
+            (void)hipGetLastError();
+            for (auto& p : S_new) (void)hipFree(p);
+            ls_set_error("out of device memory for %d score vectors of %lld rows", want, (long long)ix->s_stride);
+            return LS_ERR_HIP;
+        }
+    }
+    for (int i = 0; i < LS_NSETS; ++i) {
+        (void)hipFree(ix->sets[i].d_S);
+        ix->sets[i].d_S = S_new[i];
+    }
+    ix->s_vecs = want;
+    return LS_OK;
+}
+
+// ls_mq launch geometry for `nq` queries of one pass (ls_mq.hip): workgroups, k', keys per lane (0: not usable)
+struct mq_plan {
+    int blocks, kprime, keys;
+};
+static mq_plan mq_make_plan(const ls_index* ix, int nq, int32_t k) {
+    mq_plan p{0, 0, 0};
+    if (!(ix->opt_mq && ix->opt_multi_query && ix->dtype == LS_DTYPE_F32 && ix->n >= LS_MQ_MIN_ROWS)) return p;
+    const int keff = (int)std::max<int64_t>(std::min<int64_t>(k, ix->n), 1);
+    p.blocks = ix->opt_blocks > 0 ? std::min(ix->opt_blocks, ix->max_blocks) : ls_mq_blocks(ix->n, ix->n_cu, nq, ix->g.chunks);
+    p.kprime = pick_kprime(ix, p.blocks, keff);
+    p.keys = ls_mq_lane_keys(p.blocks, keff, nq);
+    if (p.keys == 3 && p.kprime + 1 > ls_mq_waves(nq) * 3) p.keys = 5;  // the workgroup ranks waves x keys: k' + 1 of them go out
+    return p;
+}
+// Queries one ls_mq pass may carry on this index for this k: 32 (two 16-column MFMA blocks per A operand), or
+// 0 when the kernel is not usable (fp16 storage, small shards, k too large for the shard).
+static int mq_max_queries(const ls_index* ix, int32_t k) {
+    if (!ix->opt_mq32) return mq_make_plan(ix, 16, k).keys > 0 ? 16 : 0;
+    return mq_make_plan(ix, LS_QUERIES_PER_LAUNCH_MAX, k).keys > 0 ? LS_QUERIES_PER_LAUNCH_MAX
+                                                                    : (mq_make_plan(ix, 16, k).keys > 0 ? 16 : 0);
+}
+// The most queries a call may bring and still be served by the exact scan path (ls_search's combining queue, the
+// polling host call): one ls_mq pass where that kernel serves the index, else LS_SCAN_PATH_MAX_NQ.
+static int scan_path_max_nq(const ls_index* ix, int32_t k) {
+    return std::max(LS_SCAN_PATH_MAX_NQ, mq_max_queries(ix, k));
 }
 
 // Launches (query groups) the scan path will use for a call of nq queries: ONE definition, shared by the
 // scheduling below and by the host API's decision to overlap a call (a call that owns one scratch generation
 // must be a single group).
+static int scan_group_size(const ls_index* ix, int64_t left, int mq_max) {
+    if (mq_max > 0 && left >= 2) return (int)std::min<int64_t>(left, mq_max);
+    return !ix->opt_multi_query ? 1 : (left >= 5 ? (int)std::min<int64_t>(left, 8) : (left >= 2 ? (int)std::min<int64_t>(left, 4) : 1));
+}
 static int64_t scan_group_count(const ls_index* ix, int64_t nq, int32_t k) {
-    const int64_t keff = std::min<int64_t>(k, ix->n);
-    const int mq_blocks = ix->opt_blocks > 0 ? std::min(ix->opt_blocks, ix->max_blocks)
-                                             : ls_mq_blocks(ix->n > 0 ? ix->n : 1, ix->n_cu);
-    const bool mq_ok = ix->opt_mq && ix->opt_multi_query && ix->dtype == LS_DTYPE_F32 && ix->n >= LS_MQ_MIN_ROWS &&
-                       ls_mq_lane_keys(mq_blocks, (int)std::max<int64_t>(keff, 1)) > 0;
+    const int mq_max = mq_max_queries(ix, k);
     int64_t groups = 0;
-    for (int64_t left = nq; left > 0; ++groups) {
-        if (mq_ok && left >= 2) left -= std::min<int64_t>(left, LS_QUERIES_PER_LAUNCH_MAX);
-        else left -= !ix->opt_multi_query ? 1 : (left >= 5 ? std::min<int64_t>(left, 8) : (left >= 2 ? std::min<int64_t>(left, 4) : 1));
-    }
+    for (int64_t left = nq; left > 0; ++groups) left -= scan_group_size(ix, left, mq_max);
     return groups;
 }
 
@@ -392,16 +444,9 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
     const int scan_blocks = ix->opt_blocks > 0 ? std::min(ix->opt_blocks, ix->max_blocks)
                                                : ls_scan_blocks(ix->n > 0 ? ix->n : 1, g, ix->n_cu);
     const int scan_kprime = pick_kprime(ix, scan_blocks, (int)std::max<int64_t>(keff, 1));
-    // fp32 index, two or more queries left: up to 16 of them share one pass on the f32 matrix cores
+    // fp32 index, two or more queries left: up to 32 of them share one pass on the f32 matrix cores
     // (ls_mq.hip; same bits as the scan kernel, so a query's results do not depend on its company)
-    const int mq_blocks = ix->opt_blocks > 0 ? std::min(ix->opt_blocks, ix->max_blocks)
-                                             : ls_mq_blocks(ix->n > 0 ? ix->n : 1, ix->n_cu);
-    const int mq_kprime = pick_kprime(ix, mq_blocks, (int)std::max<int64_t>(keff, 1));
-    int mq_keys = ls_mq_lane_keys(mq_blocks, (int)std::max<int64_t>(keff, 1));
-    if (mq_keys == 3 && mq_kprime + 1 > 4 * 3) mq_keys = 5;  // the workgroup ranks 4 x keys: k' + 1 of them go out
-
-    const bool mq_ok = ix->opt_mq && ix->opt_multi_query && ix->dtype == LS_DTYPE_F32 && ix->n >= LS_MQ_MIN_ROWS &&
-                       mq_keys > 0;
+    const int mq_max = mq_max_queries(ix, k);
     // scratch generations this call will use: a same-launch job's retry reads its generation's S and
     // granules after the host has seen its answer, so such a call must not wrap around the LS_NSETS
     // generations (one query per launch - debug option 6 - and 3+ queries would: ADVICE r4)
@@ -430,17 +475,21 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
     for (int64_t q0 = 0; q0 < nq;) {
         const int64_t left = nq - q0;
         // queries per launch: 8 or 4 with the last real query repeated as padding, or 1
-        const bool use_mq = mq_ok && left >= 2;
-        const int NQ = use_mq ? (int)std::min<int64_t>(left, LS_QUERIES_PER_LAUNCH_MAX)
-                              : (!ix->opt_multi_query ? 1 : (left >= 5 ? 8 : (left >= 2 ? 4 : 1)));
+        const bool use_mq = mq_max > 0 && left >= 2;
+        const int gsz = scan_group_size(ix, left, mq_max);
+        const int NQ = use_mq ? gsz : (!ix->opt_multi_query ? 1 : (left >= 5 ? 8 : (left >= 2 ? 4 : 1)));
         const int real = (int)std::min<int64_t>(NQ, left);
         if ((use_mq || NQ == 1) && ix->dev_call_repairable && !ix->reserving &&
             ((int)ix->mq_pend.size() >= LS_MQ_KEEP_SLOTS || (ix->d_mq_keep && ix->mq_keep_d != g.d))) {
             rc = mq_repair(ix);  // the ring of kept queries is full: make what is pending final first
             if (rc != LS_OK) return rc;
         }
-        const int blocks = use_mq ? mq_blocks : scan_blocks;
-        const int kprime = use_mq ? mq_kprime : scan_kprime;
+        // (an ls_mq launch's geometry depends on its query count: 17..32 queries run the two-block kernel, one
+        // workgroup per CU with the selection workgroups' CUs left free)
+        const mq_plan mp = use_mq ? mq_make_plan(ix, NQ, k) : mq_plan{0, 0, 0};
+        const int mq_keys = mp.keys;
+        const int blocks = use_mq ? mp.blocks : scan_blocks;
+        const int kprime = use_mq ? mp.kprime : scan_kprime;
         const bool prof = ix->profiling && ix->prof_n < LS_PROF_MAX;
         hipEvent_t* pe = nullptr;
         if (prof) {
@@ -478,15 +527,30 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             keff <= 256 &&  // (k > 256 orders its result on 1024 threads: own launch)
             (int64_t)blocks * (kprime + 1) <= LS_GRAN_MAX &&
             ls_fin_lds_bytes_host(own_keys_cap, (int)std::max<int64_t>(keff, 1)) <= LS_PIGGY_LDS_MAX;
+        // An ls_mq launch whose selection jobs ride along (synchronous host calls) writes NO score vectors: such
+        // a job never reads S inside the launch anyway (it answers LS_DONE_RETRY), and its retry serves the
+        // query again, alone, on the scan kernel - the same bits (host_call_finish). The 16 x n x 4 bytes of
+        // stores cost 3 us of 57 (d = 384) and 4..29 us of 140..167 (d = 1024, 2..16 queries) at N = 200 k.
+        // (k > 256: the selection has its own launch behind the pass; without S it answers the same way)
+        const bool host_words = !pipeline && ix->done_base != nullptr && ix->cur_retry != nullptr && !ix->reserving;
+        // (device-output calls whose results ls_check may still repair: mq_repair; never a repair's own launch)
+        const bool dev_keep = (use_mq || (NQ == 1 && ix->opt_scan_skip_scores)) && ix->dev_call_repairable &&
+                              !ix->reserving && ix->done_base == nullptr && ix->opt_mq_skip_scores && ix->n > 0;
+        // (single queries of synchronous host calls too - the reference's call: 0.5-1 us of 47 / 122)
+        const bool skip_scores = ((same_launch || host_words) && ix->opt_mq_skip_scores) || dev_keep;
+        if (!skip_scores && NQ > ix->s_vecs) {  // a wide launch that keeps its score vectors (rare: grow_score_vectors)
+            if ((rc = grow_score_vectors(ix, NQ)) != LS_OK) return rc;  // (flushes the pending jobs, drains the device)
+        }
         if (ix->n_pending && same_launch) {  // left by an earlier pipelined call: its own launch
             rc = ls_i_flush_pending(ix);
             if (rc != LS_OK) return rc;
         }
         if (ix->n_pending) {
-            const int keff_p = (int)std::min<int64_t>(ix->pending.p[0].k, ix->n);
-            if (ls_fin_lds_bytes_host(ix->pending.p[0].keys_cap, keff_p) <= LS_PIGGY_LDS_MAX) {
+            const int keff_p = (int)std::min<int64_t>(ix->pending.p0.k, ix->n);
+            if (ls_fin_lds_bytes_host(ix->pending.p0.keys_cap, keff_p) <= LS_PIGGY_LDS_MAX) {
                 a.nfin = ix->n_pending;
                 a.fin = ix->pending;
+                a.fin.njobs = ix->n_pending;
             } else {
                 rc = ls_i_flush_pending(ix);
                 if (rc != LS_OK) return rc;
@@ -507,17 +571,6 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
         a.nq = NQ;
         a.normalize = normalize;
         a.reverse = ix->opt_alternate && (ix->sweep_count++ & 1);
-        // An ls_mq launch whose selection jobs ride along (synchronous host calls) writes NO score vectors: such
-        // a job never reads S inside the launch anyway (it answers LS_DONE_RETRY), and its retry serves the
-        // query again, alone, on the scan kernel - the same bits (host_call_finish). The 16 x n x 4 bytes of
-        // stores cost 3 us of 57 (d = 384) and 4..29 us of 140..167 (d = 1024, 2..16 queries) at N = 200 k.
-        // (k > 256: the selection has its own launch behind the pass; without S it answers the same way)
-        const bool host_words = !pipeline && ix->done_base != nullptr && ix->cur_retry != nullptr && !ix->reserving;
-        // (device-output calls whose results ls_check may still repair: mq_repair; never a repair's own launch)
-        const bool dev_keep = (use_mq || (NQ == 1 && ix->opt_scan_skip_scores)) && ix->dev_call_repairable &&
-                              !ix->reserving && ix->done_base == nullptr && ix->opt_mq_skip_scores && ix->n > 0;
-        // (single queries of synchronous host calls too - the reference's call: 0.5-1 us of 47 / 122)
-        const bool skip_scores = ((same_launch || host_words) && ix->opt_mq_skip_scores) || dev_keep;
         int keep_slot = -1;
         if (dev_keep) {
             if (!ix->d_mq_keep || ix->mq_keep_d != g.d) {
@@ -559,30 +612,37 @@ static int scan_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int
             a.g_stride = LS_GRAN_MAX;
             a.tag = ix->gran_tag;
         }
-        for (int i = 0; i < real; ++i) {
-            ls_fin_params& p = jobs.p[i];
-            p.S = skip_scores ? nullptr : st.d_S + (size_t)i * a.s_stride;
+        {
+            // the group's jobs differ by whole-query displacements only: job 0 + strides (ls_fin_batch)
+            ls_fin_params& p = jobs.p0;
+            p.S = skip_scores ? nullptr : st.d_S;
             p.n = ix->n;
-            p.cand = st.d_cand + (size_t)i * a.c_stride;
-            p.bound = st.d_bound + (size_t)i * a.b_stride;
+            p.cand = st.d_cand;
+            p.bound = st.d_bound;
             p.blocks = blocks;
             p.kprime = kprime;
             p.k = k;
             p.keys_cap = own_keys_cap;
             p.force_slow = ix->opt_force_slow;
             p.base = ix->base;
-            p.out_scores = d_out_s + (q0 + i) * k;
-            p.out_indices = (long long*)(d_out_i + (q0 + i) * k);
+            p.out_scores = d_out_s + q0 * k;
+            p.out_indices = (long long*)(d_out_i + q0 * k);
             p.counters = ix->d_counters;
-            p.done = ix->done_base ? ix->done_base + (q0 + i) : nullptr;
-            p.out_gran = ix->gran_out_base && k <= LS_OUT_GRAN_MAX_K ? ix->gran_out_base + (size_t)(q0 + i) * k : nullptr;
+            p.done = ix->done_base ? ix->done_base + q0 : nullptr;
+            p.out_gran = ix->gran_out_base && k <= LS_OUT_GRAN_MAX_K ? ix->gran_out_base + (size_t)q0 * k : nullptr;
             p.done_val = ix->cur_done_seq;
-            p.gran = same_launch ? (const char*)st.d_gran + (size_t)i * LS_GRAN_MAX * 16 : nullptr;
+            p.gran = same_launch ? st.d_gran : nullptr;
             p.tag = same_launch ? ix->gran_tag : 0u;
             p.wait = same_launch ? 1u : 0u;
-            p.repair = keep_slot >= 0 ? ix->d_mq_flags + (size_t)keep_slot * LS_QUERIES_PER_LAUNCH_MAX + i : nullptr;
+            p.repair = keep_slot >= 0 ? ix->d_mq_flags + (size_t)keep_slot * LS_QUERIES_PER_LAUNCH_MAX : nullptr;
             p.repair_any = keep_slot >= 0 ? ix->h_mq_flags + LS_MQ_KEEP_SLOTS * LS_QUERIES_PER_LAUNCH_MAX : nullptr;
-            if ((same_launch || skip_scores) && ix->cur_retry) ix->cur_retry->push_back(p);  // kept until the host has seen the answers
+            jobs.S_stride = a.s_stride;
+            jobs.cand_stride = a.c_stride;
+            jobs.bound_stride = a.b_stride;
+            jobs.gran_stride = (long long)LS_GRAN_MAX * 16;
+            jobs.njobs = real;
+            for (int i = 0; i < LS_QUERIES_PER_LAUNCH_MAX; ++i) jobs.idx[i] = (unsigned char)i;
+            if ((same_launch || skip_scores) && ix->cur_retry) ix->cur_retry->push_back(jobs);  // kept until the host has seen the answers
         }
         if (prof) LS_HIP(hipEventRecord(pe[0], s));
         rc = use_mq ? ls_launch_mq(ix->d_corpus, ix->n, g, a, s) : ls_launch_scan(ix->d_corpus, ix->n, g, a, s);
@@ -611,7 +671,10 @@ bool ls_i_batched_eligible(const ls_index* ix, int64_t nq, int32_t k) {
                      (ix->n >= LS_GEMM_MIN_ROWS_BIGNQ && nq >= LS_GEMM_BIGNQ);
     if (ix->dtype == LS_DTYPE_F16)
         return nq > LS_SCAN_PATH_MAX_NQ && ix->g.chunks <= LS_GEMM_MAX_CHUNKS && big;
-    return nq >= LS_GEMM32_MIN_NQ && big;  // fp32: exact f32 MFMA (ls_gemm32.hip), any row length
+    // fp32: exact f32 MFMA (ls_gemm32.hip), any row length - for batches past what ONE exact ls_mq pass carries
+    // (32 queries; 16 with option 22 = 0), or from LS_GEMM32_MIN_NQ on where ls_mq does not serve this (index, k)
+    const int one_pass = mq_max_queries(ix, k);
+    return big && (one_pass > 0 ? nq > std::max(one_pass, LS_GEMM32_MIN_NQ - 1) : nq >= LS_GEMM32_MIN_NQ);
 }
 
 // ls_mq launches of device-output calls that wrote no score vectors: every selection job that could not
@@ -1247,7 +1310,7 @@ static int host_call_begin_impl(ls_host_call& c) {
     }
     c.mu_lk = std::unique_lock<std::mutex>(ix->mu);
     const size_t qn = (size_t)nq * ix->g.d, on = (size_t)nq * k;
-    const bool small_call = nq <= LS_SCAN_PATH_MAX_NQ;
+    const bool small_call = nq <= scan_path_max_nq(ix, k);
     c.out_direct = on <= (size_t)(1 << 16);
     // Small scan-path calls: the finalize workgroup of every query writes tagged result granules
     // (k <= LS_OUT_GRAN_MAX_K) or drained rows + a completion word into pinned host memory; the host
@@ -1297,13 +1360,13 @@ static int host_call_begin_impl(ls_host_call& c) {
     // (only single queries: every workgroup reads the whole query block - 256 x 16 x 4 KB over PCIe otherwise)
     const bool in_direct = c.in_direct = small_call && nq == 1 && !ix->opt_query_copy;
     if (c.spin && !S.h_done) {
-        LS_HIP(hipHostMalloc((void**)&S.h_done, sizeof(u32) * LS_SCAN_PATH_MAX_NQ, hipHostMallocDefault));
-        memset(S.h_done, 0, sizeof(u32) * LS_SCAN_PATH_MAX_NQ);
+        LS_HIP(hipHostMalloc((void**)&S.h_done, sizeof(u32) * LS_QUERIES_PER_LAUNCH_MAX, hipHostMallocDefault));
+        memset(S.h_done, 0, sizeof(u32) * LS_QUERIES_PER_LAUNCH_MAX);
     }
     memcpy(S.h_q, c.q, qn * sizeof(float));
     if (!in_direct)
         LS_HIP(hipMemcpyAsync(S.d_qraw, S.h_q, qn * sizeof(float), hipMemcpyHostToDevice, s));
-    S.retry_jobs.clear();
+    S.retry_groups.clear();
     if (c.spin) {
         if (on > S.h_out_g_cap) {
             if (S.h_out_g) (void)hipHostFree(S.h_out_g);
@@ -1318,7 +1381,7 @@ static int host_call_begin_impl(ls_host_call& c) {
         ix->done_base = S.h_done;
         ix->gran_out_base = S.h_out_g;
     }
-    ix->cur_retry = &S.retry_jobs;
+    ix->cur_retry = &S.retry_groups;
     ix->cur_done_seq = S.done_seq;
     ix->force_gen = c.gen = overlapped ? (int)si : -1;
     rc = ls_i_search_on_stream(ix, in_direct ? S.h_q : S.d_qraw, nq, k, c.flags & LS_FLAG_NORMALIZE,
@@ -1429,52 +1492,50 @@ static int host_call_finish(ls_host_call& c) {
             std::unique_lock<std::mutex> relock;
             if (!c.mu_lk.owns_lock()) relock = std::unique_lock<std::mutex>(ix->mu);
             LS_HIP(hipSetDevice(ix->device));
-            ls_fin_batch jobs{};
-            int nj = 0;
-            auto flush = [&]() -> int {
-                if (!nj) return LS_OK;
-                const int r = ls_launch_finalize(jobs, nj, s);
-                ix->n_launches_total++;
-                nj = 0;
-                return r;
-            };
-            for (const ls_fin_params& p : S.retry_jobs) {
-                const int64_t qi = p.done - S.h_done;
-                if (qi < 0 || qi >= nq || S.h_done[qi] != (S.done_seq | LS_DONE_RETRY)) continue;
-                if (!p.S) {
-                    // the job rode on an ls_mq launch that wrote no score vectors: serve the query again, alone
-                    // (scan kernel: the same bits; its selection gets its own launch and answers through the
-                    // same completion word / granules). The call still owns its slot: the query copy is intact.
-                    if ((rc = flush()) != LS_OK) return rc;
-                    ix->done_base = S.h_done + qi;
-                    ix->gran_out_base = k <= LS_OUT_GRAN_MAX_K ? S.h_out_g + (size_t)qi * k : nullptr;
-                    ix->cur_retry = nullptr;
-                    ix->cur_done_seq = S.done_seq;
-                    ix->force_gen = c.gen;
-                    ix->reserving = true;
-                    rc = ls_i_search_on_stream(ix, (c.in_direct ? S.h_q : S.d_qraw) + (size_t)qi * ix->g.d, 1, k, c.flags & LS_FLAG_NORMALIZE,
-                                               (c.out_direct ? S.h_out_s : S.d_out_s) + (size_t)qi * k,
-                                               (c.out_direct ? S.h_out_i : S.d_out_i) + (size_t)qi * k, s, true);
-                    ix->reserving = false;
-                    ix->done_base = nullptr;
-                    ix->gran_out_base = nullptr;
-                    ix->force_gen = -1;
-                    if (rc != LS_OK) return rc;
-                    ix->n_mq_reserved++;
-                    continue;
+            for (const ls_fin_batch& gb : S.retry_groups) {  // one batch per launch of the call
+                if (!gb.p0.done) continue;
+                ls_fin_batch jobs = gb;  // the stand-alone finalize of the group's flagged jobs
+                jobs.njobs = 0;
+                jobs.p0.wait = 0;  // behind the kernel boundary every granule is there
+                jobs.p0.keys_cap = LS_FINAL_CAP;
+                const int64_t q0 = gb.p0.done - S.h_done;  // the group's first query within the call
+                for (int j = 0; j < gb.njobs; ++j) {
+                    const int64_t qi = q0 + gb.idx[j];
+                    if (qi < 0 || qi >= nq || S.h_done[qi] != (S.done_seq | LS_DONE_RETRY)) continue;
+                    if (!gb.p0.S) {
+                        // the job rode on a launch that wrote no score vectors: serve the query again, alone
+                        // (scan kernel: the same bits; its selection gets its own launch and answers through the
+                        // same completion word / granules). The call still owns its slot: the query copy is intact.
+                        ix->done_base = S.h_done + qi;
+                        ix->gran_out_base = k <= LS_OUT_GRAN_MAX_K ? S.h_out_g + (size_t)qi * k : nullptr;
+                        ix->cur_retry = nullptr;
+                        ix->cur_done_seq = S.done_seq;
+                        ix->force_gen = c.gen;
+                        ix->reserving = true;
+                        rc = ls_i_search_on_stream(ix, (c.in_direct ? S.h_q : S.d_qraw) + (size_t)qi * ix->g.d, 1, k, c.flags & LS_FLAG_NORMALIZE,
+                                                   (c.out_direct ? S.h_out_s : S.d_out_s) + (size_t)qi * k,
+                                                   (c.out_direct ? S.h_out_i : S.d_out_i) + (size_t)qi * k, s, true);
+                        ix->reserving = false;
+                        ix->done_base = nullptr;
+                        ix->gran_out_base = nullptr;
+                        ix->force_gen = -1;
+                        if (rc != LS_OK) return rc;
+                        ix->n_mq_reserved++;
+                        continue;
+                    }
+                    jobs.idx[jobs.njobs++] = gb.idx[j];
                 }
-                jobs.p[nj] = p;
-                jobs.p[nj].wait = 0;  // behind the kernel boundary every granule is there
-                jobs.p[nj].keys_cap = LS_FINAL_CAP;
-                if (++nj == LS_QUERIES_PER_LAUNCH_MAX && (rc = flush()) != LS_OK) return rc;
+                if (jobs.njobs) {
+                    if ((rc = ls_launch_finalize(jobs, s)) != LS_OK) return rc;
+                    ix->n_launches_total++;
+                }
             }
-            if ((rc = flush()) != LS_OK) return rc;
             ix->n_same_launch_retries++;
             if (relock.owns_lock()) relock.unlock();
             done = wait_words(false, nullptr);
         }
     }
-    S.retry_jobs.clear();
+    S.retry_groups.clear();
     if (!done) LS_HIP(hipStreamSynchronize(s));
     if (c.spin && k <= LS_OUT_GRAN_MAX_K) {
         if (done) return LS_OK;  // (unpacked while waiting)
@@ -1596,7 +1657,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
     if (nq == 0) return LS_OK;
     flags &= LS_FLAG_NORMALIZE;
     if (ls_group_is_replicated(ix)) return ls_replica_search(ix, q, nq, k, flags, out_scores, out_indices);
-    if (!ix->opt_combine || nq > LS_QUERIES_PER_LAUNCH_MAX)  // big batches gain nothing from company
+    if (!ix->opt_combine || nq > scan_path_max_nq(ix, k))  // what fills a pass by itself gains nothing from company
         return host_search_locked(ix, q, nq, k, flags, out_scores, out_indices);
     ls_req me{q, nq, k, flags, out_scores, out_indices};
     std::unique_lock<std::mutex> lk(ix->q_mu);
@@ -1698,9 +1759,11 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         ls_served sv;
         ls_req* head = ix->req_q.front();
         int64_t total = 0;
+        const int batch_cap = scan_path_max_nq(ix, head->k);  // queries ONE pass carries (32 where ls_mq serves the index)
         while (!ix->req_q.empty()) {
             ls_req* r = ix->req_q.front();
-            if (r->k != head->k || r->flags != head->flags || total + r->nq > LS_SCAN_PATH_MAX_NQ) break;
+            // (the head request always goes: an option changed since it was queued may have lowered the cap under it)
+            if (r != head && (r->k != head->k || r->flags != head->flags || total + r->nq > batch_cap)) break;
             sv.batch.push_back(r);
             r->taken = true;
             total += r->nq;
@@ -2055,9 +2118,15 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->opt_gather = value;
         return LS_OK;
     }
+    if (which == 22) {  // fp32 index: one ls_mq pass carries up to 32 queries (two MFMA B blocks per A operand; default on)
+        ix->opt_mq32 = value != 0;
+        return LS_OK;
+    }
     if (which == 19) {  // launches whose unproven queries can be served again write no score vectors (default on; 2: not the single-query device launches)
         ix->opt_mq_skip_scores = value != 0;
         ix->opt_scan_skip_scores = value == 1;
+        // (with score vectors kept no launch may find them too few while a host call is in flight: all of them now)
+        if (!value && ix->d_corpus) return grow_score_vectors(ix, LS_QUERIES_PER_LAUNCH_MAX);
         return LS_OK;
     }
     if (which == 17) {  // synchronous host calls overlap two deep (default on)

@@ -360,7 +360,8 @@ int ls_bm25_search(ls_bm25* ix, const int32_t* token_ids, int32_t n_tokens, int3
         }
         LS_HIP(hipGetLastError());
         ls_fin_batch jobs{};
-        ls_fin_params& p = jobs.p[0];
+        ls_fin_params& p = jobs.p0;
+        jobs.njobs = 1;
         p.S = ix->d_F;
         p.n = n;
         p.cand = ix->d_cand;
@@ -383,7 +384,7 @@ int ls_bm25_search(ls_bm25* ix, const int32_t* token_ids, int32_t n_tokens, int3
         if (k > LS_MAX_K) {  // only possible when k > n_docs: select LS_MAX_K >= n_docs, pad on host
             p.k = LS_MAX_K;
         }
-        int rc = ls_launch_finalize(jobs, 1, s);
+        int rc = ls_launch_finalize(jobs, s);
         if (rc != LS_OK) return rc;
         const int kk = std::min(k, LS_MAX_K);
         {

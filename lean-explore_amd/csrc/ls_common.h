@@ -101,7 +101,7 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 #endif
 #define LS_GEMM_SAMPLE_ROWS 128      // sample pass: rows per workgroup
 #define LS_GEMM_MAX_SPLITS 512       // corpus slices (4 queues each; the select kernel walks 8 per thread)
-#define LS_GEMM32_MIN_NQ 24           // fp32 index: batches at least this big take the f32 MFMA path
+#define LS_GEMM32_MIN_NQ 24           // fp32 index: batches at least this big take the f32 MFMA path (past one ls_mq pass: 33)
 
 __host__ __device__ __forceinline__ u32 ls_ord(float f) {
     f = f + 0.0f;  // folds -0.0 into +0.0
@@ -254,10 +254,35 @@ struct ls_out_gran {   // host view of one result granule
 #define LS_GRAN_MAX 4096                 // granules per query: blocks * (kprime + 1) above this -> own launch
 #define LS_BUF_RSRC_FLAGS 0x00020000     // gfx950 raw buffer descriptor, dword 3 (32-bit data format)
 #define LS_AUX_SC1 16                    // buffer load / store cache policy: write-through / L1 bypass
-#define LS_QUERIES_PER_LAUNCH_MAX 16  // (8 per VALU scan launch; 16 per f32 MFMA small-batch launch, ls_mq.hip)
+#define LS_QUERIES_PER_LAUNCH_MAX 32  // (8 per VALU scan launch; 16 or 32 per f32 MFMA small-batch launch, ls_mq.hip)
+#define LS_FIN_WG_MAX 16              // selection workgroups riding on one launch: workgroup w runs jobs w, w + 16, ..
+// The selection jobs of one launch's queries. They differ by whole-query displacements only (score vector,
+// candidate block, output rows, completion word ...), so the batch is ONE job + strides + the list of queries:
+// 230 bytes of kernel arguments for up to 32 jobs (32 full parameter sets would be 4.8 KB, past the 4 KB a
+// launch may carry). `idx` lets a retry name any subset of the group.
 struct ls_fin_batch {
-    ls_fin_params p[LS_QUERIES_PER_LAUNCH_MAX];
+    ls_fin_params p0;        // the job of the group's query 0
+    long long S_stride;      // floats between the queries' score vectors
+    long long cand_stride;   // keys between their candidate blocks
+    long long bound_stride;  // keys between their bound vectors
+    long long gran_stride;   // bytes between their granule arrays (same-launch hand-off)
+    int njobs;
+    unsigned char idx[LS_QUERIES_PER_LAUNCH_MAX];  // job j serves query idx[j] of the group
 };
+__host__ __device__ __forceinline__ ls_fin_params ls_fin_job(const ls_fin_batch& b, int j) {
+    ls_fin_params p = b.p0;
+    const long long q = b.idx[j];
+    if (p.S) p.S += q * b.S_stride;
+    if (p.cand) p.cand += q * b.cand_stride;
+    if (p.bound) p.bound += q * b.bound_stride;
+    if (p.out_scores) p.out_scores += q * p.k;
+    if (p.out_indices) p.out_indices += q * p.k;
+    if (p.out_gran) p.out_gran = (char*)p.out_gran + q * p.k * 16;  // (sizeof(ls_out_gran))
+    if (p.done) p.done += q;
+    if (p.gran) p.gran = (const char*)p.gran + q * b.gran_stride;
+    if (p.repair) p.repair += q;
+    return p;
+}
 
 // ---- kernel launchers (defined in the .hip files) ---------------------------------------------
 // prep: q_out[nq, d_pad] = pad(round(normalise(q_in[nq, d]))), fp32
@@ -272,8 +297,8 @@ int ls_launch_unconvert(const void* d_src, float* d_dst, int64_t n, const ls_geo
 // + per-workgroup best kprime keys and bound
 int ls_scan_blocks(int64_t n, const ls_geom& g, int32_t n_cu);
 // One scan launch: `nq` (1, 4 or 8) queries share one pass over the corpus; the launch may carry
-// up to LS_QUERIES_PER_LAUNCH_MAX selection jobs of the PREVIOUS launch, each executed by one extra
-// workgroup, so that selection costs neither a launch nor a kernel boundary.
+// up to LS_QUERIES_PER_LAUNCH_MAX selection jobs of the PREVIOUS launch, executed by up to LS_FIN_WG_MAX extra
+// workgroups, so that selection costs neither a launch nor a kernel boundary.
 struct ls_scan_args {
     const float* d_q;      // nq raw queries, d floats apart (normalisation / fp16 rounding fused in)
     int nq;                // 1, 4 or 8
@@ -285,7 +310,7 @@ struct ls_scan_args {
     u64* d_bound;          // blocks bounds per query, b_stride apart
     long long b_stride;
     int blocks, kprime;
-    int nfin;              // selection jobs riding on this launch
+    int nfin;              // selection jobs riding on this launch (== fin.njobs)
     ls_fin_batch fin;
     void* d_gran;          // non-null: the jobs are this launch's own and the keys go out as
     long long g_stride;    //           tagged granules (ls_fin_params::gran), g_stride granules per query
@@ -298,15 +323,16 @@ int ls_launch_scan(const void* d_corpus, int64_t n, const ls_geom& g, const ls_s
 // Small batches on an fp32 index (ls_mq.hip): a.nq = 2..16 REAL queries share one corpus pass on the f32
 // matrix cores, bit-identical to ls_launch_scan's results; same outputs, same riding selection jobs.
 #define LS_MQ_MIN_ROWS 4096              // shards below this stay on the VALU scan groups
-int ls_mq_blocks(int64_t n, int32_t n_cu);
-int ls_mq_lane_keys(int blocks, int keff);   // 3, 5, or 0 = not for this (k, shard)
+int ls_mq_blocks(int64_t n, int32_t n_cu, int nq, int chunks);
+int ls_mq_lane_keys(int blocks, int keff, int nq);   // 3, 5, 8, or 0 = not for this (k, shard)
+int ls_mq_waves(int nq);                             // waves per workgroup of the launch that serves nq queries
 int ls_launch_mq(const void* d_corpus, int64_t n, const ls_geom& g, const ls_scan_args& a, hipStream_t s);
 // LDS bytes a piggy-backed finalize may use without lowering the scan's occupancy below 2/CU
 #define LS_PIGGY_LDS_MAX (72 * 1024)
 // finalize: exact top-k from the scan's candidates (or, if they cannot be proven complete,
 // from S itself) -> out_scores[k], out_indices[k]. Either its own launch, or carried by the
 // NEXT query's scan launch as one extra workgroup (ls_launch_scan's `fin` argument).
-int ls_launch_finalize(const struct ls_fin_batch& jobs, int njobs, hipStream_t s);
+int ls_launch_finalize(const struct ls_fin_batch& jobs, hipStream_t s);  // jobs.njobs jobs
 // batched MFMA path (ls_gemm.hip)
 struct ls_gemm_bufs {
     void* d_queues;     // uint2 [nq_pad][nsplits][4][LS_GEMM_QCAP]: private candidate queues

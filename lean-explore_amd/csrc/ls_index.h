@@ -44,10 +44,10 @@ struct ls_host_slot {
     float* d_qraw = nullptr;   size_t qraw_cap = 0;     // device query copy (floats)
     float* d_out_s = nullptr;  int64_t* d_out_i = nullptr;  size_t out_cap = 0;  // nq*k (large results)
     float* h_out_s = nullptr;  int64_t* h_out_i = nullptr;  size_t h_out_cap = 0;  // pinned
-    u32* h_done = nullptr;     // pinned [LS_SCAN_PATH_MAX_NQ]: completion words
+    u32* h_done = nullptr;     // pinned [LS_QUERIES_PER_LAUNCH_MAX]: completion words
     u32 done_seq = 0;
     ls_out_gran* h_out_g = nullptr;  size_t h_out_g_cap = 0;  // pinned: result granules of a spinning call
-    std::vector<ls_fin_params> retry_jobs;  // the call's same-launch jobs (LS_DONE_RETRY)
+    std::vector<ls_fin_batch> retry_groups;  // the call's same-launch jobs, one batch per launch (LS_DONE_RETRY)
 };
 #define LS_HOST_SLOTS 2
 
@@ -83,7 +83,7 @@ struct ls_index {
     // per-query scan scratch, LS_NSETS generations: launch i's piggy-backed finalize of group i-1
     // reads one generation while its scan of group i fills the other
     struct scratch_set {
-        float* d_S = nullptr;        // n floats
+        float* d_S = nullptr;        // s_vecs score vectors, s_stride floats apart
         u64* d_cand = nullptr;       // max_blocks * LS_KP_MAX
         u64* d_bound = nullptr;      // max_blocks
         void* d_gran = nullptr;      // same-launch selection: LS_QUERIES_PER_LAUNCH_MAX * LS_GRAN_MAX tagged
@@ -177,8 +177,11 @@ struct ls_index {
     ls_fin_batch pending{};
     hipStream_t pending_stream = nullptr;
     long long s_stride = 0;            // floats between the score vectors of one generation
+    int32_t s_vecs = 0;                // score vectors per generation: 8 (one VALU scan group) until a launch that keeps
+                                       // its score vectors serves more (ls_mq, LS_FLAG_ASYNC-only calls): grow_score_vectors
     int32_t opt_multi_query = 1;       // several queries per corpus pass (groups of 8 / 4)
     int32_t opt_mq = 1;                // fp32 index: 2..16 queries per pass on the f32 matrix cores (ls_mq.hip)
+    int32_t opt_mq32 = 1;              // ... up to 32 queries per pass (two B blocks; debug option 22)
     uint64_t n_mq_launches = 0;
     int32_t opt_scan_skip_scores = 1;  // ... single-query launches of pipelined / synchronous device calls too
     int32_t opt_mq_skip_scores = 1;    // ... whose selection jobs ride along write no score vectors (debug option 19)
@@ -218,7 +221,7 @@ struct ls_index {
     int32_t opt_overlap_calls = 1;     // synchronous host calls may overlap two deep (debug option 17)
     uint64_t n_overlapped_calls = 0;   // host calls that were queued while another one was still in flight
     int32_t force_gen = -1;            // >= 0: the scan scratch generation the call being queued must use
-    std::vector<ls_fin_params>* cur_retry = nullptr;  // where the call being queued keeps its same-launch jobs
+    std::vector<ls_fin_batch>* cur_retry = nullptr;  // where the call being queued keeps its same-launch jobs
     u32 cur_done_seq = 0;              // ... and the sequence number its completion words / granules carry
     u32* done_base = nullptr;  // set by ls_search around its scan-path call, else null
     ls_out_gran* gran_out_base = nullptr;                      // set together with done_base

@@ -240,7 +240,10 @@ __global__ __launch_bounds__(LS_SCAN_THREADS, scan_min_waves(F16, V, NQ)) void l
         // mq_repair: the riding selection workgroup has the time, the scan workgroups do not)
         if (NQ == 1 && qkeep && blockIdx.x == 0)
             for (int e = threadIdx.x; e < d; e += LS_SCAN_THREADS) qkeep[e] = qraw[e];
-        finalize_body<LS_SCAN_THREADS>(fin.p[blockIdx.x], smem_dyn, threadIdx.x);
+        for (int j = blockIdx.x; j < fin.njobs; j += nfin) {  // (nfin workgroups share the fin.njobs jobs)
+            if (j != (int)blockIdx.x) __syncthreads();        // the previous job's LDS is free again
+            finalize_body<LS_SCAN_THREADS>(ls_fin_job(fin, j), smem_dyn, threadIdx.x);
+        }
         return;
     }
     const int bid = (int)blockIdx.x - nfin;
@@ -544,11 +547,12 @@ static int launch_lvq(const void* corpus, int64_t n, const ls_geom& g, const ls_
                       hipStream_t s) {
     constexpr int U = scan_unroll(V);
     size_t smem = 0;
-    for (int i = 0; i < a.nfin; ++i) {
-        const ls_fin_params& fp = a.fin.p[i];
+    if (a.nfin > 0) {
+        const ls_fin_params& fp = a.fin.p0;
         const int keff = (int)((long long)fp.k < fp.n ? fp.k : fp.n);
-        smem = std::max(smem, ls_fin_lds_bytes(fp.keys_cap, keff));
+        smem = ls_fin_lds_bytes(fp.keys_cap, keff);
     }
+    const int nfw = std::min(a.nfin, LS_FIN_WG_MAX);  // selection workgroups (jobs nfw.. are second rounds)
     // single-query launches in which no wave sees more than 64 rows rank once instead of inserting
     constexpr int TR = U * (LS_WAVE / L);
     const long long waves = (long long)a.blocks * LS_SCAN_WAVES;
@@ -562,11 +566,11 @@ static int launch_lvq(const void* corpus, int64_t n, const ls_geom& g, const ls_
         auto kern = ls_scan_kernel<F16, L, V, U, NQ, SM>;                                          \
         static ls_attr_once once;                                                                  \
         if (int rc = ls_set_max_dynamic_lds(once, (const void*)kern, LS_PIGGY_LDS_MAX)) return rc; \
-        hipLaunchKernelGGL(kern, dim3(a.blocks + a.nfin), dim3(LS_SCAN_THREADS), smem, s,          \
+        hipLaunchKernelGGL(kern, dim3(a.blocks + nfw), dim3(LS_SCAN_THREADS), smem, s,          \
                            (const f32x4*)corpus, (long long)n, g.chunks, a.d_q, g.d,               \
                            a.normalize ? 1 : 0, a.reverse ? 1 : 0, LS_SCAN_S(a.d_S), (long long)a.s_stride,   \
                            a.d_cand, (long long)a.c_stride, a.d_bound, (long long)a.b_stride,      \
-                           a.kprime, a.nfin, a.fin, a.d_gran, (long long)a.g_stride, a.tag, a.d_qkeep);                          \
+                           a.kprime, nfw, a.fin, a.d_gran, (long long)a.g_stride, a.tag, a.d_qkeep);                          \
     }
     if constexpr (NQ == 1) {
         if (small) LS_SCAN_LAUNCH(true) else LS_SCAN_LAUNCH(false)

@@ -7,20 +7,17 @@
 // ---- stand-alone finalize: one workgroup of 1024 threads per job, dynamic LDS ---------------------
 __global__ __launch_bounds__(LS_FINAL_THREADS) void ls_finalize_kernel(ls_fin_batch jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_fin[];
-    finalize_body<LS_FINAL_THREADS>(jobs.p[blockIdx.x], smem_fin, threadIdx.x);
+    finalize_body<LS_FINAL_THREADS>(ls_fin_job(jobs, blockIdx.x), smem_fin, threadIdx.x);
 }
 
-int ls_launch_finalize(const ls_fin_batch& jobs, int njobs, hipStream_t s) {
-    if (njobs <= 0) return LS_OK;
+int ls_launch_finalize(const ls_fin_batch& jobs, hipStream_t s) {
+    if (jobs.njobs <= 0) return LS_OK;
     static ls_attr_once once;
     if (int rc = ls_set_max_dynamic_lds(once, (const void*)ls_finalize_kernel, 128 * 1024)) return rc;
-    size_t smem = 0;
-    for (int i = 0; i < njobs; ++i) {
-        const ls_fin_params& p = jobs.p[i];
-        const int keff = (int)((long long)p.k < p.n ? p.k : p.n);
-        smem = std::max(smem, ls_fin_lds_bytes(p.keys_cap, keff));
-    }
-    hipLaunchKernelGGL(ls_finalize_kernel, dim3(njobs), dim3(LS_FINAL_THREADS), smem, s, jobs);
+    const ls_fin_params& p = jobs.p0;  // (k, n and the key capacity are the group's)
+    const int keff = (int)((long long)p.k < p.n ? p.k : p.n);
+    const size_t smem = ls_fin_lds_bytes(p.keys_cap, keff);
+    hipLaunchKernelGGL(ls_finalize_kernel, dim3(jobs.njobs), dim3(LS_FINAL_THREADS), smem, s, jobs);
     LS_HIP(hipGetLastError());
     return LS_OK;
 }

@@ -1,5 +1,5 @@
-"""Small batches on an fp32 index (csrc/ls_mq.hip): 2..16 queries share one corpus pass on the f32 matrix
-cores. The kernel is built to reproduce the single-query scan kernel's summation order, so the bar is not a
+"""Small batches on an fp32 index (csrc/ls_mq.hip): 2..32 queries share one corpus pass on the f32 matrix
+cores (17..32: two 16-column B blocks per A operand, round 6). The kernel is built to reproduce the single-query scan kernel's summation order, so the bar is not a
 tolerance: scores AND indices are `array_equal` to (a) the same queries served one by one and (b) the CPU
 oracle in the documented "scan" order (oracle.compare_kernel_order), in addition to the usual 1e-5 /
 near-tie check against the strict oracle. Reference call being replaced: `index.search(x, k)`,
@@ -27,17 +27,18 @@ def one_by_one(ix, q, k, normalize):
 def test_mq_equals_single_queries_and_the_scan_order_oracle(d, k, normalize):
     n = 40_000 if d <= 512 else 24_000
     c = H.gauss(100 + d, n, d)
-    q = H.gauss(200 + d, 20, d, normalize=not normalize) * (1.0 if not normalize else 3.0)
+    q = H.gauss(200 + d, 32, d, normalize=not normalize) * (1.0 if not normalize else 3.0)
     ix = FlatIPIndex.from_array(c)
-    D1, I1 = one_by_one(ix, q[:16], k, normalize)
+    D1, I1 = one_by_one(ix, q, k, normalize)
     qn = oracle.c_normalize_l2(q) if normalize else q
-    for nq in (2, 3, 5, 8, 13, 16, 17, 20):
+    for nq in (2, 3, 5, 8, 13, 16, 17, 20, 24, 31, 32):  # (33 and up: the batched f32 MFMA path, tests/test_batched_gpu.py)
         before = ix.debug_counter(23)
         D, I = ix.search(q[:nq], k, normalize=normalize)
         if k < 1000:  # (k = 1000 of 24 k rows may or may not fit the lanes' key lists: same bits either way)
             assert ix.debug_counter(23) > before, "the small batch did not take the f32 MFMA kernel"
-        m = min(nq, 16)
-        assert np.array_equal(D[:m], D1[:m]) and np.array_equal(I[:m], I1[:m]), (d, k, nq)
+            # 17..32 queries are ONE exact pass (two B blocks), not a speculative batch
+            assert ix.debug_counter(23) == before + 1 and ix.debug_counter(10) == 1, (nq, ix.debug_counter(10))
+        assert np.array_equal(D, D1[:nq]) and np.array_equal(I, I1[:nq]), (d, k, nq)
         rep = oracle.compare_kernel_order(D, I, c, qn[:nq], k, orders=("scan",))
         assert rep["kernel_order_mismatches"] == 0
         Dr, Ir = oracle.c_search(c, qn[:nq], k)
@@ -59,6 +60,17 @@ def test_mq_full_size_config2_shapes():
         rep = oracle.compare_kernel_order(D, I, c, q, k, orders=("scan",))
         D8, I8 = ix.search(q[:8], k)
         assert np.array_equal(D8, D[:8]) and np.array_equal(I8, I[:8])
+        # 32 queries, ONE pass (two 16-column blocks): the same bits for the queries both calls share
+        q32 = np.concatenate([q, H.gauss(91011, 16, d)])
+        before = ix.debug_counter(23)
+        D32, I32 = ix.search(q32, k)
+        assert ix.debug_counter(23) == before + 1, "32 queries must be one ls_mq launch"
+        assert np.array_equal(D32[:16], D) and np.array_equal(I32[:16], I)
+        oracle.compare_kernel_order(D32, I32, c, q32, k, orders=("scan",))
+        ix.debug_option(22, 0)   # 16 columns per pass: two launches, same bits
+        D32b, I32b = ix.search(q32[:23], k)
+        assert np.array_equal(D32b, D32[:23]) and np.array_equal(I32b, I32[:23])
+        ix.debug_option(22, 1)
         ix.debug_option(16, 0)   # the VALU scan groups of 8 / 4 / 1: same bits
         Dv, Iv = ix.search(q, k)
         assert np.array_equal(Dv, D) and np.array_equal(Iv, I)
@@ -118,11 +130,11 @@ def test_mq_device_api_pipelined_and_async():
     import torch
 
     c = H.gauss(41, 50_000, 384)
-    q = H.gauss(42, 40, 384)
+    q = H.gauss(42, 100, 384)
     ix = FlatIPIndex.from_array(c)
     tq = torch.from_numpy(q).cuda()
     outs = []
-    sizes = [2, 16, 5, 1, 9, 7]
+    sizes = [2, 16, 5, 1, 9, 7, 32, 17, 3, 8]
     at = 0
     for m in sizes:
         outs.append((at, m, ix.search_device(tq[at:at + m], 50, pipeline=True)))
@@ -133,6 +145,46 @@ def test_mq_device_api_pipelined_and_async():
     Dt, It = ix.search_device(tq[:12], 100, asynchronous=True)
     ix.check()
     oracle.compare_kernel_order(Dt.cpu().numpy(), It.cpu().numpy(), c, q[:12], 100, orders=("scan",))
+    # LS_FLAG_ASYNC alone keeps the score vectors: a 32-query pass needs 32 of them (grown on demand)
+    Dt, It = ix.search_device(tq[:32], 100, asynchronous=True)
+    torch.cuda.synchronize()
+    oracle.compare_kernel_order(Dt.cpu().numpy(), It.cpu().numpy(), c, q[:32], 100, orders=("scan",))
+    ix.close()
+
+
+@pytest.mark.parametrize("d,k", [(384, 100), (1024, 100), (768, 300)])
+def test_wide_pass_repairs_and_retries(d, k):
+    """17..32 queries per pass (two B blocks; 4 KB rows: one workgroup per CU, the selection workgroups run two
+    jobs each): a clustered corpus and k' = 1 force every query through the retry / repair paths - host call
+    (completion words, the stand-alone finalize or a second serve), pipelined device call (repair at ls_check),
+    LS_FLAG_ASYNC (score vectors kept: the rescue sweeps S). Same bits as one query at a time."""
+    import torch
+
+    c = H.gauss(3, 30_000, d)
+    q = H.gauss(4, 29, d)
+    c = np.ascontiguousarray(c[np.argsort(c @ q[0])])
+    ix = FlatIPIndex.from_array(c)
+    D1, I1 = one_by_one(ix, q, k, False)
+    oracle.compare_kernel_order(D1, I1, c, q, k, orders=("scan",))
+    D, I = ix.search(q, k)
+    assert np.array_equal(D, D1) and np.array_equal(I, I1)
+    ix.debug_option(0, 1)  # k' = 1: nothing can be proven from the workgroups' keys
+    before = ix.debug_counter(25)
+    D, I = ix.search(q, k)
+    assert ix.debug_counter(25) >= before + 20
+    assert np.array_equal(D, D1) and np.array_equal(I, I1)
+    tq = torch.from_numpy(q).cuda()
+    Dt, It = ix.search_device(tq, k, pipeline=True)
+    Dt2, It2 = ix.search_device(tq[:19], k, pipeline=True)
+    ix.check()
+    assert np.array_equal(Dt.cpu().numpy(), D1) and np.array_equal(It.cpu().numpy(), I1)
+    assert np.array_equal(Dt2.cpu().numpy(), D1[:19]) and np.array_equal(It2.cpu().numpy(), I1[:19])
+    Dt, It = ix.search_device(tq, k, asynchronous=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(Dt.cpu().numpy(), D1) and np.array_equal(It.cpu().numpy(), I1)
+    ix.debug_option(19, 0)  # host calls keep their score vectors: the stand-alone finalize rescues from S
+    D, I = ix.search(q, k)
+    assert np.array_equal(D, D1) and np.array_equal(I, I1)
     ix.close()
 
 

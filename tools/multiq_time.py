@@ -15,7 +15,7 @@ for (n, d, dt) in SHAPES:
     c = H.gauss(1234, n, d)
     ix = FlatIPIndex.from_array(c, dtype=dt)
     row = []
-    for nq in (1, 2, 4, 8, 16):
+    for nq in tuple(int(x) for x in os.environ.get('MQ_NQS', '1,2,4,8,16').split(',')):
         q = torch.from_numpy(H.gauss(5678, nq, d)).cuda()
         for _ in range(30): ix.search_device(q, 50, pipeline=PIPE)
         ix.check()

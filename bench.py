@@ -61,6 +61,7 @@ WORKLOADS = {
     "c2m": (1_000_000, 384, "f32", 1, 50),      # c2's shape past the 256 MiB Infinity Cache
     "c2x8": (200_000, 384, "f32", 8, 50),       # 8 queries share one corpus pass (csrc/ls_mq.hip: what combined
     "c2px8": (200_000, 1024, "f32", 8, 1000),   # concurrent callers produce); the reference's shape likewise
+    "c2x32": (200_000, 384, "f32", 32, 50),     # 32 queries in ONE exact pass (two MFMA B blocks per A operand, round 6)
     "c3": (200_000, 384, "f16", 1024, 100),
     "c4": (12_500_000, 768, "f16", 256, 100),  # rows PER GPU
 }
@@ -350,10 +351,20 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
     # (LS_FLAG_PIPELINE: launch i = scan of step i + one workgroup finalising step i-1, all on
     # one stream); the last finalize is flushed and everything validated by local.check() inside
     # the timed region.
-    pipelined = world == 1 and nq <= 16 and not inlib
+    # (fp32 index: up to 32 queries are one exact ls_mq pass; fp16 / sharded steps: up to 16)
+    scan_nq = 32 if (dtype == "f32" and world == 1 and not inlib) else 16
+    pipelined = world == 1 and nq <= scan_nq and not inlib
+    #  pipelined scan-path steps may be repaired at local.check() through the output pointers the
+    # library kept (up to 256 launches): every step between two checks gets its OWN output buffer, and consecutive
+    # steps search DIFFERENT query sets (the same queries rotated by one row per step), so that a repair written to
+    # the wrong buffer - or a stale row - shows up in the verification of the last timed steps below
+    RING = 256 if pipelined else 64
+    NROT = 4 if (pipelined and nq > 1) else 1
     out_ring = [(torch.empty((nq, k), dtype=torch.float32, device=dev),
-                 torch.empty((nq, k), dtype=torch.int64, device=dev)) for _ in range(64)]
+                 torch.empty((nq, k), dtype=torch.int64, device=dev)) for _ in range(RING)]
+    tqs = [tq.roll(r, dims=0).contiguous() for r in range(NROT)]
     step_i = [0]
+    tail_outs = []
 
     # N > 1, small batches: the sharded pipeline (local search of step i carries the finalize of
     # step i-1; the all-gather of step i-1 runs asynchronously; step i-2 is merged)
@@ -370,8 +381,11 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
     batched_async = world == 1 and not pipelined and not env.rehearse and not inlib
 
     def step(profile=False):
-        o = out_ring[step_i[0] & 63]
+        o = out_ring[step_i[0] % RING]
+        tq = tqs[step_i[0] % NROT]
         step_i[0] += 1
+        if pipelined and step_i[0] % RING == 0:
+            local.check()  # (the ring of output buffers wraps: make the steps that used it final first)
         if inlib:
             # one process, every GPU: the sharded handle queues the local searches on its per-device
             # streams, one RCCL all-gather and the merge; batches ride the shards' two lanes
@@ -427,9 +441,10 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
             return None
         from oracle import oracle
 
+        step_i[0] = 0  # (query rotation 0: the oracle's row order)
         s, i = step()
         drain()
-        nv = min(nq, 16)
+        nv = min(nq, scan_nq)
         Dr, Ir = oracle.c_search(corpus, queries[:nv], k, f16=(dtype == "f16"))
         _, _, S = oracle.np_search(corpus, queries[:nv], k, f16=(dtype == "f16"))
         got_s, got_i = s[:nv].cpu().numpy(), i[:nv].cpu().numpy()
@@ -437,12 +452,18 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         parity.update({"checked_queries": nv, "max_score_err_vs_strict": rep["max_score_err"],
                        "index_mismatches_vs_strict": rep["index_mismatches"],
                        "near_ties_excused": rep["near_ties_excused"]})
-        if dtype == "f32" and nq <= 16 and world == 1 and not inlib:
+        if dtype == "f32" and nq <= scan_nq and world == 1 and not inlib:
             # zero excuse: bit-identical (scores and indices) to the oracle run in the scan kernels' own
             # documented fp32 summation order (oracle/flat_ip_ref.c ORDER_SCAN); raises on any difference
             ko = oracle.compare_kernel_order(got_s, got_i, corpus, queries[:nv], k, orders=("scan",))
             parity.update({"kernel_order": "scan", "kernel_order_mismatches": ko["kernel_order_mismatches"],
                            "bit_identical_queries": ko["kernel_order_queries"]["scan"]})
+        # the last timed steps' own buffers: the verified rows, rotated like their queries were
+        for rot, ts, ti in tail_outs:
+            if not (np.array_equal(ts, np.roll(got_s, rot, axis=0)) and np.array_equal(ti, np.roll(got_i, rot, axis=0))):
+                raise SystemExit(f"{workload}: a timed step's output buffer (query rotation {rot}) differs from the verified result")
+        if tail_outs:
+            parity["timed_steps_rechecked"] = len(tail_outs)
         return rep["recall"]
 
     # untimed pre-warm: a 20-step driver run is ~1 ms of GPU time, shorter than the clock ramp.
@@ -478,6 +499,10 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
     env.barrier()
     dt = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    if pipelined and verify:  # the outputs of the last timed steps, before the profiling pass reuses their buffers
+        for j in range(min(NROT, steps)):
+            i = step_i[0] - 1 - j
+            tail_outs.append((i % NROT, out_ring[i % RING][0].cpu().numpy(), out_ring[i % RING][1].cpu().numpy()))
     if world > 1:
         t = torch.tensor([dt, dev_ms], dtype=torch.float64, device=dev)
         if env.share_gpu:
@@ -488,7 +513,7 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
     # ---- dominant-kernel duration: hipEvents around EVERY launch of it, on the stream it runs
     # on, over a second pass of the same steps (events would perturb the timed pass)
     local.set_profiling(True)
-    n_prof = min(steps, 4096 // max(1, min(nq, 16)))
+    n_prof = min(steps, 4096 // max(1, min(nq, scan_nq)))
     for _ in range(n_prof):
         step(profile=True)
     drain()
@@ -539,7 +564,7 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
         ach = ab / (scan_ms_avg * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-    mq_path = dtype == "f32" and 2 <= nq <= 16
+    mq_path = dtype == "f32" and 2 <= nq <= scan_nq
     roof["kernel"] = "ls_gemm_filter_kernel" if mfma_path else ("ls_mq_kernel" if mq_path else "ls_scan_kernel")
     roof["kernel_ms"] = round(scan_ms_avg, 5)
     roof["kernel_ms_source"] = roof_src
@@ -552,7 +577,7 @@ def run_dense(env: Env, workload: str, steps: int, warmup: int, *, want_cpu: boo
             roof["traffic_source"] = f"profiles/{pmc.name}"
         except Exception:
             pass
-    roof["algorithmic_bytes"] = algorithmic_bytes(n_local, d, elem, 1 if nq <= 16 else nq, k)
+    roof["algorithmic_bytes"] = algorithmic_bytes(n_local, d, elem, 1 if nq <= scan_nq else nq, k)
 
     res = {
         "value": round(nq * steps / dt, 1),
@@ -977,7 +1002,7 @@ def main():
             # the reference's real call shape and the per-GPU shard of config 4
             # ... and (1 GPU) config 2's shape at N = 1 M rows: 1.5 GB, six times the Infinity Cache
             # ... and the small-batch shapes (8 queries per corpus pass on the f32 matrix cores)
-            sec = ["c3", "c2p", "c2m", "c2x8", "c2px8", "c4"] if env.n_gpus == 1 else ["c3", "c4"]
+            sec = ["c3", "c2p", "c2m", "c2x8", "c2px8", "c2x32", "c4"] if env.n_gpus == 1 else ["c3", "c4"]
     elif args.secondary in ("none", ""):
         sec = []
     else:
@@ -986,8 +1011,8 @@ def main():
     for w in sec:
         nq = WORKLOADS[w][3]
         # (c3: 1000 pipelined batches = 0.15 s: the chain's fill and drain and its per-128-calls check are amortised)
-        st, wu = (1000, 50) if nq <= 16 else ((1000, 50) if w == "c3" else (30, 3))
-        secondary[w] = run_dense(env, w, st, wu, want_cpu=not args.no_cpu_baseline and w not in ("c2m", "c2x8", "c2px8"),
+        st, wu = (1000, 50) if (nq <= 16 or w == "c2x32") else ((1000, 50) if w == "c3" else (30, 3))
+        secondary[w] = run_dense(env, w, st, wu, want_cpu=not args.no_cpu_baseline and w not in ("c2m", "c2x8", "c2px8", "c2x32"),
                                  verify=not args.no_verify, c4_rows=args.c4_rows, cpu_budget_s=9.0)
     if (args.secondary == "auto" and args.workload == "c2" and env.n_gpus == 1) or \
             "c5" in args.secondary.split(","):

@@ -23,18 +23,13 @@
  *     number of valid rows hold index -1 and score -FLT_MAX (IndexFlat's heap-neutral padding,
  *     which the reference relies on at search/engine.py:254). Rows whose score is NaN or
  *     <= -FLT_MAX are never returned.
- *   - ls_search / ls_search_device may be called concurrently on one handle, from several threads
- *     and on several streams: calls are serialised inside, and device work that shares the
- *     handle's scratch is fenced across streams by events. Concurrent ls_search calls do not
- *     queue one behind the other: whichever thread is serving takes every waiting request of the
- *     same k and flags (up to 16 queries) into ONE corpus pass (fp32 index: on the f32 matrix cores,
- *     bit-identical to the separate calls); waiters sleep, they do not spin. A synchronous call's
- *     launch may be queued while the previous call still waits for its answer (two host slots).
- *   - stream lifetime: a hipStream_t handed to ls_search_device must stay alive until the next
- *     ls_check (or synchronous call) on that handle has returned, or until ls_destroy: the handle
- *     remembers the stream of its most recent calls and may synchronise it when a later call
- *     arrives on a different stream (recording an event behind every call instead would cost
- *     several microseconds of GPU time per call; the library's own lanes ARE ordered by events).
+ *   - ls_search / ls_search_device may be called concurrently on one handle, from several threads and on
+ *     several streams (serialised inside; scratch shared across streams is fenced by events). Concurrent
+ *     ls_search calls are not queued one behind the other: whichever thread is serving takes every waiting
+ *     request of the same k and flags (up to 32 queries on an fp32 index, 16 otherwise) into ONE corpus pass,
+ *     bit-identical to the separate calls ("Concurrency").
+ *   - stream lifetime: a hipStream_t handed to ls_search_device must stay alive until the next ls_check (or
+ *     synchronous call) on that handle has returned, or until ls_destroy.
  *   - there is no CPU fallback: with no usable HIP device every compute entry point fails with
  *     LS_ERR_NO_DEVICE.
  */
@@ -62,15 +57,10 @@ extern "C" {
                              /* faiss.normalize_L2, search/engine.py:242, into the search)     */
 #define LS_FLAG_ASYNC 2u     /* ls_search_device only: queue and return; results are ordered  */
                              /* on `stream` like any other work queued there                  */
-#define LS_FLAG_PIPELINE 4u  /* ls_search_device only: queue on the index's internal streams  */
-                             /* so that consecutive calls overlap (scan path: the selection   */
-                             /* step of one query runs under the scan of the next; batched    */
-                             /* MFMA path: consecutive batches alternate between two internal */
-                             /* lanes with four scratch sets, behind whatever `stream` has    */
-                             /* queued so far; the MFMA pass of a batch may be queued only    */
-                             /* when the call after next arrives, because it also computes    */
-                             /* that call's sample scores, or at ls_check()); results are NOT */
-                             /* ordered on `stream` - they are valid after ls_check()         */
+#define LS_FLAG_PIPELINE 4u  /* ls_search_device only: queue on the index's internal streams so that       */
+                             /* consecutive calls overlap (scan path: the selection of one query runs    */
+                             /* under the scan of the next; batched MFMA path: two internal lanes);      */
+                             /* results are NOT ordered on `stream` - they are valid after ls_check()    */
 
 #define LS_FLAG_INORDER 8u   /* ls_search_device with LS_FLAG_PIPELINE: the caller consumes scan-path    */
                              /* results on the GPU before ls_check (in the lanes' order, e.g. a sharded */
@@ -87,33 +77,22 @@ typedef struct ls_index ls_index; /* opaque */
 int ls_create(ls_index** out, const float* corpus, int64_t n, int32_t d, int32_t dtype,
               int32_t device);
 
-/* Row-sharded index over several GPUs of one node, in ONE process and behind the SAME handle type:
- * every function of this header accepts the handle it returns (the
- * reference's backend is a single process that owns one index, reference src/lean_explore/mcp/
- * server.py:147-151, and calls index.search from it, search/engine.py:250).
- * Shard g holds the contiguous row block [g*ceil(n/G), min(n, (g+1)*ceil(n/G))) on device_ids[g].
- * A search copies the queries to every device, runs the local exact top-k on all of them
- * concurrently, exchanges the packed per-shard results [scores | rows | flags] with ONE RCCL
- * all-gather over xGMI (ncclCommInitAll communicators, bound at first use) and merges the G sorted
- * lists on device_ids[0] under the total order: results are bit-identical to the unsharded index
- * for every G. Queries / outputs of ls_search_device live on device_ids[0] (= ls_device()).
- * Duplicate ids (e.g. {0,0,0}: G shards rehearsed on one GPU) are allowed; they exchange by
- * device-to-device copies because RCCL needs distinct devices. n_devices == 0 fails with
- * LS_ERR_NO_DEVICE (there is no CPU backend). LS_FLAG_PIPELINE reaches the shards' batched path
- * only; on the per-query scan path a sharded handle treats it as LS_FLAG_ASYNC. ls_add appends to
- * the last shard. ls_export_flags and ls_debug_read_scores are not available on a sharded handle. */
+/* Row-sharded index over several GPUs of one node, in ONE process and behind the SAME handle type: every
+ * function of this header accepts the handle it returns (the reference's backend is
+ * one process that owns one index, reference src/lean_explore/mcp/server.py:147-151 -> search/engine.py:250).
+ * Shard g holds the contiguous row block [g*ceil(n/G), min(n, (g+1)*ceil(n/G))) on device_ids[g]; a search runs
+ * the local exact top-k on every shard, exchanges the packed results [scores | rows | flags] with ONE RCCL
+ * all-gather over xGMI and merges the G sorted lists on device_ids[0]: bit-identical to the unsharded index
+ * for every G. Queries / outputs of ls_search_device live on device_ids[0]. Duplicate ids
+ * (G shards rehearsed on one GPU) exchange by device-to-device copies. n_devices == 0 fails with
+ * LS_ERR_NO_DEVICE. ls_add appends to the last shard; ls_export_flags is not available on a sharded handle. */
 int ls_create_sharded(ls_index** out, const float* corpus, int64_t n, int32_t d, int32_t dtype,
                       const int32_t* device_ids, int32_t n_devices);
 
-/* REPLICAS instead of row shards: every device of device_ids holds the whole corpus, and the synchronous
- * host calls (ls_search - the reference's call, search/engine.py:250) are dealt round-robin to the
- * replicas, each with its own queue of concurrent callers: G callers run on G devices at once. For a
- * corpus that fits one GPU (the reference's ~200 k x 1024 fp32 = 0.8 GB) this is the shape that
- * scales queries/s with the device count; row shards only pay for corpora that do not fit (each query
- * touches every shard, plus the exchange). The handle is an ordinary ls_index*: ls_add appends to every
- * replica, ls_reconstruct reads replica 0, ls_search_device (queries resident on device_ids[0]) is
- * served by the replica there, ls_shard_count / ls_shard_info list the replicas (each covering all
- * rows). Results are those of a single-device index. debug counter 21: host calls dispatched. */
+/* REPLICAS instead of row shards: every device holds the whole corpus and the synchronous host calls (ls_search)
+ * are dealt round-robin to the replicas, each with its own queue of concurrent callers - the shape that scales
+ * queries/s with the device count for a corpus that fits one GPU (the reference's 200 k x 1024 fp32 = 0.8 GB).
+ * ls_add appends to every replica; results are those of a single-device index. */
 int ls_create_replicated(ls_index** out, const float* corpus, int64_t n, int32_t d, int32_t dtype,
                          const int32_t* device_ids, int32_t n_devices);
 
@@ -128,13 +107,9 @@ int32_t ls_shard_count(const ls_index* index);
 int ls_shard_info(const ls_index* index, int32_t shard, int32_t* device, int64_t* row0,
                   int64_t* rows);
 
-/* What the exchange step of a sharded handle does on THIS node, as one JSON object in `buf`
- * (NUL-terminated, truncated to `cap`): "exchange" ("rccl all-gather" | "peer-copy (RCCL failed)" |
- * "device-to-device copies (shards share a device)" ...), "rccl_version", "rccl_error" (why RCCL
- * could not be used: the handle then falls back to peer copies instead of failing every search),
- * "rccl_communicators", "enqueue_workers" (one host thread per shard queues that shard's work),
- * "devices" and the hipDeviceCanAccessPeer matrix "peer_access". Returns the length of the full
- * text, or a negative LS_ERR_* code. */
+/* What the exchange step of a sharded handle does on THIS node, as one JSON object in `buf` (NUL-terminated,
+ * truncated to `cap`): "exchange" (rccl all-gather | peer copies | ...), "rccl_version", "rccl_error",
+ * "enqueue_workers", "devices", "peer_access". Returns the length of the full text, or a negative LS_ERR_* code. */
 int32_t ls_shard_exchange_info(ls_index* index, char* buf, int32_t cap);
 
 /* As ls_create, but `d_corpus` is device memory on `device`, row-major float32 [n, d]
@@ -167,46 +142,37 @@ int ls_set_base(ls_index* index, int64_t base);
 int ls_search(ls_index* index, const float* q, int64_t nq, int32_t k, uint32_t flags,
               float* out_scores, int64_t* out_indices);
 
-/* Same search with queries and outputs already in HBM on the index's device; work is queued
- * on `stream` (a hipStream_t; NULL = default stream). Without LS_FLAG_ASYNC it synchronises
- * the stream before returning. With LS_FLAG_ASYNC it returns after queueing (results ordered on
- * `stream`); with LS_FLAG_PIPELINE it returns after queueing on internal lanes (see the flag).
- * Lifetimes of an async / pipelined call: the QUERY buffer may be reused as soon as the work
- * queued on `stream` so far has consumed it (stream order; the library keeps its own copy for
- * repairs); the OUTPUT buffers must stay valid until the ls_check that covers the call, because a
- * repaired query is re-written in place. Call ls_check before trusting the results of ANY batched
- * call (the speculative MFMA paths: nq > 16 on an fp16 index, nq >= 24 on an fp32 index, on shards
- * of at least 8192 rows) or of any pipelined search; per-query scan-path calls (everything else)
- * are exact in stream order. (Single queries and small fp32 batches - ls_scan.hip, ls_mq.hip - write no score
- * vectors when the call is pipelined or synchronous: a query whose selection could not prove its keys
- * complete is served again, in place, at ls_check / before the synchronous call returns. With LS_FLAG_ASYNC
- * alone, or with LS_FLAG_INORDER, they keep the score vectors and are exact in stream / lane order.)
- * ls_debug_counter(index, 10) names the path the last call took. */
+/* Same search with queries and outputs already in HBM on the index's device; work is queued on `stream` (a
+ * hipStream_t; NULL = default stream). Without flags it synchronises the stream before returning; LS_FLAG_ASYNC
+ * returns after queueing (results ordered on `stream`), LS_FLAG_PIPELINE after queueing on internal lanes.
+ * Lifetimes of an async / pipelined call: the QUERY buffer may be reused as soon as the work queued on `stream`
+ * so far has consumed it (the library keeps its own copy for repairs); the OUTPUT buffers must stay valid until
+ * the ls_check that covers the call, because a repaired query is re-written in place - and should not be handed
+ * to another call before that check (the library skips the repair of rows a LATER pipelined call of the same
+ * handle was given in the meantime, but it cannot see any other writer).
+ * Call ls_check before trusting the results of ANY batched call (the speculative, verified MFMA paths: nq > 16 on
+ * an fp16 index, nq > 32 on an fp32 index, shards of at least 8192 rows) or of any pipelined search: pipelined /
+ * synchronous scan-path launches write no score vectors, and a query whose selection could not prove its keys
+ * complete (~1e-3 per query) is served again, in place, at ls_check / before the synchronous call returns. With
+ * LS_FLAG_ASYNC alone, or with LS_FLAG_INORDER, scan-path calls are exact in stream / lane order. */
 int ls_search_device(ls_index* index, const void* d_q, int64_t nq, int32_t k, uint32_t flags,
                      void* d_out_scores, void* d_out_indices, void* stream);
 
-/* Synchronise `stream` and the index's internal lanes and make the results of every async /
- * pipelined search queued since the last ls_check final: queries of batched calls whose
- * speculative threshold let fewer than k rows through, or whose candidate queues overflowed, are
- * re-run here by the exact per-query scan path (from the library's own copy of the queries) and
- * their output rows re-written; so are the queries of pipelined scan-path launches (single queries and small
- * fp32 batches, up to 256 launches between two checks) that raised their repair word. Returns LS_OK once everything is exact. Up to 1024 batched calls
- * (fewer for batches of more than 4096 queries) may be outstanding; one more triggers the same repair step on its own. */
+/* Synchronise `stream` and the index's internal lanes and make the results of every async / pipelined search
+ * queued since the last ls_check final: flagged queries (batched calls whose verified threshold failed or whose
+ * candidate queues overflowed; pipelined scan-path launches that raised their repair word) are re-run by the exact
+ * per-query scan path from the library's own copy of the queries and their output rows re-written. Up to 1024
+ * batched calls / 256 pipelined scan-path launches may be outstanding; one more triggers the same step by itself. */
 int ls_check(ls_index* index, void* stream);
 
-/* Copy the per-query verification flags of the most recent search queued on this handle into
- * d_dst (device memory on the index's device, uint32 [nq]) in `stream` order: non-zero = that
- * query's output rows are provisional until ls_check. Scan-path searches export zeros: a caller that
- * ships scan-path results before ls_check passes LS_FLAG_INORDER (or LS_FLAG_ASYNC alone), which makes them
- * exact in order. Lets a sharded caller ship the flags with the results instead of synchronising before
- * the exchange. */
+/* Copy the per-query verification flags of the most recent search queued on this handle into d_dst (device
+ * memory, uint32 [nq]) in `stream` order: non-zero = that query's rows are provisional until ls_check (scan-path
+ * searches export zeros). Lets a sharded caller ship the flags with the results instead of synchronising. */
 int ls_export_flags(ls_index* index, void* d_dst, int64_t nq, void* stream);
 
-/* faiss.normalize_L2(x): in-place row normalisation of host float32 [nq, d];
- * rows with zero norm are left unchanged. Runs on `device` (cached pinned staging buffers that the
- * kernel reads and writes directly; no allocation per call). The squared norm is summed in the
- * library's one documented order (ls_common.h, ls_wave_sumsq), the same the fused
- * LS_FLAG_NORMALIZE uses, so both routes give bit-identical queries. */
+/* faiss.normalize_L2(x): in-place row normalisation of host float32 [nq, d]; rows with zero norm are left
+ * unchanged. Runs on `device`. The squared norm is summed in the library's one documented order (ls_common.h,
+ * ls_wave_sumsq), the same the fused LS_FLAG_NORMALIZE uses: both routes give bit-identical queries. */
 int ls_normalize_l2(float* x, int64_t nq, int32_t d, int32_t device);
 
 /* Merge `n_lists` per-shard results (each [nq, k], sorted by the total order, -1 padded)
@@ -218,87 +184,19 @@ int ls_merge_topk(const void* d_scores_in, const void* d_indices_in, int32_t n_l
                   int32_t device, void* stream);
 
 /* As ls_merge_topk for the packed exchange buffer of the sharded path: list l's scores start at
- * (char*)d_scores_in + l*list_stride_bytes and its rows at (char*)d_indices_in +
- * l*list_stride_bytes (one all-gather of a per-rank block [scores | rows] yields this layout).
- * list_stride_bytes must be a multiple of 8. */
+ * (char*)d_scores_in + l*list_stride_bytes, its rows at (char*)d_indices_in + l*list_stride_bytes (a multiple of 8). */
 int ls_merge_topk_strided(const void* d_scores_in, const void* d_indices_in,
                           int64_t list_stride_bytes, int32_t n_lists, int64_t nq, int32_t k,
                           void* d_out_scores, void* d_out_indices, int32_t device, void* stream);
 
-/* Kernel timing for bench.py. While profiling is on, every scan launch (up to 4096) is
- * bracketed by hipEvents on the stream it runs on. ls_last_kernel_ms returns the MEAN duration
- * of the scan kernel and of scan + selection over the launches recorded since profiling was
- * switched on (or since the last read), and clears the record. */
-int ls_set_profiling(ls_index* index, int32_t enabled);
-int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
+/* Kernel timing, tuning hooks and counters (ls_set_profiling, ls_last_kernel_ms, ls_debug_option,
+ * ls_debug_counter, ls_debug_read_scores, ls_bm25_debug_counter): include/leansearch_debug.h. A binder of the
+ * search path needs none of them. */
 
-/* Test / tuning hooks.
- * option 0: force the number of keys k' each scan workgroup emits (0 = automatic);
- * option 1: force the finalize step's general exact path; option 2: alternate the sweep
- * direction of consecutive scans (default off); option 3: piggy-back the finalize of a query
- * group on the next scan launch (default on); option 4: allow the batched MFMA path (default on);
- * option 5: speculative, verified sample threshold on the batched path (default on; off = the
- * certified k-th sample score); option 6: several queries per corpus pass on the scan path
- * (default on); option 7: force the number of scan workgroups per launch (0 = automatic);
- * option 9: synchronous host searches (ls_search, nq <= 16) run the selection step inside the scan
- * launch of its own query, sweeping the tagged 16-byte granules the scan workgroups write their keys as
- * (no drain, no counter, no fence; a query whose keys cannot be proven complete answers "retry" in its
- * completion word and the host launches the stand-alone selection): 0 off, 1 on (default);
- * option 15: synchronous host searches let the scan workgroups read the pinned host copy of the query
- * over PCIe (0, default: the read hides under the first corpus tile) or bring it to device memory with a
- * copy command in front of the launch (1: measured 1.6-2 us slower per call);
- * option 10: synchronous host searches (ls_search) that arrive while another one is running are
- * served together, up to 16 queries of equal k and flags per corpus pass (default on);
- * option 13: pipelined fp16 batches of stored rows of up to 768 bytes let the sample phase of the batch
- * two calls ahead ride on the MFMA pass launch: 0 off, 1 on (default); option 14: select
- * step of the batched path as one wave per query in <= 48 registers where the shape allows (k <= 128,
- * <= 128 corpus slices; runs inside a resident MFMA pass): default on;
- * option 16: fp32 index, 2..16 queries per corpus pass on the f32 matrix cores (ls_mq.hip): default on
- * (0: the VALU scan groups of 8 / 4 / 1 - same bits); option 17: synchronous host calls may overlap two
- * deep (default on); option 18: fp16 index with 768-byte stored rows, batched pass in the row-split,
- * 64-queries-per-wave shape (measured slower, profiles/ab/r05_tile_shape.txt: default off);
- * option 20: concurrent ls_search callers are gathered into ONE pass - a leader with nothing in flight waits up
- * to a third of a call, at most 60 us, for the callers seen lately - instead of two passes at once on the two
- * host slots (2 default; 1: only calls longer than 110 us, e.g. d = 1024; 0 off: option 17's two-deep overlap
- * decides); option 21: callers up to which a second batch may go early when option 20 allows it (default 8);
- * option 19: launches of synchronous host calls (ls_scan and ls_mq) and ls_mq launches of pipelined /
- * synchronous device calls write no score vectors; an unproven query is served again on the scan kernel - same bits (default on; 0: every
- * launch writes them and the selection repairs from them);
- * option 8 (sharded handles): exchange step 0 = RCCL all-gather between distinct devices (default),
- * 1 = peer copies into the primary device's gather buffer, 2 = RCCL gather-to-root (ncclSend / ncclRecv:
- * only the primary, which merges, receives the blocks); option 11 (sharded handles): one host
- * thread per shard queues that shard's work: -1 automatic (on when the device ids are distinct,
- * default), 0 off, 1 on; option 12 (sharded handles, test hook): make the next RCCL exchange fail
- * (the handle must fall back to peer copies and keep answering).
- * counter 9: kernel launches the most recent batched call queued (counted per launch);
- * counter 10: path of the most recent search (1 per-query scan, 2 fp16 MFMA, 3 fp32 MFMA);
- * counter 11: kernel launches queued by searches on this handle so far; counter 12: batched calls
- * that were cut into sub-batches because the candidate queues could not hold the whole batch;
- * sharded handles: counter 13 exchange steps run, 14 re-exchanges after a shard repaired a
- * query, 15 exchange transport (0 copies, 1 RCCL selected, 2 RCCL communicators initialised, 3 RCCL failed
- * on this node: fell back to peer copies), 19 calls whose shards were queued by the enqueue workers;
- * counter 20: synchronous host calls that had to launch the stand-alone selection (option 9's retry);
- * counter 22: checks of pending batched calls the library ran on its own (slots exhausted or re-sliced; summed);
- * counter 23: ls_mq launches (small fp32 batches on the f32 matrix cores); counter 24: synchronous host calls
- * that were queued while another one was still in flight; counter 25: queries of ls_mq launches without
- * score vectors that were served again on the scan kernel;
- * counters 0, 1, 8, 11, 12 are summed over the shards, 9 and 10 are the primary shard's;
- * counter 16: combined batches ls_search served, 17: the requests they carried; counter 18 (sharded
- * handles): mean host nanoseconds spent queueing one search (every device's work + exchange + merge).
- * counter 0: searches whose finalize step left the fast path (rescue or general); counter 1:
- * those that took the general path; counter 8: queries of batched calls that were repaired by
- * the exact scan path. */
-int ls_debug_option(ls_index* index, int32_t which, int32_t value);
-int64_t ls_debug_counter(ls_index* index, int32_t which);
-/* Copy the score vector S[0..count) of the most recent per-query scan to host memory. */
-int ls_debug_read_scores(ls_index* index, float* out, int64_t count);
-
-/* ---- lexical (BM25+) name retrieval: SURVEY §8(f) row 3 -----------------------------------------
- * Stands in for `bm25s.BM25.retrieve([tokens], k)` (reference src/lean_explore/search/engine.py:
- * 209-214). The index is bm25s's eager-sparse CSC matrix (one column per vocabulary token:
- * document rows + float32 scores) plus its per-token non-occurrence array (bm25+), i.e. the
- * arrays bm25s saves as data/indices/indptr.csc.index.npy and nonoccurrence_array.index.npy
- * (reference src/lean_explore/cli/data_commands.py:42-59). All pointers are host memory. */
+/* ---- lexical (BM25+) name retrieval: SURVEY section 8(f) row 3. Stands in for `bm25s.BM25.retrieve([tokens], k)`
+ * (reference src/lean_explore/search/engine.py:209-214). The index is bm25s's eager-sparse CSC matrix (one column
+ * per vocabulary token: document rows + float32 scores) plus its per-token non-occurrence array (bm25+), as saved
+ * by reference src/lean_explore/cli/data_commands.py:42-59. All pointers are host memory. */
 typedef struct ls_bm25 ls_bm25;
 int ls_bm25_create(ls_bm25** out, const int64_t* indptr, const int32_t* indices, const float* data,
                    const float* nonoccurrence, int64_t n_docs, int64_t n_vocab, int32_t device);
@@ -309,9 +207,6 @@ int ls_bm25_create(ls_bm25** out, const int64_t* indptr, const int32_t* indices,
 int ls_bm25_search(ls_bm25* index, const int32_t* token_ids, int32_t n_tokens, int32_t k,
                    float* out_scores, int64_t* out_docs);
 int64_t ls_bm25_ntotal(const ls_bm25* index);
-/* Test hook. counter 0: searches whose selection step left its fast path; counter 1: those that
- * needed the general select over the score vector. */
-int64_t ls_bm25_debug_counter(ls_bm25* index, int32_t which);
 void ls_bm25_destroy(ls_bm25* index);
 
 const char* ls_last_error(void); /* thread-local; valid until the next call on this thread */

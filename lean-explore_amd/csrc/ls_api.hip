@@ -5,7 +5,6 @@
 // point returns LS_ERR_NO_DEVICE.
 #include "ls_index.h"
 
-#include <immintrin.h>
 
 #include <algorithm>
 #include <chrono>
@@ -711,12 +710,24 @@ static int mq_repair(ls_index* ix) {
     ix->cur_retry = nullptr;
     ix->force_gen = -1;
     int rc = LS_OK;
-    for (const auto& pc : pend) {
+    for (size_t pi = 0; pi < pend.size() && rc == LS_OK; ++pi) {
+        const auto& pc = pend[pi];
         const u32* fl = ix->h_mq_flags + (size_t)pc.slot * LS_QUERIES_PER_LAUNCH_MAX;
         const float* qk = ix->d_mq_keep + (size_t)pc.slot * LS_QUERIES_PER_LAUNCH_MAX * ix->mq_keep_d;
         for (int q = 0; q < pc.nq && rc == LS_OK; ++q) {
             if (!fl[q]) continue;
             any = true;
+            //  the caller may have handed these output rows to a LATER pipelined call before this
+            // check (a ring of output buffers shorter than the calls between two checks): the later call's results
+            // own them now - a repair written there would replace a newer answer with an older one
+            const float* r0 = pc.d_out_s + (size_t)q * pc.k;
+            bool reused = false;
+            for (size_t pj = pi + 1; pj < pend.size() && !reused; ++pj)
+                reused = r0 < pend[pj].d_out_s + (size_t)pend[pj].nq * pend[pj].k && pend[pj].d_out_s < r0 + pc.k;
+            if (reused) {
+                ix->n_mq_skipped_repairs++;
+                continue;
+            }
             ix->n_mq_reserved++;
             rc = scan_search_on_stream(ix, qk + (size_t)q * ix->mq_keep_d, 1, pc.k, pc.flags & LS_FLAG_NORMALIZE,
                                        pc.d_out_s + (size_t)q * pc.k, pc.d_out_i + (size_t)q * pc.k, last);
@@ -729,7 +740,14 @@ static int mq_repair(ls_index* ix) {
     ix->gran_out_base = sv_gran;
     ix->cur_retry = sv_retry;
     ix->force_gen = sv_gen;
-    if (rc != LS_OK) return rc;
+    if (rc != LS_OK) {
+        //  a failed repair must not look like a finished one: the pending launches and the raised flag
+        // word come back (the device flags were not cleared), so the next ls_check tries again or fails again
+        pend.insert(pend.end(), ix->mq_pend.begin(), ix->mq_pend.end());
+        ix->mq_pend.swap(pend);
+        __atomic_store_n(any_word, 1u, __ATOMIC_RELEASE);
+        return rc;
+    }
     if (any) {
         LS_HIP(hipMemsetAsync(ix->d_mq_flags, 0, sizeof(u32) * used, last));
         LS_HIP(hipStreamSynchronize(last));
@@ -1356,9 +1374,9 @@ static int host_call_begin_impl(ls_host_call& c) {
     // prices that read at 7.4 us for 448 idle workgroups against 2.7 us behind a copy command and
     // 1.5 us through the kernel arguments - but in the scan kernel the first corpus tile's loads are
     // in flight before the query is touched, so the read hides, and the copy command measured 1.6-2 us
-    // SLOWER per call (profiles/ab/r04_hostapi_selection.txt). Debug option 15 = 1 selects the copy.
+    // SLOWER per call (profiles/ab/r04_hostapi_selection.txt; the copy path was removed in round 6).
     // (only single queries: every workgroup reads the whole query block - 256 x 16 x 4 KB over PCIe otherwise)
-    const bool in_direct = c.in_direct = small_call && nq == 1 && !ix->opt_query_copy;
+    const bool in_direct = c.in_direct = small_call && nq == 1;
     if (c.spin && !S.h_done) {
         LS_HIP(hipHostMalloc((void**)&S.h_done, sizeof(u32) * LS_QUERIES_PER_LAUNCH_MAX, hipHostMallocDefault));
         memset(S.h_done, 0, sizeof(u32) * LS_QUERIES_PER_LAUNCH_MAX);
@@ -1469,7 +1487,7 @@ static int host_call_finish(ls_host_call& c) {
                 if (retry) *retry = any_retry;
                 return true;
             }
-            _mm_pause();
+            ls_cpu_relax();
             if ((it & 1023) == 1023 &&
                 std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
                 return false;
@@ -1585,7 +1603,11 @@ struct ls_req {
     char err[256] = "";
 };
 
-#define LS_WAITER_SPIN_US 300  // a queued caller polls this long before it sleeps on the condition variable
+// A queued caller polls the queue's epoch before it sleeps on the condition variable: for about two calls' worth
+// of the handle's running estimate (its answer is that far away at most when it is next in line), 40..300 us -
+// not for a fixed 300 us whatever the call takes (16 callers kept 15 cores spinning)
+#define LS_WAITER_SPIN_MIN_US 40.0
+#define LS_WAITER_SPIN_MAX_US 300.0
 struct ls_served {  // one batch between its begin and its finish
     ls_host_call call;
     std::vector<ls_req*> batch;
@@ -1668,13 +1690,14 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             // The answer is typically 50-150 us away and a futex wake-up costs tens of us (times the callers
             // woken at once): poll the queue's epoch for a while before sleeping (round 5)
             const uint64_t seen = ix->q_epoch.load(std::memory_order_acquire);
+            const double spin_us = std::min(LS_WAITER_SPIN_MAX_US, std::max(LS_WAITER_SPIN_MIN_US, 2.0 * ix->call_us_est));
             lk.unlock();
             bool changed = false;
             const auto t0 = std::chrono::steady_clock::now();
             for (unsigned it = 0; !changed; ++it) {
-                for (int i = 0; i < 32; ++i) _mm_pause();
+                for (int i = 0; i < 32; ++i) ls_cpu_relax();
                 changed = ix->q_epoch.load(std::memory_order_acquire) != seen;
-                if ((it & 15) == 15 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(LS_WAITER_SPIN_US)) break;
+                if ((it & 15) == 15 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
             }
             lk.lock();
             if (!changed && !me.done && (ix->leader_active || me.taken) &&
@@ -1705,7 +1728,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             // (with the gather on, only STRAGGLERS of a short pass go early: every caller seen lately is in flight
             // or queued, so waiting could add nobody - Python threads hand the GIL around and arrive spread over
             // more than the gather window: 8 Python callers 46.6 k -> 51-67 k q/s, C threads unchanged at 75-80 k)
-            if (ix->opt_gather == 2)
+            if (ix->opt_gather)
                 return ix->opt_overlap_calls && ix->calls_in_flight < LS_HOST_SLOTS && total > 2 &&
                        total >= ix->peak_callers && total <= ix->opt_early_cap;
             return ix->opt_overlap_calls && ix->calls_in_flight < LS_HOST_SLOTS &&
@@ -1713,13 +1736,14 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         };
         while (ix->calls_in_flight > 0 && !go_early()) {
             const uint64_t seen = ix->q_epoch.load(std::memory_order_acquire);  // (as above: poll, then sleep)
+            const double spin_us = std::min(LS_WAITER_SPIN_MAX_US, std::max(LS_WAITER_SPIN_MIN_US, 2.0 * ix->call_us_est));
             lk.unlock();
             bool changed = false;
             const auto t0 = std::chrono::steady_clock::now();
             for (unsigned it = 0; !changed; ++it) {
-                for (int i = 0; i < 32; ++i) _mm_pause();
+                for (int i = 0; i < 32; ++i) ls_cpu_relax();
                 changed = ix->q_epoch.load(std::memory_order_acquire) != seen;
-                if ((it & 15) == 15 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(LS_WAITER_SPIN_US)) break;
+                if ((it & 15) == 15 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
             }
             lk.lock();
             if (!changed && ix->calls_in_flight > 0 && ix->q_epoch.load(std::memory_order_acquire) == seen)
@@ -1732,8 +1756,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         // handed out microseconds ago). Launching now would split the callers into two groups that wait for each
         // other's pass forever (4 callers, d = 1024: 2 + 2, every call 2 x 158 us); a short wait puts them all
         // into ONE pass. Bounded by a third of the running estimate of a call, at most LS_GATHER_MAX_US.
-        if (ix->opt_gather && ix->calls_in_flight == 0 && (int64_t)ix->req_q.size() < ix->peak_callers &&
-            (ix->opt_gather == 2 || ix->call_us_est > LS_GATHER_SLOW_US || ix->peak_callers > ix->opt_early_cap)) {
+        if (ix->opt_gather && ix->calls_in_flight == 0 && (int64_t)ix->req_q.size() < ix->peak_callers) {
             const double budget_us = std::min<double>(LS_GATHER_MAX_US, ix->call_us_est / LS_GATHER_DIV);
             const auto t0 = std::chrono::steady_clock::now();
             while ((int64_t)ix->req_q.size() < ix->peak_callers) {
@@ -1741,7 +1764,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
                 lk.unlock();
                 bool changed = false, late = false;
                 for (unsigned it = 0; !changed && !late; ++it) {
-                    for (int i = 0; i < 16; ++i) _mm_pause();
+                    for (int i = 0; i < 16; ++i) ls_cpu_relax();
                     changed = ix->q_epoch.load(std::memory_order_acquire) != seen;
                     if ((it & 7) == 7)
                         late = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > budget_us;
@@ -2093,10 +2116,6 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->opt_wave_select = value != 0;
         return LS_OK;
     }
-    if (which == 15) {  // synchronous host calls: copy command for the query (1, default) / kernels read pinned memory (0)
-        ix->opt_query_copy = value != 0;
-        return LS_OK;
-    }
     if (which == 9) {  // synchronous host calls: selection inside the scan launch of its own query (default on)
         ix->opt_same_launch = value != 0;
         return LS_OK;
@@ -2105,17 +2124,19 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         ix->opt_blocks = value;
         return LS_OK;
     }
-    if (which == 18) {  // fp16 index, 48-chunk rows: the batched pass in the row-split, 64-queries-per-wave shape (default off)
+#ifdef LS_VARIANT_RS2
+    if (which == 18) {  // fp16 index, 48-chunk rows: the batched pass in the row-split, 64-queries-per-wave shape (variant builds)
         if (int rc = ls_i_batched_repair(ix)) return rc;  // nothing pending in the other geometry
         ix->g.qg4 = value != 0;
         return LS_OK;
     }
+#endif
     if (which == 21) {  // most callers for which a second batch may go early on the other host slot (default 8)
         ix->opt_early_cap = value;
         return LS_OK;
     }
-    if (which == 20) {  // concurrent callers are gathered into one pass (0 off, 1 long passes only, 2 always: default)
-        ix->opt_gather = value;
+    if (which == 20) {  // concurrent callers are gathered into one pass (0 off; default on)
+        ix->opt_gather = value != 0;
         return LS_OK;
     }
     if (which == 22) {  // fp32 index: one ls_mq pass carries up to 32 queries (two MFMA B blocks per A operand; default on)
@@ -2205,7 +2226,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 25) return -1;
+    if (!ix || which < 0 || which > 26) return -1;
     if (which == 16 || which == 17) {
         std::lock_guard<std::mutex> ql(ix->q_mu);
         return (int64_t)(which == 16 ? ix->n_combined_batches : ix->n_combined_requests);
@@ -2222,6 +2243,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
     if (which == 23) return (int64_t)ix->n_mq_launches;
     if (which == 24) return (int64_t)ix->n_overlapped_calls;
     if (which == 25) return (int64_t)ix->n_mq_reserved;
+    if (which == 26) return (int64_t)ix->n_mq_skipped_repairs;
     if (which > 9) return 0;  // 13..15, 18, 19 and 21 are group counters
     if (hipSetDevice(ix->device) != hipSuccess) return -1;
     u32 v = 0;

@@ -20,7 +20,6 @@
 // - a latency-bound problem at this size, which is why the launch count is what matters.
 #include "ls_select_dev.h"
 
-#include <immintrin.h>
 
 #include <algorithm>
 #include <chrono>
@@ -397,7 +396,7 @@ int ls_bm25_search(ls_bm25* ix, const int32_t* token_ids, int32_t n_tokens, int3
                         __atomic_load_n(&ix->h_out_g[j].tag_hi, __ATOMIC_ACQUIRE) != seq)
                         break;
                 if (j == kk) break;
-                _mm_pause();
+                ls_cpu_relax();
                 if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
                     LS_HIP(hipStreamSynchronize(s));
                     std::atomic_thread_fence(std::memory_order_acquire);

@@ -16,6 +16,7 @@
 #include <cfloat>
 
 #include "../../include/leansearch.h"
+#include "../../include/leansearch_debug.h"
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
@@ -121,6 +122,16 @@ __host__ __device__ __forceinline__ float ls_key_score(u64 key) {
 __host__ __device__ __forceinline__ int64_t ls_key_index(u64 key, int64_t base) {
     return key ? base + (int64_t)(0xffffffffu - (u32)(key & 0xffffffffull)) : (int64_t)-1;
 }
+
+// ---- one step of a polite busy-wait (host code; ADVICE r5: _mm_pause alone is x86-only) ---------
+#if defined(__x86_64__) || defined(__i386__)
+#include <immintrin.h>
+static inline void ls_cpu_relax() { _mm_pause(); }
+#elif defined(__aarch64__)
+static inline void ls_cpu_relax() { __asm__ __volatile__("yield" ::: "memory"); }
+#else
+static inline void ls_cpu_relax() {}
+#endif
 
 // ---- error plumbing (host) -----------------------------------------------------------------
 void ls_set_error(const char* fmt, ...);

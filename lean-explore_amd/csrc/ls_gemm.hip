@@ -779,15 +779,23 @@ __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_ge
     const float* __restrict__ tau, long long rows_per_split, int tile_stride, ls_gemm_out out) {
     gemm_filter_body<CHUNKS, QG, 1, TOPN, NT, MODE>(corpus, n, qh, nq, nqt, tau, rows_per_split, tile_stride, out);
 }
-// the row-split, 64-queries-per-wave shape (its own kernel name: the profile tooling tells the shapes apart)
+#ifdef LS_VARIANT_RS2
+// The row-split, 64-queries-per-wave shape (round 5; `make variant NAME=rs2 VFLAGS=-DLS_VARIANT_RS2`, debug option
+// 18): exact, LDS / MFMA instruction ratio 0.25 instead of 0.5, but 21 registers spilled inside the tile loop -
+// pass 185 us against 124 (profiles/ab/r05_tile_shape.txt). A measured loser: not in the shipped library.
 template <int CHUNKS, int TOPN, bool NT, int MODE>
 __global__ __launch_bounds__(LS_GEMM_THREADS, LS_GEMM_WAVES_PER_SIMD) void ls_gemm_filter_rs2_kernel(
     const u32x4* __restrict__ corpus, long long n, const u32x4* __restrict__ qh, int nq, int nqt,
     const float* __restrict__ tau, long long rows_per_split, int tile_stride, ls_gemm_out out) {
     gemm_filter_body<CHUNKS, 4, 2, TOPN, NT, MODE>(corpus, n, qh, nq, nqt, tau, rows_per_split, tile_stride, out);
 }
+#endif
 
+#ifdef LS_VARIANT_RS2
 static inline bool gemm_is_qg4(const ls_geom& g) { return g.qg4 != 0 && g.chunks == 48 && g.elem == 2; }
+#else
+static inline bool gemm_is_qg4(const ls_geom&) { return false; }
+#endif
 int ls_gemm_rs(const ls_geom& g) { return gemm_is_qg4(g) ? 2 : 1; }
 int ls_gemm_qg(const ls_geom& g) { return gemm_is_qg4(g) ? 4 : gemm_qg(g.chunks); }
 int ls_gemm_qt(const ls_geom& g) { return (LS_GEMM_WAVES / ls_gemm_rs(g)) * 16 * ls_gemm_qg(g); }
@@ -830,6 +838,7 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
         LS_HIP(hipGetLastError());                                                                \
         return LS_OK;                                                                             \
     }
+#ifdef LS_VARIANT_RS2
 #define LS_GEMM_LAUNCH_RS2(C, MODE, TOPN, NT)                                                     \
     {                                                                                             \
         auto kern = ls_gemm_filter_rs2_kernel<C, TOPN, NT, MODE>;                                 \
@@ -852,6 +861,7 @@ int ls_launch_gemm_filter(const void* d_corpus, int64_t n, const ls_geom& g, con
         else LS_GEMM_LAUNCH_RS2(48, LS_GEMM_SAMPLE, 4, false)
     }
 #undef LS_GEMM_LAUNCH_RS2
+#endif
 #define LS_GEMM_TOP2(C) (C / 4 * gemm_qg(C) * 4 >= 128 && sample_top2)
 // (the fused launch exists for the two-accumulator geometries only: rows of up to 768 bytes. The
 // register-starved ones spend ~1 % of a multi-millisecond batch outside the pass; a forced fused run of

@@ -186,8 +186,10 @@ struct ls_index {
     int32_t opt_scan_skip_scores = 1;  // ... single-query launches of pipelined / synchronous device calls too
     int32_t opt_mq_skip_scores = 1;    // ... whose selection jobs ride along write no score vectors (debug option 19)
     uint64_t n_mq_reserved = 0;        // queries of such launches served again on the scan kernel (counter 25)
-    int32_t opt_early_cap = 8;         // ls_search: callers up to which a second batch goes early (debug option 21)
-    int32_t opt_gather = 2;            // ls_search: callers of long passes are gathered into one pass (debug option 20)
+    uint64_t n_mq_skipped_repairs = 0; // ... whose output rows a later pipelined call had been given meanwhile (counter 26)
+    // (read under q_mu by ls_search, written under the handle's mutex by ls_debug_option: atomics)
+    std::atomic<int32_t> opt_early_cap{8};   // ls_search: callers up to which a second batch goes early (debug option 21)
+    std::atomic<int32_t> opt_gather{1};      // ls_search: concurrent callers are gathered into one pass (debug option 20)
     double call_us_est = 0.0;          // running estimate of one combined call, begin to finish (under q_mu)
     bool reserving = false;            // (that second serve is being queued: its selection takes its own launch)
     // ... and so do pipelined / synchronous DEVICE-output calls: the launch keeps its raw queries (slot of
@@ -208,8 +210,6 @@ struct ls_index {
     u32* d_mq_flags = nullptr;         // [LS_MQ_KEEP_SLOTS][16]
     u32* h_mq_flags = nullptr;         // pinned mirror; its LAST word is raised by any flagged job (ls_fin_params::repair_any)
     bool dev_call_repairable = false;  // set by ls_search_device around a call whose results may be repaired later
-    int32_t opt_query_copy = 0;        // synchronous host calls: 0 = the kernels read the pinned host copy over PCIe
-                                       // themselves, 1 = a copy command brings the query to device memory first
     int32_t opt_same_launch = 1;       // synchronous host calls: the selection rides on its own query's scan launch
     uint64_t n_forced_checks = 0;           // checks of pending batched calls the library ran on its own
     uint64_t n_same_launch_retries = 0;     // host calls that had to launch the stand-alone finalize

@@ -38,7 +38,6 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
-#include <immintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -149,7 +148,7 @@ struct ls_shard_worker {
             bool got = false;
             for (int i = 0; i < 3000 && !got; ++i) {  // calls come back to back: spin ~50 us first
                 if (posted.load(std::memory_order_acquire) != seen) got = true;
-                else _mm_pause();
+                else ls_cpu_relax();
             }
             if (!got) {
                 std::unique_lock<std::mutex> lk(mu);
@@ -177,7 +176,7 @@ struct ls_shard_worker {
         const uint32_t want = posted.load(std::memory_order_relaxed);
         for (unsigned it = 0; done.load(std::memory_order_acquire) != want; ++it) {
             if ((it & 4095) == 4095) std::this_thread::yield();
-            else _mm_pause();
+            else ls_cpu_relax();
         }
         return rc;
     }

@@ -292,7 +292,7 @@ class FlatIPIndex:
         q: float32 CUDA tensor [nq, d]. Work is queued on ``stream`` (default: torch's current
         stream). Returns (scores float32 [nq, k], indices int64 [nq, k]) CUDA tensors.
         ``asynchronous``: queue and return, results ordered on the stream. For ANY batched call
-        (the speculative MFMA paths: nq > 16 on an fp16 index, nq >= 24 on an fp32 index) call
+        (the speculative MFMA paths: nq > 16 on an fp16 index, nq > 32 on an fp32 index) call
         :meth:`check` before trusting them: it repairs the rare query the speculative threshold
         short-changed, re-writing its rows of the output tensors (keep those alive until then;
         ``q`` may be reused at once in stream order). On a sharded index (``devices=[...]``) ``q``

@@ -112,7 +112,7 @@ class ShardedFlatIPIndex:
         """q: float32 tensor [nq, d] (same on every rank). Returns (scores, rows) [nq, k]
         tensors, identical on every rank. All work is queued on the current stream and the local
         search is ALWAYS asynchronous: for any batched call (the shards' speculative MFMA paths:
-        nq > 16 on fp16 shards, nq >= 24 on fp32 shards) the tensors are provisional until
+        nq > 16 on fp16 shards, nq > 32 on fp32 shards) the tensors are provisional until
         :meth:`finish`, with one rank as with many (``finish`` then is the local ls_check)."""
         import torch
         import torch.distributed as dist

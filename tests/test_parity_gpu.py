@@ -292,14 +292,14 @@ def test_synchronous_call_hand_off_variants_agree():
     """The synchronous host call (the reference's index.search, search/engine.py:250) in its four shapes:
     selection inside the scan launch over tagged granules (default), too many granules for the
     in-launch sweep (k' forced to 12: 448 x 13 > LS_GRAN_MAX, the selection gets its own launch), the
-    query brought over by a copy command (debug option 15), selection as its own launch (option 9 = 0).
+    selection as its own launch (option 9 = 0).
     Same bits from all of them, one launch for the first, results through the tagged result granules
     (a base offset is applied by the host when it decodes the keys)."""
     c = H.gauss(41, 200_000, 384)
     q = H.gauss(42, 5, 384)
     ix = FlatIPIndex.from_array(c, base=1_000_000_007)
     ref = None
-    for opts in ([], [(0, 12)], [(15, 1)], [(9, 0)]):
+    for opts in ([], [(0, 12)], [(9, 0)]):  # (round 6: the query copy command, option 15, was removed)
         for which, value in opts:
             ix.debug_option(which, value)
         before = ix.debug_counter(11)

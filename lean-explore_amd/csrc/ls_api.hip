@@ -325,12 +325,12 @@ int ls_set_base(ls_index* ix, int64_t base) {
 }  // extern "C"
 
 // choose k' (keys each scan workgroup emits) from lambda = expected top-k rows per workgroup
-static int pick_kprime(const ls_index* ix, int blocks, int keff) {
-    if (ix->opt_kprime > 0) return std::min(ix->opt_kprime, LS_KP_MAX - 1);
+static int pick_kprime(const ls_index* ix, int blocks, int keff, int kp_max = LS_KP_MAX) {
+    if (ix->opt_kprime > 0) return std::min(ix->opt_kprime, kp_max - 1);
     const double lam = (double)keff / (double)blocks;
     int kp = (int)(lam + 5.0 * __builtin_sqrt(lam) + 3.0);
     kp = std::max(kp, 2);
-    kp = std::min(kp, LS_KP_MAX - 1);
+    kp = std::min(kp, kp_max - 1);
     while (kp > 1 && (int64_t)blocks * kp > LS_FINAL_CAP) --kp;
     return kp;
 }
@@ -390,9 +390,13 @@ static mq_plan mq_make_plan(const ls_index* ix, int nq, int32_t k) {
     if (!(ix->opt_mq && ix->opt_multi_query && ix->dtype == LS_DTYPE_F32 && ix->n >= LS_MQ_MIN_ROWS)) return p;
     const int keff = (int)std::max<int64_t>(std::min<int64_t>(k, ix->n), 1);
     p.blocks = ix->opt_blocks > 0 ? std::min(ix->opt_blocks, ix->max_blocks) : ls_mq_blocks(ix->n, ix->n_cu, nq, ix->g.chunks);
-    p.kprime = pick_kprime(ix, p.blocks, keff);
+    // (an ls_mq workgroup ranks waves x keys of them and may emit more than the scan kernel's 15: at k = 1000 over
+    // 224-241 workgroups - 4.2-4.5 of a query's top-k each on average - the 15-key cap left the proof unprovable for
+    // 1.5e-3..3.6e-3 of the queries, each one a second serve of 140 us; 23 keys: 1e-9)
+    p.kprime = pick_kprime(ix, p.blocks, keff, LS_MQ_KP_MAX);
     p.keys = ls_mq_lane_keys(p.blocks, keff, nq);
-    if (p.keys == 3 && p.kprime + 1 > ls_mq_waves(nq) * 3) p.keys = 5;  // the workgroup ranks waves x keys: k' + 1 of them go out
+    while (p.keys > 0 && p.keys < 8 && p.kprime + 1 > ls_mq_waves(nq) * p.keys) p.keys = p.keys == 3 ? 5 : 8;  // k' + 1 of waves x keys go out
+    if (p.keys > 0) p.kprime = std::min(p.kprime, ls_mq_waves(nq) * p.keys - 1);
     return p;
 }
 // Queries one ls_mq pass may carry on this index for this k: 32 (two 16-column MFMA blocks per A operand), or
@@ -1498,6 +1502,7 @@ static int host_call_finish(ls_host_call& c) {
         bool retry = false;
         done = wait_words(true, &retry);
         if (!done) {  // slow launch: sleep until the stream has drained, then every word is final
+            __atomic_fetch_add(&ix->n_spin_timeouts, 1ull, __ATOMIC_RELAXED);
             LS_HIP(hipStreamSynchronize(s));
             done = wait_words(true, &retry);
         }
@@ -1599,7 +1604,9 @@ struct ls_req {
     float* out_s;
     int64_t* out_i;
     int rc = LS_OK;
-    bool done = false, taken = false;  // taken: popped into a batch some leader is serving
+    std::atomic<bool> done{false};     // set LAST by the serving thread (release): the waiter may return - and its request,
+                                       // which lives on its stack, vanish - the moment it sees it, without the queue's mutex
+    std::atomic<bool> taken{false};    // popped into a batch some leader is serving (set under q_mu; a waiter polls it)
     char err[256] = "";
 };
 
@@ -1682,26 +1689,55 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
     if (!ix->opt_combine || nq > scan_path_max_nq(ix, k))  // what fills a pass by itself gains nothing from company
         return host_search_locked(ix, q, nq, k, flags, out_scores, out_indices);
     ls_req me{q, nq, k, flags, out_scores, out_indices};
-    std::unique_lock<std::mutex> lk(ix->q_mu);
+    // (round 6: 32 callers ran at 65 k q/s where 16 ran at 100 k - 470 us per batch for a 100 us pass. Every arrival
+    // bumped the ONE epoch every waiter polled, so each of N arrivals sent the other waiters through the queue's
+    // mutex: O(N^2) acquisitions per batch, the losers parked in futex_wait. Now a waiter whose request is in a
+    // batch polls its own `done` flag and nothing else, a queued one polls `lead_epoch` - bumped only when the
+    // leadership or a host slot comes free - and neither takes the mutex to find out; arrivals bump `q_epoch`,
+    // which only the one gathering leader reads.)
+    auto q_lock = [](std::unique_lock<std::mutex>& l) {
+        for (int i = 0; i < 64; ++i) {  // (a few us: the sections are short; then park)
+            if (l.try_lock()) return;
+            for (int j = 0; j < 16; ++j) ls_cpu_relax();
+        }
+        l.lock();
+    };
+    std::unique_lock<std::mutex> lk(ix->q_mu, std::defer_lock);
+    q_lock(lk);
     ix->req_q.push_back(&me);
     ix->q_epoch.fetch_add(1, std::memory_order_release);  // (a leader waiting to form its batch counts the arrivals)
-    while (!me.done) {
-        if (ix->leader_active || me.taken) {  // (taken: my request is in a batch someone is serving)
+    {   // running estimate of the time between two arrivals (what the gather below asks before it waits)
+        const auto now = std::chrono::steady_clock::now();
+        if (ix->arrivals_seen++) {
+            const double gap = std::min(1e4, std::chrono::duration<double, std::micro>(now - ix->last_arrival).count());
+            ix->arrival_gap_us += (gap - ix->arrival_gap_us) / 8.0;
+        }
+        ix->last_arrival = now;
+    }
+    bool answered = false;  // seen `done` without holding the mutex
+    while (!me.done.load(std::memory_order_acquire)) {
+        if (ix->leader_active || me.taken.load(std::memory_order_relaxed)) {  // (taken: my request is in a batch someone is serving)
             // The answer is typically 50-150 us away and a futex wake-up costs tens of us (times the callers
-            // woken at once): poll the queue's epoch for a while before sleeping (round 5)
-            const uint64_t seen = ix->q_epoch.load(std::memory_order_acquire);
+            // woken at once): poll for a while before sleeping (round 5)
+            const uint64_t seen = ix->lead_epoch.load(std::memory_order_acquire);
             const double spin_us = std::min(LS_WAITER_SPIN_MAX_US, std::max(LS_WAITER_SPIN_MIN_US, 2.0 * ix->call_us_est));
             lk.unlock();
             bool changed = false;
             const auto t0 = std::chrono::steady_clock::now();
             for (unsigned it = 0; !changed; ++it) {
                 for (int i = 0; i < 32; ++i) ls_cpu_relax();
-                changed = ix->q_epoch.load(std::memory_order_acquire) != seen;
+                if (me.done.load(std::memory_order_acquire)) {
+                    answered = true;
+                    break;
+                }
+                // (a request still in the queue may have to lead: it looks again when the leadership or a slot came free)
+                changed = !me.taken.load(std::memory_order_acquire) && ix->lead_epoch.load(std::memory_order_acquire) != seen;
                 if ((it & 15) == 15 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
             }
-            lk.lock();
-            if (!changed && !me.done && (ix->leader_active || me.taken) &&
-                ix->q_epoch.load(std::memory_order_acquire) == seen)
+            if (answered) break;  // (nothing of the queue is touched any more: no mutex)
+            q_lock(lk);
+            if (!changed && !me.done.load(std::memory_order_acquire) && (ix->leader_active || me.taken.load(std::memory_order_relaxed)) &&
+                ix->lead_epoch.load(std::memory_order_acquire) == seen)
                 ix->q_cv.wait(lk);
             continue;
         }
@@ -1745,7 +1781,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
                 changed = ix->q_epoch.load(std::memory_order_acquire) != seen;
                 if ((it & 15) == 15 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
             }
-            lk.lock();
+            q_lock(lk);
             if (!changed && ix->calls_in_flight > 0 && ix->q_epoch.load(std::memory_order_acquire) == seen)
                 ix->q_cv.wait(lk);
         }
@@ -1756,8 +1792,12 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         // handed out microseconds ago). Launching now would split the callers into two groups that wait for each
         // other's pass forever (4 callers, d = 1024: 2 + 2, every call 2 x 158 us); a short wait puts them all
         // into ONE pass. Bounded by a third of the running estimate of a call, at most LS_GATHER_MAX_US.
-        if (ix->opt_gather && ix->calls_in_flight == 0 && (int64_t)ix->req_q.size() < ix->peak_callers) {
-            const double budget_us = std::min<double>(LS_GATHER_MAX_US, ix->call_us_est / LS_GATHER_DIV);
+        // (round 6, open-loop record profiles/ab/r06_open_loop.txt: at 5-10 k requests/s - one arrival per 100-200 us -
+        // the window mostly expired empty and cost the lone request it delayed 15-55 us: the leader waits only when
+        // the arrival rate seen lately makes another request within the window likelier than not)
+        const double budget_us = std::min<double>(LS_GATHER_MAX_US, ix->call_us_est / LS_GATHER_DIV);
+        if (ix->opt_gather && ix->calls_in_flight == 0 && (int64_t)ix->req_q.size() < ix->peak_callers &&
+            ix->arrival_gap_us < 3.5 * budget_us) {
             const auto t0 = std::chrono::steady_clock::now();
             while ((int64_t)ix->req_q.size() < ix->peak_callers) {
                 const uint64_t seen = ix->q_epoch.load(std::memory_order_acquire);
@@ -1769,7 +1809,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
                     if ((it & 7) == 7)
                         late = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > budget_us;
                 }
-                lk.lock();
+                q_lock(lk);
                 if (late) {
                     // the callers that did not come are gone (or slower than the window): stop waiting for them
                     // quickly - a lone caller after a burst of 16 would otherwise pay the window for ~500 calls
@@ -1788,14 +1828,14 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             // (the head request always goes: an option changed since it was queued may have lowered the cap under it)
             if (r != head && (r->k != head->k || r->flags != head->flags || total + r->nq > batch_cap)) break;
             sv.batch.push_back(r);
-            r->taken = true;
+            r->taken.store(true, std::memory_order_release);
             total += r->nq;
             ix->req_q.pop_front();
         }
         lk.unlock();
         const auto t_call = std::chrono::steady_clock::now();
         serve_begin(ix, sv);
-        lk.lock();
+        q_lock(lk);
         ix->calls_in_flight++;
         ix->requests_in_flight += (int64_t)sv.batch.size();
         {
@@ -1805,20 +1845,23 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         }
         ix->leader_active = false;
         ix->q_epoch.fetch_add(1, std::memory_order_release);
+        ix->lead_epoch.fetch_add(1, std::memory_order_release);
         ix->q_cv.notify_all();  // a waiter whose request is still queued leads the next batch
         lk.unlock();
         serve_finish(ix, sv);
-        lk.lock();
+        q_lock(lk);
         {
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
             ix->call_us_est = ix->call_us_est <= 0.0 ? us : ix->call_us_est + (us - ix->call_us_est) / 8.0;
         }
         ix->calls_in_flight--;
         ix->requests_in_flight -= (int64_t)sv.batch.size();
-        for (ls_req* r : sv.batch) r->done = true;
+        for (ls_req* r : sv.batch) r->done.store(true, std::memory_order_release);  // (the last access to *r)
         ix->q_epoch.fetch_add(1, std::memory_order_release);
+        ix->lead_epoch.fetch_add(1, std::memory_order_release);
         ix->q_cv.notify_all();
     }
+    if (lk.owns_lock()) lk.unlock();
     if (me.rc != LS_OK && me.err[0]) ls_set_error("%s", me.err);
     return me.rc;
 }
@@ -2226,7 +2269,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 26) return -1;
+    if (!ix || which < 0 || which > 27) return -1;
     if (which == 16 || which == 17) {
         std::lock_guard<std::mutex> ql(ix->q_mu);
         return (int64_t)(which == 16 ? ix->n_combined_batches : ix->n_combined_requests);
@@ -2244,6 +2287,7 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
     if (which == 24) return (int64_t)ix->n_overlapped_calls;
     if (which == 25) return (int64_t)ix->n_mq_reserved;
     if (which == 26) return (int64_t)ix->n_mq_skipped_repairs;
+    if (which == 27) return (int64_t)__atomic_load_n(&ix->n_spin_timeouts, __ATOMIC_RELAXED);
     if (which > 9) return 0;  // 13..15, 18, 19 and 21 are group counters
     if (hipSetDevice(ix->device) != hipSuccess) return -1;
     u32 v = 0;

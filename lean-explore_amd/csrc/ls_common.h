@@ -27,6 +27,7 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 #define LS_SCAN_THREADS 256          // 4 waves per scan workgroup
 #define LS_SCAN_WAVES (LS_SCAN_THREADS / LS_WAVE)
 #define LS_KP_MAX 16                 // per-workgroup emitted candidates (k') + 1 bound
+#define LS_MQ_KP_MAX 24              // ... of an ls_mq workgroup (it ranks waves x keys-per-lane of them; c_stride has the room)
 #define LS_FINAL_THREADS 1024
 #define LS_FINAL_CAP 8192            // keys the finalize workgroup sorts in LDS (64 KiB)
 #ifndef LS_SS_MAX_KEYS

@@ -67,10 +67,14 @@ struct ls_index {
     std::condition_variable q_cv;
     std::deque<ls_req*> req_q;
     bool leader_active = false;
-    std::atomic<uint64_t> q_epoch{0};  // bumped whenever the queue's state changes (leadership free, results handed back)
+    std::atomic<uint64_t> q_epoch{0};  // bumped whenever the queue's state changes (arrivals too: the gathering leader counts them)
+    std::atomic<uint64_t> lead_epoch{0};  // bumped when the leadership or a host slot comes free: what a QUEUED waiter polls
     int32_t calls_in_flight = 0;       // batches queued whose results have not been handed back yet (under q_mu)
     int64_t requests_in_flight = 0;    // ... and the requests in them
     int64_t peak_callers = 0;          // decaying maximum of (requests in flight + queued): the callers around lately
+    std::chrono::steady_clock::time_point last_arrival{};  // (under q_mu) ...
+    double arrival_gap_us = 1e4;       // ... running mean of the time between two ls_search arrivals
+    uint64_t arrivals_seen = 0;
     uint32_t peak_decay = 0;
     int32_t opt_combine = 1;
     uint64_t n_combined_batches = 0, n_combined_requests = 0;
@@ -213,6 +217,7 @@ struct ls_index {
     int32_t opt_same_launch = 1;       // synchronous host calls: the selection rides on its own query's scan launch
     uint64_t n_forced_checks = 0;           // checks of pending batched calls the library ran on its own
     uint64_t n_same_launch_retries = 0;     // host calls that had to launch the stand-alone finalize
+    unsigned long long n_spin_timeouts = 0; // host calls whose 2 ms of polling ran out (they slept in hipStreamSynchronize; counter 27)
     u32 gran_tag = 0;                  // tag of the last same-launch selection (ls_fin_params::tag; never 0)
     int32_t max_blocks = 0;
     u32* d_counters = nullptr;                        // [0] finalize slow-path count

@@ -540,19 +540,26 @@ int ls_mq_blocks(int64_t n, int32_t n_cu, int nq, int chunks) {
     return (int)best;
 }
 
-// keys a lane keeps: the smallest of {3, 5, 8} for which "some lane of the launch holds that many of one
-// query's top-k" is rarer than 2e-3 per query (Poisson tail, lambda = k / lanes per query); 0 = this
-// kernel is the wrong tool (k too large for the shard: the scan path's groups take the call)
+// keys a lane - and, after the in-register merge of its four lane groups, a WAVE - keeps per query: the smallest
+// of {3, 5, 8} for which "some wave of the launch holds more than that many of one query's top-k" is rarer than
+// 2e-3 per query (the wave-level list is the binding one: a wave sees n / waves rows of the query, a Poisson(k /
+// waves) number of them in the top-k; whatever it drops raises the workgroup's bound past the k-th key and the
+// query is served again - 140 us at d = 1024). Round 5 priced the per-lane lists only; with two B blocks at
+// k = 1000 (1792 waves, 0.56 top-k rows per wave) that chose 5 keys and 4 % of the queries were served twice.
+// 0 = this kernel is the wrong tool (k too large for the shard: the scan path's groups take the call).
 int ls_mq_waves(int nq) { return mq_wpb(nq); }
 int ls_mq_lane_keys(int blocks, int keff, int nq) {
-    const double lanes = 4.0 * mq_wpb(nq) * blocks;
-    const double lam = (double)keff / lanes;
-    const double p3 = lam * lam * lam / 6.0 * lanes;
-    if (p3 < 2e-3) return 3;
-    const double p5 = lam * lam * lam * lam * lam / 120.0 * lanes;
-    if (p5 < 4e-3) return 5;
-    const double l4 = lam * lam * lam * lam;
-    if (l4 * l4 / 40320.0 * lanes < 4e-3) return 8;  // (k = 1000 over 200 k rows: lambda = 0.24)
+    const double waves = (double)mq_wpb(nq) * blocks;
+    const double mu = (double)keff / waves;
+    for (int m : {3, 5, 8}) {
+        double term = __builtin_exp(-mu), tail = 1.0 - term;  // P(X >= 1)
+        for (int j = 1; j <= m; ++j) {
+            term *= mu / j;
+            tail -= term;  // ... P(X >= m + 1)
+        }
+        if (tail < 0.0) tail = 0.0;
+        if (tail * waves < 2e-3) return m;
+    }
     return 0;
 }
 
@@ -592,7 +599,7 @@ static int mq_launch(const void* corpus, int64_t n, const ls_geom& g, const ls_s
 // a.nq = the real query count (2..32); a.mq_keys = ls_mq_lane_keys(a.blocks, k, a.nq): 3, 5 or 8
 int ls_launch_mq(const void* d_corpus, int64_t n, const ls_geom& g, const ls_scan_args& a, hipStream_t s) {
     if (n <= 0) return LS_OK;
-    if (g.elem != 4 || a.nq < 1 || a.nq > 2 * LS_MQ_NQ || a.kprime < 1 || a.kprime + 1 > LS_KP_MAX ||
+    if (g.elem != 4 || a.nq < 1 || a.nq > 2 * LS_MQ_NQ || a.kprime < 1 || a.kprime + 1 > LS_MQ_KP_MAX ||
         (a.mq_keys != 3 && a.mq_keys != 5 && a.mq_keys != 8)) {
         ls_set_error("ls_launch_mq: bad arguments (elem %d nq %d kprime %d keys %d)", g.elem, a.nq, a.kprime, a.mq_keys);
         return LS_ERR_INVALID_ARG;

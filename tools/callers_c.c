@@ -1,7 +1,13 @@
 /* callers_c.c - T threads making synchronous single-query ls_search calls on ONE handle (the reference's call,
  * search/engine.py:250, issued by several MCP clients, mcp/server.py:147-151), timed from C: what the library's
  * caller combining delivers without the Python threads' GIL hand-offs that tools/concurrent_callers.py includes.
- *   gcc -O2 tools/callers_c.c -o scratch/callers_c -ldl -lm -lpthread && ./scratch/callers_c lean-explore_amd/libleansearch.so [overlap [gather [reps]]] */
+ *   gcc -O2 tools/callers_c.c -o scratch/callers_c -ldl -lm -lpthread && ./scratch/callers_c lean-explore_amd/libleansearch.so [overlap [gather [reps]]]
+ * Round 6, OPEN LOOP (verdict item 4):  ./scratch/callers_c lib open [seconds per point]
+ *   16 client threads, each a Poisson process of rate lambda / 16 (arrival times drawn ahead, independent of the
+ *   answers: a thread that is still in a call when its next arrival is due starts late, and the latency of that
+ *   request counts from its ARRIVAL time), lambda = 5 / 10 / 20 / 40 / 80 k requests/s, with the caller gather
+ *   (debug option 20) on and off: achieved q/s, p50, p99 - next to the lone caller's closed-loop p50 / p99. */
+#include <string.h>
 #include <dlfcn.h>
 #include <math.h>
 #include <pthread.h>
@@ -11,6 +17,7 @@
 #include <time.h>
 
 typedef struct ls_index ls_index;
+static int64_t (*g_counter)(ls_index*, int32_t);
 static int (*search)(ls_index*, const float*, int64_t, int32_t, uint32_t, float*, int64_t*);
 static double now_us(void) {
     struct timespec t;
@@ -39,6 +46,68 @@ static void* worker(void* p) {
     free(D); free(I);
     return NULL;
 }
+/* ---- open loop ---------------------------------------------------------------------------------------------- */
+struct ojob { ls_index* ix; const float* q; int d, k; double t0, stop, rate_per_us; uint64_t seed; long calls; double* lat; long cap; };
+static void* open_worker(void* p) {
+    struct ojob* j = p;
+    float* D = malloc(sizeof(float) * j->k);
+    int64_t* I = malloc(sizeof(int64_t) * j->k);
+    uint64_t s = j->seed;
+    double arrival = j->t0;
+    for (;;) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const double u = ((s >> 11) + 1.0) / 9007199254740993.0;
+        arrival += -log(u) / j->rate_per_us;          /* exponential inter-arrival time */
+        if (arrival >= j->stop) break;
+        while (now_us() < arrival) { /* idle until the request arrives (a busy wait: sleeping costs tens of us) */ }
+        if (search(j->ix, j->q, 1, j->k, 1u, D, I)) break;
+        if (j->calls < j->cap) j->lat[j->calls] = now_us() - arrival;   /* from ARRIVAL, not from the call's start */
+        j->calls++;
+    }
+    free(D); free(I);
+    return NULL;
+}
+static int open_loop(ls_index* ix, int (*option)(ls_index*, int32_t, int32_t), const float* q, int64_t n, int d, int k, double secs) {
+    enum { T = 16 };
+    float* D = malloc(sizeof(float) * k); int64_t* I = malloc(sizeof(int64_t) * k);
+    for (int i = 0; i < 200; ++i) search(ix, q, 1, k, 1u, D, I);
+    double lone[2000];
+    for (int i = 0; i < 2000; ++i) { const double t0 = now_us(); search(ix, q, 1, k, 1u, D, I); lone[i] = now_us() - t0; }
+    qsort(lone, 2000, sizeof(double), cmp);
+    printf("open loop N=%lld d=%d k=%d: lone caller (closed loop) p50 %.1f us, p99 %.1f us\n", (long long)n, d, k, lone[1000], lone[1980]);
+    free(D); free(I);
+    const double lambdas[5] = {5e3, 10e3, 20e3, 40e3, 80e3};
+    for (int li = 0; li < 5; ++li) {
+        for (int gather = 1; gather >= 0; --gather) {
+            option(ix, 20, gather ? 2 : 0);
+            pthread_t th[T];
+            struct ojob jobs[T];
+            const double t0 = now_us() + 2000.0, stop = t0 + secs * 1e6;
+            for (int t = 0; t < T; ++t) {
+                jobs[t] = (struct ojob){ix, q + (size_t)t * d, d, k, t0, stop, lambdas[li] / T * 1e-6, 0x9E3779B97F4A7C15ull * (t + 1) + li, 0,
+                                        malloc(sizeof(double) * 400000), 400000};
+                pthread_create(&th[t], NULL, open_worker, &jobs[t]);
+            }
+            long total = 0;
+            for (int t = 0; t < T; ++t) { pthread_join(th[t], NULL); total += jobs[t].calls; }
+            const double dt = now_us() - t0;
+            double* all = malloc(sizeof(double) * (size_t)(total + 1));
+            long m = 0;
+            for (int t = 0; t < T; ++t) { for (long i = 0; i < jobs[t].calls && i < jobs[t].cap; ++i) all[m++] = jobs[t].lat[i]; free(jobs[t].lat); }
+            qsort(all, m, sizeof(double), cmp);
+            printf("open loop N=%lld d=%d k=%d lambda %6.0f/s gather %s: achieved %7.0f q/s, p50 %6.1f us, p99 %6.1f us, p99.9 %7.1f us, max %8.1f us (from arrival)",
+                   (long long)n, d, k, lambdas[li], gather ? "on " : "off", total / (dt * 1e-6), m ? all[m / 2] : 0.0, m ? all[(long)(m * 0.99)] : 0.0,
+                   m ? all[(long)(m * 0.999)] : 0.0, m ? all[m - 1] : 0.0);
+            if (g_counter) printf("  [2 ms poll timeouts so far %lld, retries %lld]", (long long)g_counter(ix, 27), (long long)g_counter(ix, 20));
+            printf("\n");
+            fflush(stdout);
+            free(all);
+        }
+    }
+    option(ix, 20, 2);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     void* lib = dlopen(argc > 1 ? argv[1] : "lean-explore_amd/libleansearch.so", RTLD_NOW);
     if (!lib) { printf("dlopen: %s\n", dlerror()); return 1; }
@@ -47,19 +116,29 @@ int main(int argc, char** argv) {
     void (*destroy)(ls_index*) = dlsym(lib, "ls_destroy");
     int (*option)(ls_index*, int32_t, int32_t) = dlsym(lib, "ls_debug_option");
     const char* (*lasterr)(void) = dlsym(lib, "ls_last_error");
-    const int overlap = argc > 2 ? atoi(argv[2]) : 1;  /* debug option 17: synchronous calls overlap two deep */
-    const int gather = argc > 3 ? atoi(argv[3]) : -1;  /* debug option 20: 0 off, 1 long passes only, 2 always (default) */
+    int64_t (*counter)(ls_index*, int32_t) = dlsym(lib, "ls_debug_counter");
+    g_counter = counter;
+    const int open_mode = argc > 2 && !strcmp(argv[2], "open");
+    const double open_secs = argc > 3 && open_mode ? atof(argv[3]) : 2.0;
+    const int overlap = argc > 2 && !open_mode ? atoi(argv[2]) : 1;  /* debug option 17: synchronous calls overlap two deep */
+    const int gather = argc > 3 && !open_mode ? atoi(argv[3]) : -1;  /* debug option 20: 0 off, 1 long passes only, 2 always (default) */
     const int shapes[2][3] = {{200000, 384, 50}, {200000, 1024, 1000}};
     for (int c = 0; c < 2; ++c) {
         const int64_t n = shapes[c][0];
         const int d = shapes[c][1], k = shapes[c][2];
         float* corpus = malloc(sizeof(float) * n * d);
-        float* q = malloc(sizeof(float) * 16 * d);
+        float* q = malloc(sizeof(float) * 32 * d);
         uint64_t s = 1234;
         for (int64_t i = 0; i < n * d; ++i) corpus[i] = gauss(&s);
-        for (int i = 0; i < 16 * d; ++i) q[i] = gauss(&s);
+        for (int i = 0; i < 32 * d; ++i) q[i] = gauss(&s);
         ls_index* ix = NULL;
         if (create(&ix, corpus, n, d, 0, 0)) { printf("ls_create: %s\n", lasterr()); return 1; }
+        if (open_mode) {
+            open_loop(ix, option, q, n, d, k, open_secs);
+            destroy(ix);
+            free(corpus); free(q);
+            continue;
+        }
         option(ix, 17, overlap);
         if (gather >= 0) option(ix, 20, gather);
         if (argc > 5) option(ix, 21, atoi(argv[5]));  /* debug option 21: callers up to which a second batch goes early */
@@ -68,12 +147,12 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 50; ++i) search(ix, q, 1, k, 1u, D, I);
             free(D); free(I);
         }
-        const int Ts[5] = {1, 2, 4, 8, 16};
-        for (int ti = 0; ti < 5; ++ti) {
+        const int Ts[6] = {1, 2, 4, 8, 16, 32};  /* (32: one two-block ls_mq pass carries them all, round 6) */
+        for (int ti = 0; ti < 6; ++ti) {
             const int T = Ts[ti];
             for (int rep = 0; rep < (argc > 4 ? atoi(argv[4]) : 2); ++rep) {
-                pthread_t th[16];
-                struct job jobs[16];
+                pthread_t th[32];
+                struct job jobs[32];
                 const double t0 = now_us(), stop = t0 + 0.8e6;
                 for (int t = 0; t < T; ++t) {
                     jobs[t] = (struct job){ix, q + (size_t)t * d, d, k, stop, 0, malloc(sizeof(double) * 100000), 100000};
@@ -86,7 +165,11 @@ int main(int argc, char** argv) {
                 long m = 0;
                 for (int t = 0; t < T; ++t) { for (long i = 0; i < jobs[t].calls && i < jobs[t].cap; ++i) all[m++] = jobs[t].lat[i]; free(jobs[t].lat); }
                 qsort(all, m, sizeof(double), cmp);
-                printf("C threads%s N=%lld d=%d k=%d, %2d callers: %8.0f q/s, p50 %.1f us\n", overlap ? "" : " (no overlap)", (long long)n, d, k, T, total / (dt * 1e-6), m ? all[m / 2] : 0.0);
+                printf("C threads%s N=%lld d=%d k=%d, %2d callers: %8.0f q/s, p50 %.1f us", overlap ? "" : " (no overlap)", (long long)n, d, k, T, total / (dt * 1e-6), m ? all[m / 2] : 0.0);
+                if (getenv("CALLERS_COUNTERS"))  /* cumulative: combined batches, their requests, launches, ls_mq launches, retries, second serves */
+                    printf("   [batches %lld requests %lld launches %lld mq %lld retries %lld reserved %lld]", (long long)counter(ix, 16), (long long)counter(ix, 17),
+                           (long long)counter(ix, 11), (long long)counter(ix, 23), (long long)counter(ix, 20), (long long)counter(ix, 25));
+                printf("\n");
                 fflush(stdout);
                 free(all);
             }

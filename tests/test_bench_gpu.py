@@ -154,3 +154,21 @@ def test_default_line_carries_both_metric_halves_and_host_api():
     summ = out["_summary"]
     assert summ["host_api"]["c2"]["scan_kernel_us"] > 0 and summ["bm25"]["bit_exact_vs_oracle"] is True
     assert summ["host_api"]["c2"]["us_per_call_p50"] > summ["host_api"]["c2"]["scan_kernel_us"]
+
+
+def test_scale_day_script_rehearsal():
+    """tools/scale_day.sh (verdict r5 item 7): the one script for the first N-GPU node - bit-equality of sharded
+    results with one index in both process models, bench.py at G = 1, 2 for c2 and c4, the exchange record and
+    the table - rehearsed with two shards sharing this box's GPU and reduced sizes."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"SCALE_SHARE": "1", "SCALE_C4_ROWS": "100000", "SCALE_STEPS_C2": "48", "SCALE_STEPS_C4": "3",
+                "SCALE_CHECK_ROWS": "20000", "SCALE_CHECK_C2_ROWS": "40000"})
+    p = subprocess.run(["bash", str(ROOT / "tools" / "scale_day.sh"), "2"], env=env, timeout=1500, capture_output=True, text=True)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-2000:])
+    assert "scale_check inlib: OK" in p.stdout and "scale_check dist: OK" in p.stdout and "scale_day: OK" in p.stdout
+    assert "bit-identical to one index" in p.stdout and "DIFFERS" not in p.stdout
+    rows = [ln for ln in p.stdout.splitlines() if ln.startswith("| inlib |") or ln.startswith("| dist |")]
+    assert len(rows) == 8, rows  # 2 models x 2 workloads x G = 1, 2
+    assert "exchange:" in p.stdout

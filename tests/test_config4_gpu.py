@@ -16,6 +16,7 @@ from lean_explore_amd.index import FlatIPIndex
 pytestmark = pytest.mark.gpu
 
 ROWS, D, NQ, K = 12_500_000, 768, 256, 100
+C4_RANK_DIFFS = 2  # measured on the round-6 library for seeds 1234 / 5678: 2 of 1600 ranks (all 1600 rows shared)
 
 
 def _torch_reference(shard, tq, base, nv):
@@ -57,6 +58,11 @@ def test_config4_full_shard():
     assert np.allclose(S[:16], rs, rtol=0, atol=2e-5)
     hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(I[:16], ri))
     assert hits >= 16 * K - 2, hits  # a near-tie at the k-th place may legitimately differ
+    # (round 6: what holds today for these seeds is asserted - the same ROW SETS, and how many of the 1600 ranks
+    # hold another row than the torch reference's, near ties swapped by the summation order)
+    rank_diffs = int((I[:16] != ri).sum())
+    print("config4 full shard: rows shared", hits, "of", 16 * K, "; ranks that differ", rank_diffs, "; repaired", repaired)
+    assert hits == 16 * K and rank_diffs <= C4_RANK_DIFFS, (hits, rank_diffs)
     # (2) structure: sorted by (score desc, row asc), rows inside the shard's global range
     assert np.all(S[:, :-1] >= S[:, 1:]) and I.min() >= base and I.max() < base + ROWS
     assert repaired <= 2, repaired  # exchangeable rows: a repair is a ~1e-5 event per query

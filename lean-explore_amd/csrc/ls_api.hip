@@ -1705,6 +1705,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
     std::unique_lock<std::mutex> lk(ix->q_mu, std::defer_lock);
     q_lock(lk);
     ix->req_q.push_back(&me);
+    ix->q_len.store((int64_t)ix->req_q.size(), std::memory_order_release);
     ix->q_epoch.fetch_add(1, std::memory_order_release);  // (a leader waiting to form its batch counts the arrivals)
     {   // running estimate of the time between two arrivals (what the gather below asks before it waits)
         const auto now = std::chrono::steady_clock::now();
@@ -1771,18 +1772,23 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
                    (total <= 2 || (total >= ix->peak_callers && total <= ix->opt_early_cap));
         };
         while (ix->calls_in_flight > 0 && !go_early()) {
-            const uint64_t seen = ix->q_epoch.load(std::memory_order_acquire);  // (as above: poll, then sleep)
+            // (what may end this wait: the call in flight hands its results back - lead_epoch - or, while few enough
+            // callers are around for a second batch to go early, an arrival - q_epoch. With more callers than that
+            // an arrival changes nothing, and a leader that re-took the mutex on each of 30 arrivals stood in their way)
+            const bool arrivals_matter = ix->peak_callers <= ix->opt_early_cap;
+            std::atomic<uint64_t>& ep = arrivals_matter ? ix->q_epoch : ix->lead_epoch;
+            const uint64_t seen = ep.load(std::memory_order_acquire);  // (as above: poll, then sleep)
             const double spin_us = std::min(LS_WAITER_SPIN_MAX_US, std::max(LS_WAITER_SPIN_MIN_US, 2.0 * ix->call_us_est));
             lk.unlock();
             bool changed = false;
             const auto t0 = std::chrono::steady_clock::now();
             for (unsigned it = 0; !changed; ++it) {
                 for (int i = 0; i < 32; ++i) ls_cpu_relax();
-                changed = ix->q_epoch.load(std::memory_order_acquire) != seen;
+                changed = ep.load(std::memory_order_acquire) != seen;
                 if ((it & 15) == 15 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
             }
             q_lock(lk);
-            if (!changed && ix->calls_in_flight > 0 && ix->q_epoch.load(std::memory_order_acquire) == seen)
+            if (!changed && ix->calls_in_flight > 0 && ep.load(std::memory_order_acquire) == seen)
                 ix->q_cv.wait(lk);
         }
         // Gather (round 5; first for long passes only, then for all - 2 / 4 / 8 callers at d = 384: 23.7 / 40.0 /
@@ -1800,12 +1806,13 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             ix->arrival_gap_us < 3.5 * budget_us) {
             const auto t0 = std::chrono::steady_clock::now();
             while ((int64_t)ix->req_q.size() < ix->peak_callers) {
-                const uint64_t seen = ix->q_epoch.load(std::memory_order_acquire);
+                // (the queue's length is read through an atomic the arrivals maintain: the leader stays out of their
+                // way and takes the mutex ONCE, when everyone is there or the window is over)
+                const int64_t want = ix->peak_callers;
                 lk.unlock();
-                bool changed = false, late = false;
-                for (unsigned it = 0; !changed && !late; ++it) {
+                bool late = false;
+                for (unsigned it = 0; !late && ix->q_len.load(std::memory_order_acquire) < want; ++it) {
                     for (int i = 0; i < 16; ++i) ls_cpu_relax();
-                    changed = ix->q_epoch.load(std::memory_order_acquire) != seen;
                     if ((it & 7) == 7)
                         late = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > budget_us;
                 }
@@ -1832,6 +1839,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             total += r->nq;
             ix->req_q.pop_front();
         }
+        ix->q_len.store((int64_t)ix->req_q.size(), std::memory_order_release);
         lk.unlock();
         const auto t_call = std::chrono::steady_clock::now();
         serve_begin(ix, sv);

@@ -68,6 +68,7 @@ struct ls_index {
     std::deque<ls_req*> req_q;
     bool leader_active = false;
     std::atomic<uint64_t> q_epoch{0};  // bumped whenever the queue's state changes (arrivals too: the gathering leader counts them)
+    std::atomic<int64_t> q_len{0};     // req_q.size(), readable without q_mu (the gathering leader polls it)
     std::atomic<uint64_t> lead_epoch{0};  // bumped when the leadership or a host slot comes free: what a QUEUED waiter polls
     int32_t calls_in_flight = 0;       // batches queued whose results have not been handed back yet (under q_mu)
     int64_t requests_in_flight = 0;    // ... and the requests in them

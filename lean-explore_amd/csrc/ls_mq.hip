@@ -153,8 +153,9 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 1) void ls_mq_kernel(
     const int li = lane & 15, kq = lane >> 4;
 
     float* Bs = reinterpret_cast<float*>(smem_dyn);   // [NQT queries][DP]
-    u64* Ks = reinterpret_cast<u64*>(smem_dyn);       // [NQT queries][WPB waves][M], then the bounds: over the queries,
-                                                      // once every wave is through its tiles
+    // [NQT queries][WPB waves][M] key lists, then the bounds. Two blocks: over the queries, once every wave is through
+    // its tiles (131 KB of queries at d = 1024 leave no room beside them); one block: behind them (no barrier needed)
+    u64* Ks = reinterpret_cast<u64*>(smem_dyn + (NB == 1 ? ((size_t)NQT * DP * 4 + 15) / 16 * 16 : 0));
 
     // Tiles of 16 rows are dealt round-robin to the waves of the launch (adjacent tiles go to different
     // workgroups): a run of adjacent, similar rows spreads over many workgroups.
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 1) void ls_mq_kernel(
     };
     constexpr int TK = WPB * M;          // keys per query (k' + 1 <= TK)
     u64* Kb = Ks + NQT * TK;             // [NQT queries][WPB waves] bounds
-    __syncthreads();                     // (the key lists overwrite the queries: every wave is through its tiles)
+    if (NB == 2) __syncthreads();        // (the key lists overwrite the queries: every wave is through its tiles)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         u64 bnd = lst[b][M - 1];
@@ -566,7 +567,8 @@ int ls_mq_lane_keys(int blocks, int keff, int nq) {
 // LDS of a scan workgroup: the queries, later overwritten by the waves' key lists + bounds
 static size_t mq_lds_bytes(int chunks, int lane_keys, int nb, int wpb) {
     const size_t nqt = (size_t)nb * LS_MQ_NQ;
-    return std::max(nqt * mq_pitch(chunks) * sizeof(float), nqt * wpb * (lane_keys + 1) * sizeof(u64));
+    const size_t qb = (nqt * mq_pitch(chunks) * sizeof(float) + 15) / 16 * 16, kb = nqt * wpb * (lane_keys + 1) * sizeof(u64);
+    return nb == 1 ? qb + kb : std::max(qb, kb);
 }
 
 template <int L, int V, int M, int NB>

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence behind bench.py's roofline blocks. Run on the GPU box:
-#   gpurun -- 'bash profiles/collect.sh c2 r02'        (workloads: c2 c2m c2p c3 c4 bm25)
+#   gpurun -- 'bash profiles/collect.sh c2 r02'        (workloads: c2 c2m c2p c2x8 c2px8 c2x32 c3 c4 bm25)
 # Raw CSVs go under /tmp/prof_<tag>_<workload>/ (tens of MB: they stay on the box);
 # profiles/summarize.py condenses them into the small files that are committed under profiles/
 # (written to gpurun_out/profiles/, which gpurun copies back).

@@ -29,7 +29,7 @@ dst.mkdir(parents=True, exist_ok=True)
 
 DOMINANT = {  # substring(s) that must ALL appear in the kernel name
     "c3": ("ls_gemm_filter_kernel", ", 0>("), "c4": ("ls_gemm_filter_kernel", ", 0>("),
-    "bm25": ("bm25_score_kernel",), "c2x8": ("ls_mq_kernel",), "c2px8": ("ls_mq_kernel",),
+    "bm25": ("bm25_score_kernel",), "c2x8": ("ls_mq_kernel",), "c2px8": ("ls_mq_kernel",), "c2x32": ("ls_mq_kernel",),
 }
 need = DOMINANT.get(wl, ("ls_scan_kernel",))
 
@@ -132,5 +132,7 @@ if sq:
         out["mfma_busy_frac"] = round(sq["SQ_VALU_MFMA_BUSY_CYCLES"] /
                                       (sq["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
         out["mfma_busy_formula"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)"
+if sq.get("SQ_INSTS_LDS"):
+    out["lds_bank_conflict_cycles_per_lds_instruction"] = round(sq.get("SQ_LDS_BANK_CONFLICT", 0) / sq["SQ_INSTS_LDS"], 4)
 (dst / f"pmc_{wl}.json").write_text(json.dumps(out, indent=1) + "\n")
 print(json.dumps(out))

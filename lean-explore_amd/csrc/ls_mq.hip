@@ -250,11 +250,19 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 1) void ls_mq_kernel(
     __syncthreads();
 
     LS_MQSTAMP(1);
-    u64 lst[NB][M];  // this lane's best keys (queries li, 16 + li; rows 4kq.. of the wave's tiles), descending
+    // this lane's best rows (queries li, 16 + li; rows 4kq.. of the wave's tiles), best first - as (score, row) pairs
+    // while the tiles stream (round 6): a lane meets its rows in increasing order, so "key greater" is "score
+    // greater" (an equal score loses to the earlier row) and NaN / <= -FLT_MAX scores never pass `s > -FLT_MAX`:
+    // one 32-bit compare and four selects per list step, no key built per row. The 64-bit keys are made once, below.
+    float bs[NB][M];
+    u32 br[NB][M];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int i = 0; i < M; ++i) lst[b][i] = 0ull;
+        for (int i = 0; i < M; ++i) {
+            bs[b][i] = -FLT_MAX;
+            br[b][i] = 0u;
+        }
 
     while (t < NT) {
         const mq_f32x4* pcur = tile_ptr(t);
@@ -372,16 +380,21 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 1) void ls_mq_kernel(
                         if (row0 + r < n) sp[r] = sc[b][r];
                 }
             }
+            // (unused query columns keep lists of whatever their zero columns score: dropped when the keys are made)
+            const bool ragged = t * 16 + 16 > n;  // (wave-uniform: only the launch's last tile holds rows >= n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float s = sc[b][r];
-                u64 x = (live_q && row0 + r < n) ? ls_make_key(s, (u32)(row0 + r)) : 0ull;
+                float xs = (ragged && row0 + r >= n) ? -FLT_MAX : sc[b][r];
+                u32 xr = (u32)(row0 + r);
 #pragma unroll
-                for (int i = 0; i < M; ++i) {  // branch-free insert: the larger key stays, the smaller moves on
-                    const bool gt = x > lst[b][i];
-                    const u64 hi = gt ? x : lst[b][i];
-                    x = gt ? lst[b][i] : x;
-                    lst[b][i] = hi;
+                for (int i = 0; i < M; ++i) {  // branch-free insert: the better row stays, the other moves on
+                    const bool gt = xs > bs[b][i];
+                    const float hs = gt ? xs : bs[b][i];
+                    const u32 hr = gt ? xr : br[b][i];
+                    xs = gt ? bs[b][i] : xs;
+                    xr = gt ? br[b][i] : xr;
+                    bs[b][i] = hs;
+                    br[b][i] = hr;
                 }
             }
         }
@@ -412,6 +425,13 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 1) void ls_mq_kernel(
     constexpr int TK = WPB * M;          // keys per query (k' + 1 <= TK)
     u64* Kb = Ks + NQT * TK;             // [NQT queries][WPB waves] bounds
     if (NB == 2) __syncthreads();        // (the key lists overwrite the queries: every wave is through its tiles)
+    u64 lst[NB][M];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const bool live_q = LS_MQ_NQ * b + li < nq;
+#pragma unroll
+        for (int i = 0; i < M; ++i) lst[b][i] = live_q ? ls_make_key(bs[b][i], br[b][i]) : 0ull;  // (-FLT_MAX -> 0: no row)
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         u64 bnd = lst[b][M - 1];

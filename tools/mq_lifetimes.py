@@ -12,6 +12,7 @@ from tests import helpers as H  # noqa: E402
 
 n, d = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (200_000, 384)
 ix = FlatIPIndex.from_array(H.gauss(1234, n, d))
+ix.debug_option(19, 0)  # keep the score vectors: the lifetimes are parked in score vector 7 (S must exist)
 for i in range(20):
     ix.search(H.gauss(100 + i, 4, d), 50)
 for rep in range(2):

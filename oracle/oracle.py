@@ -114,10 +114,12 @@ def c_round_f16(x: np.ndarray) -> np.ndarray:
 #             (1e-5, BASELINE.json) and what compare_topk's near-tie excuse refers to;
 #   "scan"  : the fp32 scan kernels' own order (per-lane fmaf chains over chunks sub, sub+L, .. then the
 #             xor tree; csrc/ls_scan.hip, and the f32 MFMA small-batch kernel csrc/ls_mq.hip reproduces
-#             it) - every fp32 search of nq < LS_GEMM32_MIN_NQ queries must match it BIT FOR BIT;
+#             it) - every fp32 search of nq < LS_GEMM32_MIN_NQ queries must match it BIT FOR BIT (round 6: and
+#             every search of up to 32 queries where ls_mq serves the index - one exact pass of two B blocks);
 #   "fma"   : one sequential fmaf chain in increasing k (csrc/ls_gemm32.hip's v_mfma_f32_16x16x4_f32,
-#             measured bit-identical to that chain by tools/arith_probe.hip) - fp32 batches of
-#             >= LS_GEMM32_MIN_NQ queries (a query repaired through the scan path follows "scan").
+#             measured bit-identical to that chain by tools/arith_probe.hip) - fp32 batches of more than 32
+#             queries, or of >= LS_GEMM32_MIN_NQ where ls_mq does not serve the (index, k) (a query repaired
+#             through the scan path follows "scan"). For 24..32 queries compare_kernel_order admits both.
 ORDERS = {"strict": 0, "scan": 1, "fma": 2}
 SCAN_PATH_MAX_NQ_F32 = 23  # LS_GEMM32_MIN_NQ - 1 (csrc/ls_common.h)
 

@@ -173,3 +173,46 @@ def test_callers_of_long_passes_are_gathered_and_stay_exact():
     batches, reqs = ix.debug_counter(16) - b0, ix.debug_counter(17) - r0
     assert reqs >= 180 and reqs / batches > 2.5, (batches, reqs)  # (combined batches only) mostly passes of 3-4 callers
     ix.close()
+
+
+def test_more_than_sixteen_callers_share_wide_passes_and_stay_exact():
+    """Round 6: one ls_mq pass carries up to 32 queries (two MFMA B blocks), so 28 concurrent single-query callers -
+    some bringing three queries - are served in passes of 17..32. Every caller must get exactly what its own
+    separate call returns, bit for bit, whatever company it rode in (reference: index.search from several MCP
+    clients, search/engine.py:250, mcp/server.py:147-151)."""
+    n, d, T, per = 100_000, 384, 28, 25
+    corpus = H.gauss(91, n, d)
+    pool = H.gauss(92, 96, d, normalize=False)
+    ix = FlatIPIndex.from_array(corpus)
+    try:
+        ix.search(pool[:1], 10)
+        ix.debug_option(10, 0)  # separate calls
+        want = {(qi, k): ix.search(pool[qi:qi + 1], k, normalize=True) for qi in range(96) for k in (50, 300)}
+        ix.debug_option(10, 1)
+        before_mq, before_launches = ix.debug_counter(23), ix.debug_counter(11)
+        errors, sizes = [], []
+
+        def worker(t):
+            rng = np.random.default_rng(1000 + t)
+            for j in range(per):
+                qi = int(rng.integers(94))
+                k = 300 if rng.integers(8) == 0 else 50
+                m = 3 if j % 9 == 4 else 1
+                D, I = ix.search(pool[qi:qi + m], k, normalize=True)
+                for r in range(m):
+                    Dw, Iw = want[(qi + r, k)]
+                    if not (np.array_equal(D[r], Dw[0]) and np.array_equal(I[r], Iw[0])):
+                        errors.append((t, j, qi + r, k))
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors[:5]
+        batches, requests = ix.debug_counter(16), ix.debug_counter(17)
+        assert batches >= 1 and requests > 2 * batches, (batches, requests)
+        print("28 callers:", requests, "requests in", batches, "combined batches;", ix.debug_counter(23) - before_mq, "ls_mq launches of",
+              ix.debug_counter(11) - before_launches)
+    finally:
+        ix.close()

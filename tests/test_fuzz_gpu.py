@@ -27,14 +27,14 @@ def _case(rng):
     n = int(rng.integers(40_000, 260_000)) if big else int(rng.integers(1, 6000))
     if rng.random() < 0.2:
         n = int(rng.integers(7_000, 40_000))  # small shards of the batched path
-    nq = int(rng.choice([1, 1, 2, 3, 5, 8, 9, 17, 33, 130, 300, 520]))
+    nq = int(rng.choice([1, 1, 2, 3, 5, 8, 9, 17, 24, 32, 33, 130, 300, 520]))  # (17..32 on fp32: one two-block ls_mq pass)
     k = int(rng.choice([1, 2, 7, 50, 100, 128, 129, 500, 1000, 2048]))
     while n * d * nq > 6e9:  # keep the STRICT (scalar, left-to-right) CPU oracle in seconds
         nq = max(1, nq // 2)
     return kind, dtype, n, d, nq, k, bool(rng.random() < 0.3)
 
 
-@pytest.mark.parametrize("default_seed", [20260928, 1])  # seed 1 caught a counted-vmcnt race in round 2
+@pytest.mark.parametrize("default_seed", [20260928, 1, 6, 606])  # seed 1 caught a counted-vmcnt race in round 2 (round 6: four seeds)
 def test_random_parity_sweep(default_seed):
     budget = float(os.environ.get("LS_FUZZ_SECONDS", "30"))
     rng = np.random.default_rng(int(os.environ.get("LS_FUZZ_SEED", str(default_seed))))

@@ -1744,6 +1744,7 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         }
         // lead ONE batch: queue its launch, pass the leadership on, then wait for its results
         ix->leader_active = true;
+        const auto t_lead = std::chrono::steady_clock::now();  // (phase clocks of the leader: debug counters 28-30)
         // A call is still in flight. Two callers taking turns (one request in flight, one waiting): queue
         // the waiting one's launch NOW, behind the running one - the GPU then goes from scan to scan instead
         // of idling from one call's last result to the next call's launch (2 callers: 15.5 k -> 18 k
@@ -1826,6 +1827,8 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
                 }
             }
         }
+        const auto t_formed = std::chrono::steady_clock::now();
+        ix->n_lead_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_formed - t_lead).count();
         ls_served sv;
         ls_req* head = ix->req_q.front();
         int64_t total = 0;
@@ -1857,7 +1860,10 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         ix->q_cv.notify_all();  // a waiter whose request is still queued leads the next batch
         lk.unlock();
         serve_finish(ix, sv);
+        const auto t_served = std::chrono::steady_clock::now();
         q_lock(lk);
+        ix->n_lead_call_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_served - t_call).count();
+        ix->n_lead_relock_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_served).count();
         {
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
             ix->call_us_est = ix->call_us_est <= 0.0 ? us : ix->call_us_est + (us - ix->call_us_est) / 8.0;
@@ -2277,10 +2283,14 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 27) return -1;
+    if (!ix || which < 0 || which > 30) return -1;
     if (which == 16 || which == 17) {
         std::lock_guard<std::mutex> ql(ix->q_mu);
         return (int64_t)(which == 16 ? ix->n_combined_batches : ix->n_combined_requests);
+    }
+    if (which >= 28 && which <= 30) {  // the leaders' phase clocks, cumulative ns: waiting + gathering | begin..finish | re-taking the queue's mutex
+        std::lock_guard<std::mutex> ql(ix->q_mu);
+        return (int64_t)(which == 28 ? ix->n_lead_wait_ns : which == 29 ? ix->n_lead_call_ns : ix->n_lead_relock_ns);
     }
     std::lock_guard<std::mutex> lk(ix->mu);
     if (ix->group) return ls_group_debug_counter(ix, which);

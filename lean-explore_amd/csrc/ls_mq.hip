@@ -109,6 +109,7 @@ __device__ __forceinline__ void mq_transpose(const mq_f32x4& x, float (&r)[4]) {
 // SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS = 0.019 (round 5's [chunk][k][query] layout: 0.24, all of it staging
 // writes; a pitch of 4 (mod 64) - right for 64 banks - measured 3.8: half of all LDS cycles).
 __host__ __device__ constexpr int mq_pitch(int chunks) { return chunks * 4 + 2; }
+__host__ __device__ constexpr int mq_key_pitch(int tk) { return (tk + 14) / 16 * 16 + 1; }  // u64 between two queries' key lists
 
 // NB = MFMA B blocks (16 query columns each) per A operand: 1 serves 2..16 queries, 2 serves 17..32.
 // WPB = waves per workgroup (4, 8 with two blocks).
@@ -423,7 +424,10 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 1) void ls_mq_kernel(
         return ((u64)xor_lanes32((u32)(v >> 32), mask) << 32) | xor_lanes32((u32)v, mask);
     };
     constexpr int TK = WPB * M;          // keys per query (k' + 1 <= TK)
-    u64* Kb = Ks + NQT * TK;             // [NQT queries][WPB waves] bounds
+    // (a query's keys / bounds start TKP / WPB + 1 u64 apart - 2 (mod 32) dwords: the 16 lanes that write one key slot of
+    // 16 queries at once fall on 32 different banks; with the plain pitch of 32 u64 at M = 8 they all shared one pair)
+    constexpr int TKP = mq_key_pitch(TK);
+    u64* Kb = Ks + NQT * TKP;            // [NQT queries][WPB waves] bounds
     if (NB == 2) __syncthreads();        // (the key lists overwrite the queries: every wave is through its tiles)
     u64 lst[NB][M];
 #pragma unroll
@@ -462,8 +466,8 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 1) void ls_mq_kernel(
         if (kq == 0) {
             const int qc = LS_MQ_NQ * b + li;
 #pragma unroll
-            for (int i = 0; i < M; ++i) Ks[qc * TK + wave * M + i] = lst[b][i];
-            Kb[qc * WPB + wave] = bnd;
+            for (int i = 0; i < M; ++i) Ks[qc * TKP + wave * M + i] = lst[b][i];
+            Kb[qc * (WPB + 1) + wave] = bnd;
         }
     }
     __syncthreads();
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 1) void ls_mq_kernel(
         constexpr int TPQ = 64 * WPB / NQT;           // threads per query (16)
         constexpr int SPT = (TK + TPQ - 1) / TPQ;     // keys per thread (M = 3 / 5 / 8: 12 / 20 / 32 keys)
         const int qi = threadIdx.x / TPQ, slot = threadIdx.x % TPQ;
-        const u64* kk = Ks + qi * TK;
+        const u64* kk = Ks + qi * TKP;
         u64 mine[SPT];
         int rank[SPT];
 #pragma unroll
@@ -490,9 +494,9 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 1) void ls_mq_kernel(
             for (int c = 0; c < SPT; ++c)
                 rank[c] += (o > mine[c]) || (o == mine[c] && i < slot + TPQ * c);  // ties exist only among the zeros
         }
-        u64 lb = Kb[qi * WPB];
+        u64 lb = Kb[qi * (WPB + 1)];
 #pragma unroll
-        for (int w = 1; w < WPB; ++w) lb = Kb[qi * WPB + w] > lb ? Kb[qi * WPB + w] : lb;
+        for (int w = 1; w < WPB; ++w) lb = Kb[qi * (WPB + 1) + w] > lb ? Kb[qi * (WPB + 1) + w] : lb;
 #pragma unroll
         for (int c = 0; c < SPT; ++c) {
             if (qi >= nq || slot + TPQ * c >= TK) continue;
@@ -587,7 +591,8 @@ int ls_mq_lane_keys(int blocks, int keff, int nq) {
 // LDS of a scan workgroup: the queries, later overwritten by the waves' key lists + bounds
 static size_t mq_lds_bytes(int chunks, int lane_keys, int nb, int wpb) {
     const size_t nqt = (size_t)nb * LS_MQ_NQ;
-    const size_t qb = (nqt * mq_pitch(chunks) * sizeof(float) + 15) / 16 * 16, kb = nqt * wpb * (lane_keys + 1) * sizeof(u64);
+    const size_t qb = (nqt * mq_pitch(chunks) * sizeof(float) + 15) / 16 * 16;
+    const size_t kb = nqt * (mq_key_pitch(wpb * lane_keys) + wpb + 1) * sizeof(u64);
     return nb == 1 ? qb + kb : std::max(qb, kb);
 }
 

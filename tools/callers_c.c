@@ -141,6 +141,7 @@ int main(int argc, char** argv) {
         }
         option(ix, 17, overlap);
         if (gather >= 0) option(ix, 20, gather);
+        if (getenv("CALLERS_OPT22")) option(ix, 22, atoi(getenv("CALLERS_OPT22")));  /* debug option 22: 32 (1, default) or 16 (0) queries per ls_mq pass */
         if (argc > 5) option(ix, 21, atoi(argv[5]));  /* debug option 21: callers up to which a second batch goes early */
         {
             float* D = malloc(sizeof(float) * k); int64_t* I = malloc(sizeof(int64_t) * k);
@@ -167,8 +168,9 @@ int main(int argc, char** argv) {
                 qsort(all, m, sizeof(double), cmp);
                 printf("C threads%s N=%lld d=%d k=%d, %2d callers: %8.0f q/s, p50 %.1f us", overlap ? "" : " (no overlap)", (long long)n, d, k, T, total / (dt * 1e-6), m ? all[m / 2] : 0.0);
                 if (getenv("CALLERS_COUNTERS"))  /* cumulative: combined batches, their requests, launches, ls_mq launches, retries, second serves */
-                    printf("   [batches %lld requests %lld launches %lld mq %lld retries %lld reserved %lld]", (long long)counter(ix, 16), (long long)counter(ix, 17),
-                           (long long)counter(ix, 11), (long long)counter(ix, 23), (long long)counter(ix, 20), (long long)counter(ix, 25));
+                    printf("   [batches %lld requests %lld launches %lld mq %lld retries %lld reserved %lld | leaders, cumulative us: wait+gather %lld, begin..finish %lld, relock %lld]",
+                           (long long)counter(ix, 16), (long long)counter(ix, 17), (long long)counter(ix, 11), (long long)counter(ix, 23), (long long)counter(ix, 20),
+                           (long long)counter(ix, 25), (long long)counter(ix, 28) / 1000, (long long)counter(ix, 29) / 1000, (long long)counter(ix, 30) / 1000);
                 printf("\n");
                 fflush(stdout);
                 free(all);

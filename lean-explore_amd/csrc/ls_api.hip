@@ -14,6 +14,9 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <condition_variable>
+#include <thread>
+#include <sched.h>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -433,6 +436,10 @@ static int64_t scan_group_count(const ls_index* ix, int64_t nq, int32_t k) {
 #ifndef LS_GATHER_DIV
 #define LS_GATHER_DIV 3.0        // ... and the fraction of a call's running estimate it may spend on that
 #endif
+#ifndef LS_GATHER_QUIET_US
+#define LS_GATHER_QUIET_US 6.0   // with >= LS_GATHER_QUIET_MIN callers around, 3/4 of them queued and no arrival for this long: go
+#endif
+#define LS_GATHER_QUIET_MIN 16
 #define LS_MQ_KEEP_SLOTS 256  // ls_mq launches without score vectors between two repairs (device-output calls)
 static int mq_repair(ls_index* ix);
 
@@ -1310,11 +1317,28 @@ struct ls_host_call {
     int gen = -1;  // the scratch generation an overlapped call was given (ls_index::force_gen)
 };
 
+#ifdef LS_LEAD_TRACE  // (variant build: where a leader's begin / finish goes, debug counters 40-47, cumulative ns)
+static std::atomic<uint64_t> g_lead_trace[8];
+struct ls_trace_clock {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(int i) {
+        const auto n = std::chrono::steady_clock::now();
+        g_lead_trace[i].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count(), std::memory_order_relaxed);
+        t = n;
+    }
+};
+#define LS_LAP(c, i) (c).lap(i)
+#else
+struct ls_trace_clock { };
+#define LS_LAP(c, i) ((void)(c))
+#endif
+
 static int host_call_begin_impl(ls_host_call& c) {
     ls_index* ix = c.ix;
     const int64_t nq = c.nq;
     const int32_t k = c.k;
     int rc = LS_OK;
+    ls_trace_clock tc;
     if (ix->group) {  // the group handle has its own host path (ls_shard.hip); nothing to overlap here
         c.group = true;
         c.mu_lk = std::unique_lock<std::mutex>(ix->mu);
@@ -1385,9 +1409,11 @@ static int host_call_begin_impl(ls_host_call& c) {
         LS_HIP(hipHostMalloc((void**)&S.h_done, sizeof(u32) * LS_QUERIES_PER_LAUNCH_MAX, hipHostMallocDefault));
         memset(S.h_done, 0, sizeof(u32) * LS_QUERIES_PER_LAUNCH_MAX);
     }
+    LS_LAP(tc, 4);
     memcpy(S.h_q, c.q, qn * sizeof(float));
     if (!in_direct)
         LS_HIP(hipMemcpyAsync(S.d_qraw, S.h_q, qn * sizeof(float), hipMemcpyHostToDevice, s));
+    LS_LAP(tc, 5);
     S.retry_groups.clear();
     if (c.spin) {
         if (on > S.h_out_g_cap) {
@@ -1412,6 +1438,7 @@ static int host_call_begin_impl(ls_host_call& c) {
     ix->gran_out_base = nullptr;
     ix->cur_retry = nullptr;
     ix->force_gen = -1;
+    LS_LAP(tc, 6);
     if (rc != LS_OK) return c.rc = rc;
     if (!c.out_direct) {
         LS_HIP(hipMemcpyAsync(S.h_out_s, S.d_out_s, on * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1608,11 +1635,45 @@ struct ls_req {
                                        // which lives on its stack, vanish - the moment it sees it, without the queue's mutex
     std::atomic<bool> taken{false};    // popped into a batch some leader is serving (set under q_mu; a waiter polls it)
     char err[256] = "";
+    std::condition_variable cv;        // where THIS request's caller sleeps once it may not (or no longer) spin ...
+    bool parked = false;               // ... (under q_mu) and whether it does: whoever finishes its batch, or hands on the
+                                       // leadership while it heads the queue, wakes it - and nobody else (round 6)
 };
 
 // A queued caller polls the queue's epoch before it sleeps on the condition variable: for about two calls' worth
 // of the handle's running estimate (its answer is that far away at most when it is next in line), 40..300 us -
 // not for a fixed 300 us whatever the call takes (16 callers kept 15 cores spinning)
+// ... and only as many waiters poll at all as the process has CPUs for (round 6: the GPU box's container has a
+// 16-CPU cgroup quota; 32 callers spinning were throttled for half of every period - cpu.stat nr_throttled - and ran at
+// 80 k q/s where 16 ran at 120-160 k; 16 UNRELATED busy threads next to 16 callers halved them the same way). The
+// CPUs: the affinity mask, capped by the cgroup's quota (v2 cpu.max, v1 cpu.cfs_quota_us), or LS_SPIN_CPUS; one is
+// the leader's, two stay free for the callers' own work, the rest may spin; everyone else sleeps on his request's
+// condition variable at once.
+static int ls_spin_cap() {
+    static const int cap = [] {
+        long cpus = (long)std::thread::hardware_concurrency();
+        cpu_set_t cs;
+        if (sched_getaffinity(0, sizeof(cs), &cs) == 0 && CPU_COUNT(&cs) > 0) cpus = CPU_COUNT(&cs);
+        long quota = -1, period = 0;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char qs[32] = "";
+            if (fscanf(f, "%31s %ld", qs, &period) == 2 && strcmp(qs, "max") != 0) quota = atol(qs);
+            fclose(f);
+        } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(f1, "%ld", &quota) != 1) quota = -1;
+            fclose(f1);
+            if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(f2, "%ld", &period) != 1) period = 0;
+                fclose(f2);
+            }
+        }
+        if (quota > 0 && period > 0) cpus = std::min(cpus, (quota + period - 1) / period);
+        if (const char* e = getenv("LS_SPIN_CPUS")) cpus = atol(e);
+        return (int)std::max<long>(1, cpus - 3);  // (measured on the 16-CPU box, 16 / 32 callers, k q/s: 15 pollers 138 / 119 - throttled -,
+                                                  // 13: 138 / 135, 11: 120 / 133, 8: 125 / 129, 4: 130 / 123)
+    }();
+    return cap;
+}
 #define LS_WAITER_SPIN_MIN_US 40.0
 #define LS_WAITER_SPIN_MAX_US 300.0
 struct ls_served {  // one batch between its begin and its finish
@@ -1634,6 +1695,7 @@ static void serve_begin(ls_index* ix, ls_served& sv) {
         return;
     }
     sv.combined = true;
+    ls_trace_clock tc;
     int64_t total = 0;
     for (ls_req* r : batch) total += r->nq;
     c.nq = total;
@@ -1652,12 +1714,16 @@ static void serve_begin(ls_index* ix, ls_served& sv) {
     ts.resize((size_t)total * c.k);
     ti.resize((size_t)total * c.k);
     c.q = tq.data(); c.out_scores = ts.data(); c.out_indices = ti.data();
+    LS_LAP(tc, 0);
     host_call_begin(c);  // (copies the queries into the slot's pinned buffer before it returns)
+    LS_LAP(tc, 1);
 }
 
 static void serve_finish(ls_index* ix, ls_served& sv) {
     ls_host_call& c = sv.call;
+    ls_trace_clock tc;
     const int rc = host_call_finish(c);
+    LS_LAP(tc, 2);
     const int32_t k = c.k;
     int64_t at = 0;
     for (ls_req* r : sv.batch) {
@@ -1669,6 +1735,7 @@ static void serve_finish(ls_index* ix, ls_served& sv) {
         }
         at += r->nq;
     }
+    LS_LAP(tc, 3);
     if (sv.combined) {
         std::lock_guard<std::mutex> ql(ix->q_mu);
         ix->n_combined_batches++;
@@ -1724,8 +1791,9 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             const double spin_us = std::min(LS_WAITER_SPIN_MAX_US, std::max(LS_WAITER_SPIN_MIN_US, 2.0 * ix->call_us_est));
             lk.unlock();
             bool changed = false;
+            const bool may_spin = ix->spinners.fetch_add(1, std::memory_order_relaxed) < ls_spin_cap();  // (a CPU to poll on)
             const auto t0 = std::chrono::steady_clock::now();
-            for (unsigned it = 0; !changed; ++it) {
+            for (unsigned it = 0; may_spin && !changed; ++it) {
                 for (int i = 0; i < 32; ++i) ls_cpu_relax();
                 if (me.done.load(std::memory_order_acquire)) {
                     answered = true;
@@ -1735,11 +1803,19 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
                 changed = !me.taken.load(std::memory_order_acquire) && ix->lead_epoch.load(std::memory_order_acquire) != seen;
                 if ((it & 15) == 15 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
             }
+            ix->spinners.fetch_sub(1, std::memory_order_relaxed);
             if (answered) break;  // (nothing of the queue is touched any more: no mutex)
             q_lock(lk);
-            if (!changed && !me.done.load(std::memory_order_acquire) && (ix->leader_active || me.taken.load(std::memory_order_relaxed)) &&
-                ix->lead_epoch.load(std::memory_order_acquire) == seen)
-                ix->q_cv.wait(lk);
+            // Sleep - on the request's own condition variable: its batch's server wakes it when the answer is there, a
+            // leader that hands the leadership on wakes it if it heads the queue; nobody is woken for anything else.
+            // (Checked under the mutex both wakers hold: a taken request sleeps until it is done, a queued one while
+            // somebody leads.)
+            if (!me.done.load(std::memory_order_acquire) && (me.taken.load(std::memory_order_relaxed) || ix->leader_active)) {
+                me.parked = true;
+                ix->n_waiter_parks++;
+                me.cv.wait(lk);
+                me.parked = false;
+            }
             continue;
         }
         // lead ONE batch: queue its launch, pass the leadership on, then wait for its results
@@ -1811,13 +1887,23 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
                 // way and takes the mutex ONCE, when everyone is there or the window is over)
                 const int64_t want = ix->peak_callers;
                 lk.unlock();
-                bool late = false;
-                for (unsigned it = 0; !late && ix->q_len.load(std::memory_order_acquire) < want; ++it) {
+                bool late = false, quiet = false;
+                int64_t len_seen = ix->q_len.load(std::memory_order_acquire);
+                double changed_at = 0.0;
+                for (unsigned it = 0; !late && !quiet && ix->q_len.load(std::memory_order_acquire) < want; ++it) {
                     for (int i = 0; i < 16; ++i) ls_cpu_relax();
-                    if ((it & 7) == 7)
-                        late = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > budget_us;
+                    if ((it & 7) == 7) {
+                        const double now = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                        late = now > budget_us;
+                        // (many callers, some of them asleep - more callers than CPUs: those take tens of us to come back;
+                        // once three quarters are here and the arrivals have stopped, the pass goes without the rest)
+                        const int64_t len = ix->q_len.load(std::memory_order_acquire);
+                        if (len != len_seen) { len_seen = len; changed_at = now; }
+                        quiet = want >= LS_GATHER_QUIET_MIN && len >= want - want / 4 && now - changed_at > LS_GATHER_QUIET_US;
+                    }
                 }
                 q_lock(lk);
+                if (quiet && !late) break;
                 if (late) {
                     // the callers that did not come are gone (or slower than the window): stop waiting for them
                     // quickly - a lone caller after a burst of 16 would otherwise pay the window for ~500 calls
@@ -1846,7 +1932,9 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         lk.unlock();
         const auto t_call = std::chrono::steady_clock::now();
         serve_begin(ix, sv);
+        const auto t_begun = std::chrono::steady_clock::now();
         q_lock(lk);
+        ix->n_lead_begin_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_begun - t_call).count();
         ix->calls_in_flight++;
         ix->requests_in_flight += (int64_t)sv.batch.size();
         {
@@ -1857,12 +1945,16 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         ix->leader_active = false;
         ix->q_epoch.fetch_add(1, std::memory_order_release);
         ix->lead_epoch.fetch_add(1, std::memory_order_release);
-        ix->q_cv.notify_all();  // a waiter whose request is still queued leads the next batch
+        // (a waiter whose request is still queued leads the next batch: the spinning ones see the epoch, a sleeping
+        // head of the queue is woken - it goes whichever batch comes next, so it is the one worth a wake-up)
+        if (!ix->req_q.empty() && ix->req_q.front()->parked) ix->req_q.front()->cv.notify_one();
         lk.unlock();
+        const auto t_fin = std::chrono::steady_clock::now();
         serve_finish(ix, sv);
         const auto t_served = std::chrono::steady_clock::now();
         q_lock(lk);
         ix->n_lead_call_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_served - t_call).count();
+        ix->n_lead_finish_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_served - t_fin).count();
         ix->n_lead_relock_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_served).count();
         {
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count();
@@ -1870,10 +1962,20 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         }
         ix->calls_in_flight--;
         ix->requests_in_flight -= (int64_t)sv.batch.size();
-        for (ls_req* r : sv.batch) r->done.store(true, std::memory_order_release);  // (the last access to *r)
+        for (ls_req* r : sv.batch) {
+            // (a sleeping caller cannot leave cv.wait before this thread lets go of the mutex: its request is still
+            // there to be notified; for a polling one the store is the last access to *r)
+            if (r->parked) {
+                r->done.store(true, std::memory_order_release);
+                r->cv.notify_one();
+            } else {
+                r->done.store(true, std::memory_order_release);
+            }
+        }
         ix->q_epoch.fetch_add(1, std::memory_order_release);
         ix->lead_epoch.fetch_add(1, std::memory_order_release);
-        ix->q_cv.notify_all();
+        ix->q_cv.notify_all();  // (the next batch's leader, if it sleeps waiting for this call's slot: one thread at most)
+        if (!ix->leader_active && !ix->req_q.empty() && ix->req_q.front()->parked) ix->req_q.front()->cv.notify_one();
     }
     if (lk.owns_lock()) lk.unlock();
     if (me.rc != LS_OK && me.err[0]) ls_set_error("%s", me.err);
@@ -2283,14 +2385,23 @@ int64_t ls_debug_counter(ls_index* ix, int32_t which) {
         return (int64_t)v;
     }
 #endif
-    if (!ix || which < 0 || which > 30) return -1;
+#ifdef LS_LEAD_TRACE
+    if (which >= 40 && which < 48) return (int64_t)g_lead_trace[which - 40].load(std::memory_order_relaxed);
+#endif
+    if (!ix || which < 0 || which > 33) return -1;
     if (which == 16 || which == 17) {
         std::lock_guard<std::mutex> ql(ix->q_mu);
         return (int64_t)(which == 16 ? ix->n_combined_batches : ix->n_combined_requests);
     }
-    if (which >= 28 && which <= 30) {  // the leaders' phase clocks, cumulative ns: waiting + gathering | begin..finish | re-taking the queue's mutex
+    if (which == 33) {  // waiters that went to sleep on their request (more callers than CPUs to poll on, or a long wait)
         std::lock_guard<std::mutex> ql(ix->q_mu);
-        return (int64_t)(which == 28 ? ix->n_lead_wait_ns : which == 29 ? ix->n_lead_call_ns : ix->n_lead_relock_ns);
+        return (int64_t)ix->n_waiter_parks;
+    }
+    if (which >= 28 && which <= 32) {  // the leaders' phase clocks, cumulative ns: waiting + gathering | begin..finish | re-taking the queue's
+                                       // mutex | of begin..finish: the enqueue (serve_begin) | the wait for the results and their copy
+        std::lock_guard<std::mutex> ql(ix->q_mu);
+        return (int64_t)(which == 28 ? ix->n_lead_wait_ns : which == 29 ? ix->n_lead_call_ns : which == 30 ? ix->n_lead_relock_ns :
+                         which == 31 ? ix->n_lead_begin_ns : ix->n_lead_finish_ns);
     }
     std::lock_guard<std::mutex> lk(ix->mu);
     if (ix->group) return ls_group_debug_counter(ix, which);

@@ -79,7 +79,9 @@ struct ls_index {
     uint32_t peak_decay = 0;
     int32_t opt_combine = 1;
     uint64_t n_combined_batches = 0, n_combined_requests = 0;
-    uint64_t n_lead_wait_ns = 0, n_lead_call_ns = 0, n_lead_relock_ns = 0;  // (under q_mu) debug counters 28-30
+    std::atomic<int32_t> spinners{0};  // waiters polling right now (ls_spin_cap: as many as the process has CPUs for)
+    uint64_t n_waiter_parks = 0;       // (under q_mu) debug counter 33
+    uint64_t n_lead_wait_ns = 0, n_lead_call_ns = 0, n_lead_relock_ns = 0, n_lead_begin_ns = 0, n_lead_finish_ns = 0;  // (under q_mu) debug counters 28-30
     // non-null: this handle is a row-sharded GROUP (ls_create_sharded): `n`, `dtype`, `g` and
     // `device` (the primary shard's) describe the whole index, every other member below is unused
     // and the per-device sub-handles live in the group (ls_shard.hip)

@@ -7,6 +7,9 @@
  *   answers: a thread that is still in a call when its next arrival is due starts late, and the latency of that
  *   request counts from its ARRIVAL time), lambda = 5 / 10 / 20 / 40 / 80 k requests/s, with the caller gather
  *   (debug option 20) on and off: achieved q/s, p50, p99 - next to the lone caller's closed-loop p50 / p99. */
+#define _GNU_SOURCE
+#include <sched.h>
+#include <sys/prctl.h>
 #include <string.h>
 #include <dlfcn.h>
 #include <math.h>
@@ -32,24 +35,34 @@ static float gauss(uint64_t* s) {
     return (float)(sqrt(-2.0 * log(u)) * cos(6.283185307179586 * v));
 }
 static int cmp(const void* a, const void* b) { return (*(const double*)a > *(const double*)b) - (*(const double*)a < *(const double*)b); }
-struct job { ls_index* ix; const float* q; int d, k; double stop; long calls; double* lat; long cap; };
+struct job { ls_index* ix; const float* q; int d, k; double stop; long calls; double* lat; long cap; int nq; };
 static void* worker(void* p) {
     struct job* j = p;
-    float* D = malloc(sizeof(float) * j->k);
-    int64_t* I = malloc(sizeof(int64_t) * j->k);
+    float* D = malloc(sizeof(float) * j->k * j->nq);
+    int64_t* I = malloc(sizeof(int64_t) * j->k * j->nq);
     while (now_us() < j->stop) {
         const double t0 = now_us();
-        if (search(j->ix, j->q, 1, j->k, 1u, D, I)) break;
+        if (search(j->ix, j->q, j->nq, j->k, 1u, D, I)) break;
         if (j->calls < j->cap) j->lat[j->calls] = now_us() - t0;
         j->calls++;
+        if (getenv("CALLERS_GAP_US")) {  /* think time between two calls (busy wait): what an idle GPU costs the next call */
+            const double until = now_us() + atof(getenv("CALLERS_GAP_US"));
+            while (now_us() < until) { }
+        }
     }
     free(D); free(I);
+    return NULL;
+}
+static void* burner(void* p) {  /* CALLERS_BURNERS=<n>: n more threads that only spin (what busy cores alone cost the callers) */
+    const double stop = *(double*)p;
+    while (now_us() < stop) { }
     return NULL;
 }
 /* ---- open loop ---------------------------------------------------------------------------------------------- */
 struct ojob { ls_index* ix; const float* q; int d, k; double t0, stop, rate_per_us; uint64_t seed; long calls; double* lat; long cap; };
 static void* open_worker(void* p) {
     struct ojob* j = p;
+    prctl(PR_SET_TIMERSLACK, 1000UL);  /* (1 us instead of the default 50 us of slack on this thread's sleeps) */
     float* D = malloc(sizeof(float) * j->k);
     int64_t* I = malloc(sizeof(int64_t) * j->k);
     uint64_t s = j->seed;
@@ -59,7 +72,16 @@ static void* open_worker(void* p) {
         const double u = ((s >> 11) + 1.0) / 9007199254740993.0;
         arrival += -log(u) / j->rate_per_us;          /* exponential inter-arrival time */
         if (arrival >= j->stop) break;
-        while (now_us() < arrival) { /* idle until the request arrives (a busy wait: sleeping costs tens of us) */ }
+        /* idle until the request arrives: asleep while it is more than 150 us away (16 busy-waiting clients are the whole
+         * 16-CPU quota of the GPU box's container - every row of the first record had a 7-8 ms maximum, the throttle),
+         * polling the clock for the rest (a wake-up is tens of us late) */
+        for (double now = now_us(); now < arrival; now = now_us()) {
+            if (arrival - now > 150.0) {
+                const double us = arrival - now - 100.0;
+                struct timespec ts = {(time_t)(us * 1e-6), (long)(fmod(us, 1e6) * 1e3)};
+                nanosleep(&ts, NULL);
+            }
+        }
         if (search(j->ix, j->q, 1, j->k, 1u, D, I)) break;
         if (j->calls < j->cap) j->lat[j->calls] = now_us() - arrival;   /* from ARRIVAL, not from the call's start */
         j->calls++;
@@ -98,7 +120,7 @@ static int open_loop(ls_index* ix, int (*option)(ls_index*, int32_t, int32_t), c
             printf("open loop N=%lld d=%d k=%d lambda %6.0f/s gather %s: achieved %7.0f q/s, p50 %6.1f us, p99 %6.1f us, p99.9 %7.1f us, max %8.1f us (from arrival)",
                    (long long)n, d, k, lambdas[li], gather ? "on " : "off", total / (dt * 1e-6), m ? all[m / 2] : 0.0, m ? all[(long)(m * 0.99)] : 0.0,
                    m ? all[(long)(m * 0.999)] : 0.0, m ? all[m - 1] : 0.0);
-            if (g_counter) printf("  [2 ms poll timeouts so far %lld, retries %lld]", (long long)g_counter(ix, 27), (long long)g_counter(ix, 20));
+            if (g_counter) printf("  [2 ms poll timeouts so far %lld, retries %lld, waiters put to sleep %lld]", (long long)g_counter(ix, 27), (long long)g_counter(ix, 20), (long long)g_counter(ix, 33));
             printf("\n");
             fflush(stdout);
             free(all);
@@ -123,7 +145,7 @@ int main(int argc, char** argv) {
     const int overlap = argc > 2 && !open_mode ? atoi(argv[2]) : 1;  /* debug option 17: synchronous calls overlap two deep */
     const int gather = argc > 3 && !open_mode ? atoi(argv[3]) : -1;  /* debug option 20: 0 off, 1 long passes only, 2 always (default) */
     const int shapes[2][3] = {{200000, 384, 50}, {200000, 1024, 1000}};
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < (getenv("CALLERS_SHAPES") ? atoi(getenv("CALLERS_SHAPES")) : 2); ++c) {
         const int64_t n = shapes[c][0];
         const int d = shapes[c][1], k = shapes[c][2];
         float* corpus = malloc(sizeof(float) * n * d);
@@ -148,29 +170,51 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 50; ++i) search(ix, q, 1, k, 1u, D, I);
             free(D); free(I);
         }
-        const int Ts[6] = {1, 2, 4, 8, 16, 32};  /* (32: one two-block ls_mq pass carries them all, round 6) */
-        for (int ti = 0; ti < 6; ++ti) {
+        const int nq_each = getenv("CALLERS_NQ") ? atoi(getenv("CALLERS_NQ")) : 1;  /* queries per call (<= 32; 1 = the reference's call) */
+        const int Ts[7] = {1, 2, 4, 8, 16, 32, 64};  /* (32: one two-block ls_mq pass carries them all, round 6) */
+        for (int ti = 0; ti < (getenv("CALLERS_ONLY") ? 7 : 6); ++ti) {  /* (64 callers: only when asked for) */
             const int T = Ts[ti];
+            if (getenv("CALLERS_ONLY") && atoi(getenv("CALLERS_ONLY")) != T) continue;  /* (one caller count: for a profile) */
             for (int rep = 0; rep < (argc > 4 ? atoi(argv[4]) : 2); ++rep) {
-                pthread_t th[32];
-                struct job jobs[32];
+                pthread_t th[64];
+                struct job jobs[64];
                 const double t0 = now_us(), stop = t0 + 0.8e6;
                 for (int t = 0; t < T; ++t) {
-                    jobs[t] = (struct job){ix, q + (size_t)t * d, d, k, stop, 0, malloc(sizeof(double) * 100000), 100000};
+                    jobs[t] = (struct job){ix, q + (size_t)(t * nq_each % 32) * d, d, k, stop, 0, malloc(sizeof(double) * 100000), 100000, nq_each};
                     pthread_create(&th[t], NULL, worker, &jobs[t]);
+                    if (getenv("CALLERS_PIN")) {  /* CALLERS_PIN=<first cpu>: caller t on cpu first + t (one socket, one thread per core) */
+                        cpu_set_t cs; CPU_ZERO(&cs); CPU_SET(atoi(getenv("CALLERS_PIN")) + t, &cs);
+                        pthread_setaffinity_np(th[t], sizeof(cs), &cs);
+                    }
+                }
+                pthread_t bt[64];
+                double bstop = stop;
+                const int nb = getenv("CALLERS_BURNERS") ? atoi(getenv("CALLERS_BURNERS")) : 0;
+                for (int b = 0; b < nb && b < 64; ++b) {
+                    pthread_create(&bt[b], NULL, burner, &bstop);
+                    if (getenv("CALLERS_PIN")) {
+                        cpu_set_t cs; CPU_ZERO(&cs); CPU_SET(atoi(getenv("CALLERS_PIN")) + T + b, &cs);
+                        pthread_setaffinity_np(bt[b], sizeof(cs), &cs);
+                    }
                 }
                 long total = 0;
                 for (int t = 0; t < T; ++t) { pthread_join(th[t], NULL); total += jobs[t].calls; }
                 const double dt = now_us() - t0;
+                for (int b = 0; b < nb && b < 64; ++b) pthread_join(bt[b], NULL);
                 double* all = malloc(sizeof(double) * (size_t)total);
                 long m = 0;
                 for (int t = 0; t < T; ++t) { for (long i = 0; i < jobs[t].calls && i < jobs[t].cap; ++i) all[m++] = jobs[t].lat[i]; free(jobs[t].lat); }
                 qsort(all, m, sizeof(double), cmp);
-                printf("C threads%s N=%lld d=%d k=%d, %2d callers: %8.0f q/s, p50 %.1f us", overlap ? "" : " (no overlap)", (long long)n, d, k, T, total / (dt * 1e-6), m ? all[m / 2] : 0.0);
+                printf("C threads%s N=%lld d=%d k=%d, %2d callers: %8.0f q/s, p50 %.1f us", overlap ? "" : " (no overlap)", (long long)n, d, k, T, total * nq_each / (dt * 1e-6), m ? all[m / 2] : 0.0);
+                if (nq_each > 1) printf(" (%d queries per call)", nq_each);
                 if (getenv("CALLERS_COUNTERS"))  /* cumulative: combined batches, their requests, launches, ls_mq launches, retries, second serves */
-                    printf("   [batches %lld requests %lld launches %lld mq %lld retries %lld reserved %lld | leaders, cumulative us: wait+gather %lld, begin..finish %lld, relock %lld]",
+                    printf("   [batches %lld requests %lld launches %lld mq %lld retries %lld reserved %lld | leaders, cumulative us: wait+gather %lld, begin..finish %lld (begin %lld, finish %lld), relock %lld | waiters put to sleep %lld]",
                            (long long)counter(ix, 16), (long long)counter(ix, 17), (long long)counter(ix, 11), (long long)counter(ix, 23), (long long)counter(ix, 20),
-                           (long long)counter(ix, 25), (long long)counter(ix, 28) / 1000, (long long)counter(ix, 29) / 1000, (long long)counter(ix, 30) / 1000);
+                           (long long)counter(ix, 25), (long long)counter(ix, 28) / 1000, (long long)counter(ix, 29) / 1000, (long long)counter(ix, 31) / 1000, (long long)counter(ix, 32) / 1000, (long long)counter(ix, 30) / 1000, (long long)counter(ix, 33));
+                if (getenv("CALLERS_COUNTERS") && counter(ix, 40) >= 0)  /* (a -DLS_LEAD_TRACE variant of the library) */
+                    printf("\n      leader trace, cumulative us: stage requests %lld | host_call_begin %lld (of it: to the query copy %lld, copy + H2D %lld, launch %lld) | wait for results %lld | hand results out %lld",
+                           (long long)counter(ix, 40) / 1000, (long long)counter(ix, 41) / 1000, (long long)counter(ix, 44) / 1000, (long long)counter(ix, 45) / 1000,
+                           (long long)counter(ix, 46) / 1000, (long long)counter(ix, 42) / 1000, (long long)counter(ix, 43) / 1000);
                 printf("\n");
                 fflush(stdout);
                 free(all);

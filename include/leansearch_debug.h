@@ -72,7 +72,14 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * counter 23: ls_mq launches (small fp32 batches on the f32 matrix cores); counter 24: synchronous host calls
  * that were queued while another one was still in flight; counter 25: queries of ls_mq launches without
  * score vectors that were served again on the scan kernel; counter 26: such repairs skipped because a later
- * pipelined call had been given the same output rows;
+ * pipelined call had been given the same output rows; counter 27: synchronous host calls whose 2 ms poll for the
+ * results expired (they slept in hipStreamSynchronize instead);
+ * counters 28-32, the phase clocks of ls_search's batch leaders, cumulative nanoseconds: 28 waiting for the call in
+ * flight + gathering, 29 begin..finish of their batch, 30 re-taking the queue's mutex, 31 of 29: the enqueue
+ * (staging + launch), 32 of 29: the wait for the results and handing them out; counter 33: waiters that went to
+ * sleep on their request - at most (CPUs of the process: affinity mask, capped by the cgroup's CPU quota) - 3
+ * waiters poll, environment LS_SPIN_CPUS overrides the CPU count (tools/callers_c.c prints all of them with
+ * CALLERS_COUNTERS=1; profiles/ab/r06_open_loop.txt);
  * counters 0, 1, 8, 11, 12 are summed over the shards, 9 and 10 are the primary shard's;
  * counter 16: combined batches ls_search served, 17: the requests they carried; counter 18 (sharded
  * handles): mean host nanoseconds spent queueing one search (every device's work + exchange + merge).

@@ -694,19 +694,24 @@ bool ls_i_batched_eligible(const ls_index* ix, int64_t nq, int32_t k) {
 static int mq_repair(ls_index* ix) {
     if (ix->mq_pend.empty()) return LS_OK;
     if (int rc = ls_i_flush_pending(ix)) return rc;  // the youngest launch's selection jobs
-    std::vector<ls_index::mq_pending_call> pend;
-    pend.swap(ix->mq_pend);
-    hipStream_t last = pend.back().stream;
-    for (const auto& pc : pend)
+    // (the pending list stays in the handle until nothing below can fail before the repairs themselves: an early
+    // return leaves it - and the raised flag word - for the next check)
+    hipStream_t last = ix->mq_pend.back().stream;
+    for (const auto& pc : ix->mq_pend)
         if (pc.stream != last) LS_HIP(hipStreamSynchronize(pc.stream));
     if (ix->pending_stream && ix->pending_stream != last) LS_HIP(hipStreamSynchronize(ix->pending_stream));
-    const size_t used = pend.size() * LS_QUERIES_PER_LAUNCH_MAX;
+    const size_t used = ix->mq_pend.size() * LS_QUERIES_PER_LAUNCH_MAX;
     LS_HIP(hipStreamSynchronize(last));
     u32* any_word = ix->h_mq_flags + LS_MQ_KEEP_SLOTS * LS_QUERIES_PER_LAUNCH_MAX;
-    if (__atomic_load_n(any_word, __ATOMIC_ACQUIRE) == 0u) return LS_OK;  // the common case: no copy, nothing to read
-    __atomic_store_n(any_word, 0u, __ATOMIC_RELEASE);
+    if (__atomic_load_n(any_word, __ATOMIC_ACQUIRE) == 0u) {  // the common case: no copy, nothing to read
+        ix->mq_pend.clear();
+        return LS_OK;
+    }
     LS_HIP(hipMemcpyAsync(ix->h_mq_flags, ix->d_mq_flags, sizeof(u32) * used, hipMemcpyDeviceToHost, last));
     LS_HIP(hipStreamSynchronize(last));
+    __atomic_store_n(any_word, 0u, __ATOMIC_RELEASE);
+    std::vector<ls_index::mq_pending_call> pend;
+    pend.swap(ix->mq_pend);
     bool any = false;
     const bool was = ix->reserving, rep = ix->dev_call_repairable;
     ix->reserving = true;  // (its launches keep their score vectors and are final when they return)

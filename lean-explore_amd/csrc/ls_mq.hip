@@ -288,6 +288,9 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 1) void ls_mq_kernel(
         }
         // (an explicit count: a bare `#pragma unroll` is a request the unroller declines past 16 K instructions - the
         // 64 units x 8 MFMAs of 4 KB rows with two B blocks - and a rolled loop indexes ring / acc dynamically)
+        // (two waves share a SIMD's matrix pipe in the two-block form: the one streaming its tile's MFMAs goes first, the
+        // other's list inserts fill the issue slots behind them - 32 queries, d = 384: 66.3 -> 64.5 us; one block: no change)
+        if (NB == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll NU
         for (int u = 0; u < NU; ++u) {
             const mq_f32x4 x = ring[u % P];
@@ -355,6 +358,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 1) void ls_mq_kernel(
                 }
             }
         }
+        if (NB == 2) __builtin_amdgcn_s_setprio(0);
 #ifdef LS_SCAN_TIMING
         if (tiles_done == 0) LS_MQSTAMP(2);
 #endif

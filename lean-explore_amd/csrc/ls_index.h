@@ -1,5 +1,6 @@
 // ls_index.h — private: the index handle behind include/leansearch.h's opaque `ls_index`, shared by
-// ls_api.hip (single-device orchestration) and ls_shard.hip (the row-sharded group handle).
+// ls_api.hip (single-device orchestration; ls_callers.hip, ls_batched.hip, ls_debug.hip are its other parts) and
+// ls_shard.hip (the row-sharded group handle).
 #pragma once
 #include "ls_common.h"
 
@@ -11,7 +12,7 @@
 #include <vector>
 
 struct ls_shard_group;  // ls_shard.hip
-struct ls_req;          // ls_api.hip: one queued synchronous host search
+struct ls_req;          // ls_callers.hip: one queued synchronous host search
 
 #define LS_NSETS 2
 // Unchecked batched calls a handle carries before it checks them itself (a check drains the pipeline:
@@ -297,6 +298,14 @@ int ls_i_flush_pending(ls_index* ix);
 int ls_i_flush_deferred(ls_index* ix);
 int ls_i_batched_repair(ls_index* ix);
 int ls_i_export_flags(ls_index* ix, void* d_dst, int64_t nq, hipStream_t s);
+int ls_i_grow_score_vectors(ls_index* ix, int need);  // score vectors per scratch generation, grown on demand
+// (ls_batched.hip)
+int64_t ls_i_bc_chunk(const ls_index* ix, int64_t nq, int32_t k);  // queries one batched call takes at once (0: none)
+int ls_i_batched_search_on_stream(ls_index* ix, const float* d_q, int64_t nq, int32_t k, uint32_t flags,
+                                  float* d_out_s, int64_t* d_out_i, hipStream_t s);
+// (what the synchronous host path, ls_callers.hip, asks about a call's shape)
+int ls_i_scan_path_max_nq(const ls_index* ix, int32_t k);            // queries ONE scan-path launch carries at this k
+int64_t ls_i_scan_group_count(const ls_index* ix, int64_t nq, int32_t k);  // launches the scan path cuts nq queries into
 
 // ---- the group handle (ls_shard.hip); every function takes the GROUP's ls_index -----------------
 int ls_group_search(ls_index* ix, const float* q, bool q_on_host, int64_t nq, int32_t k,

@@ -1086,7 +1086,7 @@ static __device__ __forceinline__ void finalize_body(const ls_fin_params& p, uns
         // thread saw; the vote replaces a reduction of the bounds
         done = __syncthreads_and(mb == 0ull || (T != 0ull && mb < T)) != 0;
     }
-    if (!done && (p.wait || (!p.S && p.done))) {  // (no S: an ls_mq launch of a synchronous host call, ls_api.hip)
+    if (!done && (p.wait || (!p.S && p.done))) {  // (no S: an ls_mq launch of a synchronous host call, ls_callers.hip)
         // same-launch job: S is not part of the hand-off (see ls_fin_params::gran). Ask the host
         // for the stand-alone finalize behind this launch instead of reading S here.
         if (tid == 0) {  // (the stand-alone finalize counts the slow path in counters[0])

@@ -319,7 +319,12 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 1) void ls_mq_kernel(
                     } else {
                         c = acc[b][4 * j + m];
                     }
+#ifdef LS_MQ_ABL_NOMFMA  // (ablation: everything but the matrix instruction - wrong results)
+                    c[0] = fmaf(a[m], bv, c[0]);
+                    acc[b][4 * j + m] = c;
+#else
                     acc[b][4 * j + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, c, 0, 0, 0);
+#endif
                 }
             }
             // (the unit's B fragment reads go first: their LDS round trip then runs under the lane swaps. The
@@ -545,7 +550,7 @@ int ls_mq_blocks(int64_t n, int32_t n_cu, int nq, int chunks) {
     const int64_t NT = (n + 15) / 16;
     constexpr int tpw = 2;  // at least this many tiles per wave on small shards
     const int64_t b = (NT + wpb * tpw - 1) / (wpb * tpw);
-    const int64_t cap = wpb == LS_MQ_WAVES2 ? std::max(8, n_cu - LS_FIN_WG_MAX) : n_cu;
+    const int64_t cap = nq > LS_MQ_NQ ? std::max(8, n_cu - LS_FIN_WG_MAX) : n_cu;
     // (big shards: ONE workgroup per CU. tools/mq_blocks_sweep.py, N = 200 k, 16 queries, d = 384 / 768 / 1024:
     //  256 workgroups 60.3 / 128.6 / 167.0 us, 448: 67.2 / 140.9 / 179.7, 512: 65.0 / 137.0 / 176.9,
     //  768: 65.9 / 140.3 / 181.0 - four waves per CU with 12-16 KB in flight each already carry the HBM

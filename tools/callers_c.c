@@ -35,7 +35,7 @@ static float gauss(uint64_t* s) {
     return (float)(sqrt(-2.0 * log(u)) * cos(6.283185307179586 * v));
 }
 static int cmp(const void* a, const void* b) { return (*(const double*)a > *(const double*)b) - (*(const double*)a < *(const double*)b); }
-struct job { ls_index* ix; const float* q; int d, k; double stop; long calls; double* lat; long cap; int nq; };
+struct job { ls_index* ix; const float* q; int d, k; double stop; long calls; double* lat; long cap; int nq; const float* wantD; const int64_t* wantI; long bad; };
 static void* worker(void* p) {
     struct job* j = p;
     float* D = malloc(sizeof(float) * j->k * j->nq);
@@ -45,6 +45,8 @@ static void* worker(void* p) {
         if (search(j->ix, j->q, j->nq, j->k, 1u, D, I)) break;
         if (j->calls < j->cap) j->lat[j->calls] = now_us() - t0;
         j->calls++;
+        /* CALLERS_VERIFY=1: every call's rows against the lone call's, bit for bit */
+        if (j->wantD && (memcmp(D, j->wantD, sizeof(float) * j->k * j->nq) || memcmp(I, j->wantI, sizeof(int64_t) * j->k * j->nq))) j->bad++;
         if (getenv("CALLERS_GAP_US")) {  /* think time between two calls (busy wait): what an idle GPU costs the next call */
             const double until = now_us() + atof(getenv("CALLERS_GAP_US"));
             while (now_us() < until) { }
@@ -171,6 +173,12 @@ int main(int argc, char** argv) {
             free(D); free(I);
         }
         const int nq_each = getenv("CALLERS_NQ") ? atoi(getenv("CALLERS_NQ")) : 1;  /* queries per call (<= 32; 1 = the reference's call) */
+        float* wantD = NULL; int64_t* wantI = NULL;
+        if (getenv("CALLERS_VERIFY")) {  /* the lone calls' answers for the 32 queries */
+            wantD = malloc(sizeof(float) * 64 * k); wantI = malloc(sizeof(int64_t) * 64 * k);
+            for (int i = 0; i < 32; ++i) search(ix, q + (size_t)i * d, 1, k, 1u, wantD + (size_t)i * k, wantI + (size_t)i * k);
+            memcpy(wantD + (size_t)32 * k, wantD, sizeof(float) * 32 * k); memcpy(wantI + (size_t)32 * k, wantI, sizeof(int64_t) * 32 * k);
+        }
         const int Ts[7] = {1, 2, 4, 8, 16, 32, 64};  /* (32: one two-block ls_mq pass carries them all, round 6) */
         for (int ti = 0; ti < (getenv("CALLERS_ONLY") ? 7 : 6); ++ti) {  /* (64 callers: only when asked for) */
             const int T = Ts[ti];
@@ -180,7 +188,8 @@ int main(int argc, char** argv) {
                 struct job jobs[64];
                 const double t0 = now_us(), stop = t0 + 0.8e6;
                 for (int t = 0; t < T; ++t) {
-                    jobs[t] = (struct job){ix, q + (size_t)(t * nq_each % 32) * d, d, k, stop, 0, malloc(sizeof(double) * 100000), 100000, nq_each};
+                    jobs[t] = (struct job){ix, q + (size_t)(t * nq_each % 32) * d, d, k, stop, 0, malloc(sizeof(double) * 100000), 100000, nq_each,
+                                             wantD ? wantD + (size_t)(t * nq_each % 32) * k : NULL, wantI ? wantI + (size_t)(t * nq_each % 32) * k : NULL, 0};
                     pthread_create(&th[t], NULL, worker, &jobs[t]);
                     if (getenv("CALLERS_PIN")) {  /* CALLERS_PIN=<first cpu>: caller t on cpu first + t (one socket, one thread per core) */
                         cpu_set_t cs; CPU_ZERO(&cs); CPU_SET(atoi(getenv("CALLERS_PIN")) + t, &cs);
@@ -197,8 +206,8 @@ int main(int argc, char** argv) {
                         pthread_setaffinity_np(bt[b], sizeof(cs), &cs);
                     }
                 }
-                long total = 0;
-                for (int t = 0; t < T; ++t) { pthread_join(th[t], NULL); total += jobs[t].calls; }
+                long total = 0, bad = 0;
+                for (int t = 0; t < T; ++t) { pthread_join(th[t], NULL); total += jobs[t].calls; bad += jobs[t].bad; }
                 const double dt = now_us() - t0;
                 for (int b = 0; b < nb && b < 64; ++b) pthread_join(bt[b], NULL);
                 double* all = malloc(sizeof(double) * (size_t)total);
@@ -207,6 +216,7 @@ int main(int argc, char** argv) {
                 qsort(all, m, sizeof(double), cmp);
                 printf("C threads%s N=%lld d=%d k=%d, %2d callers: %8.0f q/s, p50 %.1f us", overlap ? "" : " (no overlap)", (long long)n, d, k, T, total * nq_each / (dt * 1e-6), m ? all[m / 2] : 0.0);
                 if (nq_each > 1) printf(" (%d queries per call)", nq_each);
+                if (wantD) printf(" [calls that differ from the lone call: %ld of %ld]", bad, total);
                 if (getenv("CALLERS_COUNTERS"))  /* cumulative: combined batches, their requests, launches, ls_mq launches, retries, second serves */
                     printf("   [batches %lld requests %lld launches %lld mq %lld retries %lld reserved %lld | leaders, cumulative us: wait+gather %lld, begin..finish %lld (begin %lld, finish %lld), relock %lld | waiters put to sleep %lld]",
                            (long long)counter(ix, 16), (long long)counter(ix, 17), (long long)counter(ix, 11), (long long)counter(ix, 23), (long long)counter(ix, 20),

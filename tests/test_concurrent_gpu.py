@@ -216,3 +216,53 @@ def test_more_than_sixteen_callers_share_wide_passes_and_stay_exact():
               ix.debug_counter(11) - before_launches)
     finally:
         ix.close()
+
+
+_SLEEPERS = r"""
+import sys, threading
+import numpy as np
+sys.path.insert(0, {root!r})
+from lean_explore_amd.index import FlatIPIndex
+from tests import helpers as H
+n, d, T, per = 100_000, 384, 24, 30
+ix = FlatIPIndex.from_array(H.gauss(93, n, d))
+pool = H.gauss(94, 64, d, normalize=False)
+ix.search(pool[:1], 10)
+ix.debug_option(10, 0)
+want = {{qi: ix.search(pool[qi:qi + 1], 50, normalize=True) for qi in range(64)}}
+ix.debug_option(10, 1)
+bad = []
+def worker(t):
+    rng = np.random.default_rng(t)
+    for j in range(per):
+        qi = int(rng.integers(64))
+        D, I = ix.search(pool[qi:qi + 1], 50, normalize=True)
+        if not (np.array_equal(D, want[qi][0]) and np.array_equal(I, want[qi][1])):
+            bad.append((t, j, qi))
+th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+[x.start() for x in th]; [x.join() for x in th]
+print("RESULT", len(bad), ix.debug_counter(16), ix.debug_counter(17), ix.debug_counter(33))
+ix.close()
+"""
+
+
+def test_sleeping_waiters_are_woken_by_their_batch_and_stay_exact():
+    """Round 6: only as many waiters poll as the process has CPUs for (affinity mask, cgroup quota; LS_SPIN_CPUS
+    overrides), the others sleep on their OWN request and are woken by the thread that finished their batch. With
+    LS_SPIN_CPUS=2 ONE waiter may poll (max(1, cpus - 3)): 24 callers, nearly every one asleep while
+    it waits - all of them must come back, with exactly their own call's rows (the variable is read once per process:
+    a subprocess)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LS_SPIN_CPUS="2")
+    out = subprocess.run([sys.executable, "-c", _SLEEPERS.format(root=root)], env=env, capture_output=True, text=True, timeout=300)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+    assert line, out.stdout[-2000:] + out.stderr[-2000:]
+    bad, batches, requests, parks = (int(x) for x in line[0].split()[1:])
+    assert bad == 0
+    assert batches >= 1 and requests > batches, (batches, requests)
+    assert parks > 0, "no waiter went to sleep although one CPU was allowed to poll"
+    print("24 callers, LS_SPIN_CPUS=2:", requests, "requests in", batches, "batches,", parks, "waiters put to sleep")

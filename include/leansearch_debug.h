@@ -49,6 +49,8 @@ int ls_last_kernel_ms(ls_index* index, float* scan_ms, float* total_ms);
  * to a third of a call, at most 60 us, for the callers seen lately - instead of two passes at once on the two
  * host slots (default on; 0 off: option 17's two-deep overlap decides); option 21: callers up to which a
  * second batch may go early when option 20 allows it (default 8);
+ * option 23: concurrent ls_search callers - a queue that alone fills a pass (32 requests on an fp32 index) is launched at once
+ * behind the call in flight, on the other host slot (default on);
  * option 22: fp32 index, one ls_mq pass carries up to 32 queries (two MFMA B blocks per A operand; default on;
  * 0: 16 per pass - same bits);
  * option 19: launches of synchronous host calls (ls_scan and ls_mq) and ls_mq launches of pipelined /

@@ -571,8 +571,13 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
         // (round 5, second step: the slots have their own streams, so a second batch may also go early when
         // EVERY caller the handle has seen lately is either in the running batch or already queued - waiting
         // for the running call could add nobody; `peak_callers` is a slowly decaying maximum of that count)
+        // (round 6, more than 32 callers: once the queue alone fills a pass nobody can join this batch any more - it is
+        // queued at once behind the running one, on the other slot: the GPU goes from pass to pass. 64 C-thread callers, same
+        // box: d = 384 131 -> 151-174 k q/s, d = 1024 k = 1000 77 -> 148 k (p50 787 -> 400 us); 32 callers unchanged; debug option 23)
+        const int64_t full_pass = ls_i_scan_path_max_nq(ix, ix->req_q.front()->k);
         auto go_early = [&]() {
             const int64_t total = ix->requests_in_flight + (int64_t)ix->req_q.size();
+            if (ix->opt_overlap_calls && ix->opt_full_early && ix->calls_in_flight < LS_HOST_SLOTS && (int64_t)ix->req_q.size() >= full_pass) return true;
             // (up to 8 callers: with more, the two halves are big passes that only slow each other down -
             // 16 callers 76.5 k early vs 81.2 k waiting, 8 callers 51.4 k vs 45.9 k, 4 callers 32.9 k vs 25.6 k)
             // (long passes - d = 1024: 140 us - gain nothing from running two at once, they share one HBM; their
@@ -600,7 +605,8 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             const auto t0 = std::chrono::steady_clock::now();
             for (unsigned it = 0; !changed; ++it) {
                 for (int i = 0; i < 32; ++i) ls_cpu_relax();
-                changed = ep.load(std::memory_order_acquire) != seen;
+                // (... or the queue has grown to a full pass: read through the arrivals' atomic, not through the mutex)
+                changed = ep.load(std::memory_order_acquire) != seen || ix->q_len.load(std::memory_order_acquire) >= full_pass;
                 if ((it & 15) == 15 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
             }
             q_lock(lk);

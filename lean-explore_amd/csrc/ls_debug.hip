@@ -105,6 +105,10 @@ int ls_debug_option(ls_index* ix, int32_t which, int32_t value) {
         if (!value && ix->d_corpus) return ls_i_grow_score_vectors(ix, LS_QUERIES_PER_LAUNCH_MAX);
         return LS_OK;
     }
+    if (which == 23) {  // ls_search: a queue that alone fills a pass is launched at once behind the call in flight (default on)
+        ix->opt_full_early = value != 0;
+        return LS_OK;
+    }
     if (which == 17) {  // synchronous host calls overlap two deep (default on)
         ix->opt_overlap_calls = value != 0;
         return LS_OK;

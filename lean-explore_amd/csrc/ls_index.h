@@ -198,6 +198,7 @@ struct ls_index {
     uint64_t n_mq_skipped_repairs = 0; // ... whose output rows a later pipelined call had been given meanwhile (counter 26)
     // (read under q_mu by ls_search, written under the handle's mutex by ls_debug_option: atomics)
     std::atomic<int32_t> opt_early_cap{8};   // ls_search: callers up to which a second batch goes early (debug option 21)
+    std::atomic<int32_t> opt_full_early{1};  // ls_search: a queue that fills a pass goes at once behind the call in flight (debug option 23)
     std::atomic<int32_t> opt_gather{1};      // ls_search: concurrent callers are gathered into one pass (debug option 20)
     double call_us_est = 0.0;          // running estimate of one combined call, begin to finish (under q_mu)
     bool reserving = false;            // (that second serve is being queued: its selection takes its own launch)

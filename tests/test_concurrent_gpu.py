@@ -175,12 +175,14 @@ def test_callers_of_long_passes_are_gathered_and_stay_exact():
     ix.close()
 
 
-def test_more_than_sixteen_callers_share_wide_passes_and_stay_exact():
+@pytest.mark.parametrize("T", [28, 44])
+def test_more_than_sixteen_callers_share_wide_passes_and_stay_exact(T):
     """Round 6: one ls_mq pass carries up to 32 queries (two MFMA B blocks), so 28 concurrent single-query callers -
-    some bringing three queries - are served in passes of 17..32. Every caller must get exactly what its own
+    some bringing three queries - are served in passes of 17..32; with 44, a queue that alone fills a pass is
+    launched behind the call in flight (two host slots). Every caller must get exactly what its own
     separate call returns, bit for bit, whatever company it rode in (reference: index.search from several MCP
     clients, search/engine.py:250, mcp/server.py:147-151)."""
-    n, d, T, per = 100_000, 384, 28, 25
+    n, d, per = 100_000, 384, 25
     corpus = H.gauss(91, n, d)
     pool = H.gauss(92, 96, d, normalize=False)
     ix = FlatIPIndex.from_array(corpus)
@@ -212,7 +214,7 @@ def test_more_than_sixteen_callers_share_wide_passes_and_stay_exact():
         assert not errors, errors[:5]
         batches, requests = ix.debug_counter(16), ix.debug_counter(17)
         assert batches >= 1 and requests > 2 * batches, (batches, requests)
-        print("28 callers:", requests, "requests in", batches, "combined batches;", ix.debug_counter(23) - before_mq, "ls_mq launches of",
+        print(T, "callers:", requests, "requests in", batches, "combined batches;", ix.debug_counter(23) - before_mq, "ls_mq launches of",
               ix.debug_counter(11) - before_launches)
     finally:
         ix.close()

@@ -166,6 +166,7 @@ int main(int argc, char** argv) {
         option(ix, 17, overlap);
         if (gather >= 0) option(ix, 20, gather);
         if (getenv("CALLERS_OPT22")) option(ix, 22, atoi(getenv("CALLERS_OPT22")));  /* debug option 22: 32 (1, default) or 16 (0) queries per ls_mq pass */
+        if (getenv("CALLERS_OPT23")) option(ix, 23, atoi(getenv("CALLERS_OPT23")));  /* debug option 23: a queue that fills a pass goes early (default 1) */
         if (argc > 5) option(ix, 21, atoi(argv[5]));  /* debug option 21: callers up to which a second batch goes early */
         {
             float* D = malloc(sizeof(float) * k); int64_t* I = malloc(sizeof(int64_t) * k);

@@ -34,6 +34,38 @@ def test_embed_shapes_norms_and_prompt(embedder):
     assert not np.allclose(q, e, atol=1e-3)  # the query prompt changes the encoding
 
 
+def test_query_prompt_is_what_prompt_name_query_sends():
+    """Reference util/embedding_client.py:90-99: `model.encode(texts, prompt_name="query")` only when is_query - sentence-
+    transformers then PREPENDS prompts["query"] of the model's config to every text, and nothing to documents
+    (Qwen3-Embedding's config_sentence_transformers.json: "Instruct: Given a web search query, retrieve relevant passages
+    that answer the query\nQuery:"). Pinned here: the exact strings the tokenizer receives, batch by batch (the
+    reference's batch size 8 and LEAN_EXPLORE_EMBEDDING_BATCH_SIZE, :13,49-52), and that embed() passes is_query on."""
+    from lean_explore_amd.util.embedding_client import DEFAULT_BATCH_SIZE, QUERY_PROMPT
+
+    assert QUERY_PROMPT == ("Instruct: Given a web search query, retrieve relevant passages that answer the query\nQuery:")
+    assert DEFAULT_BATCH_SIZE == 8
+    seen = []
+    inner = HashTokenizer(512)
+
+    class Recording:
+        def __call__(self, texts, **kw):
+            seen.append((list(texts), kw.get("padding"), kw.get("truncation"), kw.get("max_length")))
+            return inner(texts, **kw)
+
+    emb = EmbeddingClient("tiny-random-qwen3", device="cpu", max_length=32, batch_size=2,
+                          model=random_qwen3(seed=1, **TINY), tokenizer=Recording())
+    docs = ["continuous function", "prime number", "Nat.add_comm"]
+    emb.encode(docs)
+    assert [t for t, *_ in seen] == [docs[:2], docs[2:]]  # documents: no prompt, batches of batch_size
+    assert all(pad is True and trunc is True and ml == 32 for _, pad, trunc, ml in seen)
+    seen.clear()
+    run(emb.embed(docs[:1], is_query=True))
+    assert [t for t, *_ in seen] == [[QUERY_PROMPT + docs[0]]]  # queries: the config's prompt, prepended verbatim
+    seen.clear()
+    run(emb.embed(docs[:1]))
+    assert [t for t, *_ in seen] == [[docs[0]]]  # is_query defaults to False (documents), as in the reference
+
+
 def test_embed_is_independent_of_batch_composition(embedder):
     """Left padding + last-token pooling: a text's vector must not depend on its batch mates."""
     texts = ["x y z", "one two three four five six seven eight", "p", "q r"]

@@ -353,12 +353,13 @@ static int host_search_locked(ls_index* ix, const float* q, int64_t nq, int32_t 
 // ---- combining concurrent callers ---------------------------------------------------------------
 // The reference's event loop makes one blocking index.search per query (search/engine.py:250), but
 // an MCP server with several clients, or a threaded caller, has several of them in flight. The scan
-// path serves up to 16 queries per corpus pass (fp32: ls_mq.hip, ~60 us for 16 at N = 200 k; one query
-// alone: 47 us), so requests that arrive while a search is running are not queued behind the mutex one by
+// path serves up to 32 queries per corpus pass (fp32: ls_mq.hip, ~50 us for 16, ~65 us for 32 at N = 200 k; one
+// query alone: 47 us), so requests that arrive while a search is running are not queued behind the mutex one by
 // one: they wait in a queue, and whoever holds the leadership serves ALL compatible waiters (same k, same
-// flags, <= LS_SCAN_PATH_MAX_NQ queries in total) as ONE batch, then hands their results back. A lone
-// caller becomes leader at once and pays nothing; waiters sleep on a condition variable (no
-// spinning on the mutex). Round 5: the leadership is released as soon as the batch's launch is QUEUED
+// flags, as many queries as one launch carries: ls_i_scan_path_max_nq) as ONE batch, then hands their results
+// back. A lone caller becomes leader at once and pays nothing; waiters poll their own request's flag (as many of
+// them as the process has CPUs for) or sleep on its condition variable (round 6, ls_spin_cap). Round 5: the
+// leadership is released as soon as the batch's launch is QUEUED
 // (host_call_begin), so the next leader queues the requests that arrived meanwhile behind it while the
 // first one polls for its answers. Results are those of the separate calls: every query's arithmetic
 // is the same whatever group it rides in.

@@ -1,12 +1,18 @@
 /* callers_c.c - T threads making synchronous single-query ls_search calls on ONE handle (the reference's call,
  * search/engine.py:250, issued by several MCP clients, mcp/server.py:147-151), timed from C: what the library's
  * caller combining delivers without the Python threads' GIL hand-offs that tools/concurrent_callers.py includes.
- *   gcc -O2 tools/callers_c.c -o scratch/callers_c -ldl -lm -lpthread && ./scratch/callers_c lean-explore_amd/libleansearch.so [overlap [gather [reps]]]
- * Round 6, OPEN LOOP (verdict item 4):  ./scratch/callers_c lib open [seconds per point]
+ *   gcc -O2 tools/callers_c.c -o /tmp/callers_c -ldl -lm -lpthread && /tmp/callers_c lean-explore_amd/libleansearch.so [overlap [gather [reps]]]
+ * Round 6, OPEN LOOP (verdict item 4):  /tmp/callers_c lib open [seconds per point]
  *   16 client threads, each a Poisson process of rate lambda / 16 (arrival times drawn ahead, independent of the
  *   answers: a thread that is still in a call when its next arrival is due starts late, and the latency of that
  *   request counts from its ARRIVAL time), lambda = 5 / 10 / 20 / 40 / 80 k requests/s, with the caller gather
- *   (debug option 20) on and off: achieved q/s, p50, p99 - next to the lone caller's closed-loop p50 / p99. */
+ *   (debug option 20) on and off: achieved q/s, p50, p99 - next to the lone caller's closed-loop p50 / p99. The clients sleep
+ *   while their next arrival is > 150 us away (16 busy-waiting clients would be the whole CPU quota of the GPU box's container).
+ * Closed-loop switches (environment): CALLERS_ONLY=<T> one caller count (64 only this way) | CALLERS_SHAPES=1 the d = 384 shape only |
+ *   CALLERS_NQ=<n> queries per call | CALLERS_COUNTERS=1 print the handle's cumulative counters (batches, requests, launches, the
+ *   leaders' phase clocks 28-33; with a -DLS_LEAD_TRACE variant also counters 40-47) | CALLERS_VERIFY=1 every call's rows memcmp'd
+ *   with the lone call's | CALLERS_PIN=<cpu> caller t on cpu + t | CALLERS_BURNERS=<n> n more threads that only spin |
+ *   CALLERS_GAP_US=<us> think time between two calls | CALLERS_OPT22 / CALLERS_OPT23 = debug options 22 / 23. */
 #define _GNU_SOURCE
 #include <sched.h>
 #include <sys/prctl.h>

@@ -1,6 +1,6 @@
 /* hostapi_c.c - the reference's call (index.search on host arrays, search/engine.py:250) timed from C, no
  * Python / ctypes in the loop: separates library time from interpreter time for host_api.c2 / c2p.
- *   gcc -O2 tools/hostapi_c.c -o scratch/hostapi_c -ldl -lm && ./scratch/hostapi_c lean-explore_amd/libleansearch.so */
+ *   gcc -O2 tools/hostapi_c.c -o /tmp/hostapi_c -ldl -lm && /tmp/hostapi_c lean-explore_amd/libleansearch.so */
 #include <dlfcn.h>
 #include <math.h>
 #include <stdint.h>

@@ -529,9 +529,16 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             // woken at once): poll for a while before sleeping (round 5)
             const uint64_t seen = ix->lead_epoch.load(std::memory_order_acquire);
             const double spin_us = std::min(LS_WAITER_SPIN_MAX_US, std::max(LS_WAITER_SPIN_MIN_US, 2.0 * ix->call_us_est));
+            // (... and fewer pollers the more callers there are beyond the CPUs: 64 callers on the 16-CPU box, pollers
+            // 13 / 8 / 4 / 2 / 1: 149 / 171 / 197 / 211 / 197 k q/s - the pollers stood in the way of the callers that
+            // were waking up; 8-32 callers are within 5-10 % of each other for every cap, 13 the best: half a poller
+            // less per caller beyond the CPU count, two at least)
+            const int cap = ls_spin_cap();
+            const int64_t beyond = std::max<int64_t>(0, ix->peak_callers - (cap + 3));
+            const int pollers = (int)std::max<int64_t>(std::min(2, cap), cap - beyond / 2);
             lk.unlock();
             bool changed = false;
-            const bool may_spin = ix->spinners.fetch_add(1, std::memory_order_relaxed) < ls_spin_cap();  // (a CPU to poll on)
+            const bool may_spin = ix->spinners.fetch_add(1, std::memory_order_relaxed) < pollers;  // (a CPU to poll on)
             const auto t0 = std::chrono::steady_clock::now();
             for (unsigned it = 0; may_spin && !changed; ++it) {
                 for (int i = 0; i < 32; ++i) ls_cpu_relax();

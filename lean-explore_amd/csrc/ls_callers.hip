@@ -608,13 +608,17 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             std::atomic<uint64_t>& ep = arrivals_matter ? ix->q_epoch : ix->lead_epoch;
             const uint64_t seen = ep.load(std::memory_order_acquire);  // (as above: poll, then sleep)
             const double spin_us = std::min(LS_WAITER_SPIN_MAX_US, std::max(LS_WAITER_SPIN_MIN_US, 2.0 * ix->call_us_est));
+            // (a full queue matters only while a host slot is free: with both in flight - more than three passes' worth of
+            // callers - it would end every poll at once and send this leader round and round through the mutex)
+            const bool full_matters = ix->opt_overlap_calls && ix->opt_full_early && ix->calls_in_flight < LS_HOST_SLOTS;
             lk.unlock();
             bool changed = false;
             const auto t0 = std::chrono::steady_clock::now();
             for (unsigned it = 0; !changed; ++it) {
                 for (int i = 0; i < 32; ++i) ls_cpu_relax();
                 // (... or the queue has grown to a full pass: read through the arrivals' atomic, not through the mutex)
-                changed = ep.load(std::memory_order_acquire) != seen || ix->q_len.load(std::memory_order_acquire) >= full_pass;
+                changed = ep.load(std::memory_order_acquire) != seen ||
+                          (full_matters && ix->q_len.load(std::memory_order_acquire) >= full_pass);
                 if ((it & 15) == 15 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
             }
             q_lock(lk);

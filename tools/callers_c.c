@@ -8,7 +8,7 @@
  *   request counts from its ARRIVAL time), lambda = 5 / 10 / 20 / 40 / 80 k requests/s, with the caller gather
  *   (debug option 20) on and off: achieved q/s, p50, p99 - next to the lone caller's closed-loop p50 / p99. The clients sleep
  *   while their next arrival is > 150 us away (16 busy-waiting clients would be the whole CPU quota of the GPU box's container).
- * Closed-loop switches (environment): CALLERS_ONLY=<T> one caller count (64 only this way) | CALLERS_SHAPES=1 the d = 384 shape only |
+ * Closed-loop switches (environment): CALLERS_ONLY=<T> one caller count (64 and 128 only this way) | CALLERS_SHAPES=1 the d = 384 shape only |
  *   CALLERS_NQ=<n> queries per call | CALLERS_COUNTERS=1 print the handle's cumulative counters (batches, requests, launches, the
  *   leaders' phase clocks 28-33; with a -DLS_LEAD_TRACE variant also counters 40-47) | CALLERS_VERIFY=1 every call's rows memcmp'd
  *   with the lone call's | CALLERS_PIN=<cpu> caller t on cpu + t | CALLERS_BURNERS=<n> n more threads that only spin |
@@ -186,13 +186,13 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 32; ++i) search(ix, q + (size_t)i * d, 1, k, 1u, wantD + (size_t)i * k, wantI + (size_t)i * k);
             memcpy(wantD + (size_t)32 * k, wantD, sizeof(float) * 32 * k); memcpy(wantI + (size_t)32 * k, wantI, sizeof(int64_t) * 32 * k);
         }
-        const int Ts[7] = {1, 2, 4, 8, 16, 32, 64};  /* (32: one two-block ls_mq pass carries them all, round 6) */
-        for (int ti = 0; ti < (getenv("CALLERS_ONLY") ? 7 : 6); ++ti) {  /* (64 callers: only when asked for) */
+        const int Ts[8] = {1, 2, 4, 8, 16, 32, 64, 128};  /* (32: one two-block ls_mq pass carries them all, round 6) */
+        for (int ti = 0; ti < (getenv("CALLERS_ONLY") ? 8 : 6); ++ti) {  /* (64 / 128 callers: only when asked for) */
             const int T = Ts[ti];
             if (getenv("CALLERS_ONLY") && atoi(getenv("CALLERS_ONLY")) != T) continue;  /* (one caller count: for a profile) */
             for (int rep = 0; rep < (argc > 4 ? atoi(argv[4]) : 2); ++rep) {
-                pthread_t th[64];
-                struct job jobs[64];
+                pthread_t th[128];
+                struct job jobs[128];
                 const double t0 = now_us(), stop = t0 + 0.8e6;
                 for (int t = 0; t < T; ++t) {
                     jobs[t] = (struct job){ix, q + (size_t)(t * nq_each % 32) * d, d, k, stop, 0, malloc(sizeof(double) * 100000), 100000, nq_each,

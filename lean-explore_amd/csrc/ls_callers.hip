@@ -557,7 +557,8 @@ int ls_search(ls_index* ix, const float* q, int64_t nq, int32_t k, uint32_t flag
             // leader that hands the leadership on wakes it if it heads the queue; nobody is woken for anything else.
             // (Checked under the mutex both wakers hold: a taken request sleeps until it is done, a queued one while
             // somebody leads.)
-            if (!me.done.load(std::memory_order_acquire) && (me.taken.load(std::memory_order_relaxed) || ix->leader_active)) {
+            // (a poller that saw the leadership change and lost the race for it goes on polling: `changed`)
+            if (!changed && !me.done.load(std::memory_order_acquire) && (me.taken.load(std::memory_order_relaxed) || ix->leader_active)) {
                 me.parked = true;
                 ix->n_waiter_parks++;
                 me.cv.wait(lk);
